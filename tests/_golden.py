@@ -1,0 +1,53 @@
+"""Helpers shared by the CPU (oracle) and GPU (HIP) parity tests."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List
+
+import numpy as np
+
+from oracle.golden_cases import CASES, case_by_name  # noqa: F401
+from oracle.kaldi_ref import RefConfig
+from oracle.signals import crc, make_signal
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(name: str):
+    """-> (case dict, list of input waveforms, npz dict)"""
+    case = case_by_name(name)
+    z = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    sr = case["cfg"].get("sampling_rate", 16000)
+    waves = [make_signal(k, n, seed, sr) for k, n, seed in case["inputs"]]
+    for i, w in enumerate(waves):
+        assert crc(w) == int(z[f"crc{i}"]), f"input {i} of golden case {name} drifted"
+    return case, waves, z
+
+
+def ref_config(case) -> RefConfig:
+    cfg = dict(case["cfg"])
+    if case["kind"] == "mfcc":
+        cfg.setdefault("num_filters", 23)  # MfccConfig default (extractors.py:172)
+    return RefConfig(kind=case["kind"], **cfg)
+
+
+def golden_rows(z: Dict[str, np.ndarray], i: int, got: np.ndarray):
+    """Return (got_rows, want_rows) restricted to the rows the fixture stores."""
+    shape = tuple(int(s) for s in z[f"shape{i}"])
+    assert tuple(got.shape) == shape, f"shape {got.shape} != golden {shape}"
+    if f"out{i}" in z:
+        return got, z[f"out{i}"]
+    h, t = z[f"head{i}"], z[f"tail{i}"]
+    return np.concatenate([got[: len(h)], got[-len(t) :]]), np.concatenate([h, t])
+
+
+def err_stats(got: np.ndarray, want: np.ndarray) -> Dict[str, float]:
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    d = got - want
+    den = np.linalg.norm(want)
+    return {
+        "max_abs": float(np.abs(d).max()) if d.size else 0.0,
+        "rel_l2": float(np.linalg.norm(d) / den) if den > 0 else float(np.linalg.norm(d)),
+        "frac_within": float(np.mean(np.abs(d) <= 1e-3 + 1e-4 * np.abs(want))) if d.size else 1.0,
+    }

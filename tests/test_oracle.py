@@ -1,0 +1,132 @@
+"""
+CPU tests that PIN the oracle (oracle/kaldi_ref.py) to the reference:
+  * every golden case produced by the reference itself (tests/golden, oracle/make_golden.py),
+  * the known-answer table of SURVEY.md section 8c,
+  * the shape goldens of the reference's own tests (test/features/test_kaldi_layers.py:21-66,
+    test/features/test_kaldi_features.py:92-128),
+  * (authoring container only) a live comparison against /root/reference.
+"""
+import numpy as np
+import pytest
+
+from _golden import CASES, err_stats, golden_rows, load_case, ref_config
+from oracle import kaldi_ref as K
+from oracle.kaldi_ref import RefConfig, RefExtractor
+
+CASE_NAMES = [c["name"] for c in CASES]
+
+
+def run_oracle(case, waves, dtype):
+    ex = RefExtractor(ref_config(case), dtype)
+    if case["mode"] == "extract":
+        return [ex.extract(w) for w in waves]
+    return ex.extract_batch(waves, "batch_zero_pad")
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_oracle_matches_reference_golden(name):
+    case, waves, z = load_case(name)
+    out32 = run_oracle(case, waves, np.float32)
+    out64 = run_oracle(case, waves, np.float64)
+    for i, (o32, o64) in enumerate(zip(out32, out64)):
+        got, want = golden_rows(z, i, o32)
+        truth, _ = golden_rows(z, i, o64)
+        s = err_stats(got, want)
+        floor = err_stats(want, truth)  # the reference's own float32 error vs float64 arithmetic
+        assert s["rel_l2"] <= max(1e-4, 3 * floor["rel_l2"]), (name, i, s, floor)
+        assert s["max_abs"] <= max(2e-3, 3 * floor["max_abs"]), (name, i, s, floor)
+        assert abs(float(o32.astype(np.float64).sum()) - float(z[f"sum{i}"])) <= 1e-4 * max(1.0, np.abs(o32).sum())
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_oracle_constants_match_reference(name):
+    case, _, z = load_case(name)
+    ex = RefExtractor(ref_config(case), np.float32)
+    assert ex.fft == int(z["fft_length"])
+    np.testing.assert_allclose(ex.window, z["window"], rtol=0, atol=5e-7)
+    if "fb" in z:
+        assert ex.fb.shape == z["fb"].shape
+        np.testing.assert_allclose(ex.fb, z["fb"], rtol=0, atol=1e-6)
+    if "dct" in z:
+        np.testing.assert_allclose(ex.dct, z["dct"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(ex.lifter, z["lifter"], rtol=0, atol=5e-6)
+
+
+def test_known_answer_tripwires():
+    """SURVEY.md section 8c (values printed by the reference on torch 2.10 CPU)."""
+    x = K.tripwire_signal()
+    y = RefExtractor(RefConfig(kind="fbank"), np.float32).extract(x)
+    assert y.shape == (100, 80)
+    np.testing.assert_allclose(y[0, :4], [-4.480583, -3.873957, -3.635004, -3.326463], atol=2e-4)
+    np.testing.assert_allclose(y[50, 10:14], [-4.822061, -2.874318, -1.147494, 3.102133], atol=2e-4)
+    np.testing.assert_allclose(y[99, 76:], [-3.093771, -3.463164, -3.919509, -4.527234], atol=2e-4)
+    assert abs(float(y.astype(np.float64).sum()) - (-79468.177)) < 1.0
+    m = RefExtractor(RefConfig(kind="mfcc", num_filters=40, num_ceps=40), np.float32).extract(x)
+    np.testing.assert_allclose(m[50, :4], [-56.79254, 39.436134, -4.260915, 93.49189], rtol=1e-4)
+    m = RefExtractor(RefConfig(kind="mfcc", num_filters=23), np.float32).extract(x)
+    np.testing.assert_allclose(m[50, :4], [-35.647915, 28.312605, -6.895573, 97.56834], rtol=1e-4)
+    s = RefExtractor(RefConfig(kind="spectrogram"), np.float32).extract(x)
+    assert abs(s[50, 14] - 83.3287) < 1e-2
+    ls = RefExtractor(RefConfig(kind="log-spectrogram"), np.float32).extract(x)
+    np.testing.assert_allclose(ls[50, :3], [-12.562129, -10.7374, -9.951348], atol=5e-3)
+
+
+def test_reference_shape_goldens():
+    # test/features/test_kaldi_layers.py:21-66: randn(1,16000) -> 100 x {257, 80, 13}
+    x = np.random.RandomState(0).randn(16000).astype(np.float32) * 0.1
+    assert RefExtractor(RefConfig(kind="spectrogram")).extract(x).shape == (100, 257)
+    assert RefExtractor(RefConfig(kind="log-spectrogram")).extract(x).shape == (100, 257)
+    assert RefExtractor(RefConfig(kind="fbank")).extract(x).shape == (100, 80)
+    assert RefExtractor(RefConfig(kind="mfcc", num_filters=23)).extract(x).shape == (100, 13)
+    # test_kaldi_layers.py:126 -- 98 frames with snip_edges=True
+    assert RefExtractor(RefConfig(kind="fbank", snip_edges=True)).extract(x).shape == (98, 80)
+    # test/features/test_kaldi_features.py:92-128: the 256640-sample libri wav -> 1604 frames
+    assert K.num_frames(256640, 400, 160, False) == 1604
+
+
+def test_frame_count_contract():
+    """lhotse/utils.py:410-434 == layers.py:753 for snip_edges=False at every length."""
+    for sr, fs in [(16000, 0.01), (8000, 0.01), (22050, 0.01), (44100, 0.01), (16000, 0.008)]:
+        shift = int(np.floor(fs * sr))
+        assert shift == round(fs * sr)
+        for s in list(range(1, 2000)) + [160000, 100050, 256640]:
+            assert K.compute_num_frames_from_samples(s, fs, sr) == K.num_frames(s, 400, shift, False)
+
+
+def test_too_short_raises():
+    ex = RefExtractor(RefConfig(kind="fbank"))
+    for s in (80, 100, 139):
+        with pytest.raises(ValueError):
+            ex.extract(np.zeros(s, dtype=np.float32))
+    assert ex.extract(np.zeros(140, dtype=np.float32)).shape == (1, 80)
+
+
+def test_edge_rule_quirk_q1():
+    """in a zero-padded batch only the last frame(s) of a shorter item differ
+    from its own extract()."""
+    rs = np.random.RandomState(5)
+    a = (rs.rand(16000).astype(np.float32) - 0.5)
+    b = (rs.rand(10000).astype(np.float32) - 0.5)
+    ex = RefExtractor(RefConfig(kind="fbank"))
+    alone = ex.extract(b)
+    batched = ex.extract_batch([a, b], "batch_zero_pad")[1]
+    assert alone.shape == batched.shape == (63, 80)  # (10000 + 80) // 160 = 63
+    np.testing.assert_allclose(alone[:-2], batched[:-2], atol=1e-5)
+    assert np.abs(alone[-1] - batched[-1]).max() > 1e-2
+
+
+@pytest.mark.reference
+def test_live_against_reference():
+    """Authoring container only: run the reference itself on fresh random input."""
+    from oracle.make_golden import build, import_reference
+
+    mod = import_reference()
+    rs = np.random.RandomState(1234)
+    for kind, cfg in [("fbank", {}), ("mfcc", {"num_filters": 40, "num_ceps": 40}), ("fbank", {"sampling_rate": 8000})]:
+        x = (rs.rand(12345).astype(np.float32) - 0.5)
+        ref = build(mod, kind, cfg)
+        want = ref.extract(x, ref.config.sampling_rate)
+        rc = dict(cfg)
+        got = RefExtractor(RefConfig(kind=kind, **rc), np.float32).extract(x)
+        assert got.shape == want.shape
+        assert err_stats(got, want)["rel_l2"] < 1e-4
