@@ -1,0 +1,171 @@
+/*
+ * hipfeat.h -- C ABI of libhipfeat.so: batched Kaldi-style audio feature extraction
+ * (spectrogram / log-spectrogram / log-mel filterbank / MFCC) on AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE path of lhotse: the arithmetic behind
+ *   FeatureExtractor.extract / extract_batch   (lhotse/features/base.py:75-82, :152-222)
+ * as implemented by the torch layers
+ *   Wav2Win -> Wav2FFT -> Wav2Spec / Wav2LogSpec / Wav2LogFilterBank / Wav2MFCC
+ *                                              (lhotse/features/kaldi/layers.py:59-724)
+ * and driven by _extract_batch                 (lhotse/features/kaldi/extractors.py:485-554).
+ *
+ * The reference has no native code and therefore no FFI for this path; its FFI
+ * convention elsewhere is ctypes.CDLL + integer status codes
+ * (lhotse/tools/libsox.py:74-117).  Every entry point below is plain C: opaque
+ * handles, raw pointers, sizes; no torch / Python types.  It is loadable with
+ * ctypes or cffi (see INTEGRATION.md for the binding a lhotse maintainer would add).
+ *
+ * Conventions
+ *   - every function returns hipfeat_status (0 == OK) unless stated otherwise;
+ *     hipfeat_last_error() returns a thread-local message for the last failure;
+ *   - "d_" pointers are device (HBM) pointers on the plan's device, "h_" pointers are host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued asynchronously on it, nothing synchronises the device;
+ *   - no global state; safe to call with the Python GIL released; a plan may be used
+ *     from several host threads as long as they use different streams.
+ */
+#ifndef HIPFEAT_H_
+#define HIPFEAT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPFEAT_ABI_VERSION 1
+
+#if defined(HIPFEAT_BUILD)
+#define HIPFEAT_API __attribute__((visibility("default")))
+#else
+#define HIPFEAT_API
+#endif
+
+typedef enum hipfeat_status {
+  HIPFEAT_OK = 0,
+  HIPFEAT_ERR_INVALID = 1,     /* bad argument / inconsistent config                        */
+  HIPFEAT_ERR_HIP = 2,         /* a HIP runtime call failed (message has the hipError name) */
+  HIPFEAT_ERR_UNSUPPORTED = 3, /* valid in the reference but not implemented here           */
+  HIPFEAT_ERR_TOO_SHORT = 4    /* waveform shorter than the reflect padding needs; the
+                                  reference raises here too (layers.py:759-764)             */
+} hipfeat_status;
+
+/* Which layer of lhotse/features/kaldi/layers.py the plan reproduces. */
+typedef enum hipfeat_kind {
+  HIPFEAT_SPECTROGRAM = 0,     /* Wav2Spec            layers.py:336-402 */
+  HIPFEAT_LOG_SPECTROGRAM = 1, /* Wav2LogSpec         layers.py:405-473 */
+  HIPFEAT_FBANK = 2,           /* Wav2LogFilterBank   layers.py:476-578 */
+  HIPFEAT_MFCC = 3             /* Wav2MFCC            layers.py:581-724 */
+} hipfeat_kind;
+
+/*
+ * Scalar options.  Field meaning == the constructor arguments of the layers above
+ * (layers.py:80-94, :247-261, :494-514, :599-621), already converted to samples.
+ * The float32 constant arrays (window, mel matrix, DCT, lifter) are passed separately
+ * to hipfeat_plan_create so that the caller -- who computes them with the reference's
+ * own formulae -- owns their exact values.
+ */
+typedef struct hipfeat_config {
+  int32_t struct_size;      /* = sizeof(hipfeat_config); ABI guard                              */
+  int32_t kind;             /* hipfeat_kind                                                     */
+  int32_t frame_length;     /* N  = floor(frame_length_s * sampling_rate)    layers.py:114     */
+  int32_t frame_shift;      /* floor(frame_shift_s * sampling_rate)          layers.py:116     */
+  int32_t fft_length;       /* next_power_of_2(N) or N                       layers.py:265     */
+  int32_t num_filters;      /* M (mel bins);   0 for (log-)spectrogram                          */
+  int32_t num_ceps;         /* C (MFCC only);  0 otherwise                                      */
+  int32_t snip_edges;       /* layers.py:747-753                                                */
+  int32_t remove_dc_offset; /* layers.py:155-157                                                */
+  int32_t use_energy;       /* layers.py:575-576 (fbank: prepended column), :399-400, :470-471  */
+  int32_t raw_energy;       /* layers.py:161 vs :183                                            */
+  int32_t use_fft_mag;      /* |X| instead of |X|^2                          layers.py:387-390 */
+  int32_t apply_lifter;     /* cepstral_lifter > 0                           layers.py:717     */
+  float preemph_coeff;      /* 0 disables                                    layers.py:165     */
+  float energy_floor;       /* log-energy floored at log(energy_floor) if >0 layers.py:864     */
+  float mel_floor;          /* eps of max(mel, eps).log() = 1.1920929e-07    layers.py:536,572 */
+  float log_offset;         /* 1e-15 added before log in Wav2LogSpec         layers.py:467     */
+  float dither;             /* must be 0 in ABI v1 (layers.py:191-193 draws torch.randn)        */
+} hipfeat_config;
+
+typedef struct hipfeat_plan hipfeat_plan;     /* constants + kernel selection, per (device, config) */
+typedef struct hipfeat_layout hipfeat_layout; /* device-resident description of one batch shape     */
+
+/* ---- library ------------------------------------------------------------------- */
+HIPFEAT_API int32_t hipfeat_abi_version(void);
+HIPFEAT_API const char* hipfeat_last_error(void);
+HIPFEAT_API hipfeat_status hipfeat_device_count(int32_t* count);
+
+/* ---- pure host helpers (no GPU needed) ------------------------------------------ */
+/* Frame count of one waveform: layers.py:747-753; for snip_edges == 0 it equals
+ * compute_num_frames_from_samples (lhotse/utils.py:424-434), the contract that
+ * validate_features asserts (lhotse/qa.py:286-311). */
+HIPFEAT_API int64_t hipfeat_num_frames(int64_t num_samples, int32_t frame_length, int32_t frame_shift, int32_t snip_edges);
+/* HIPFEAT_OK, or HIPFEAT_ERR_TOO_SHORT when reflect padding is impossible:
+ * the reflection is taken on a row of `padded_len` samples (== num_samples for a
+ * single waveform). */
+HIPFEAT_API hipfeat_status hipfeat_check_length(int64_t padded_len, int32_t frame_length, int32_t frame_shift, int32_t snip_edges);
+
+/* ---- plan ------------------------------------------------------------------------ */
+/* window[frame_length]; mel[(fft_length/2+1) * num_filters] row-major (bin, filter) as in
+ * Wav2LogFilterBank._fb (layers.py:553,563); dct[num_filters * num_ceps] row-major as in
+ * Wav2MFCC._dct (layers.py:697-706); lifter[num_ceps] (layers.py:681-695).  Unused arrays
+ * may be NULL.  All are HOST float32 arrays, copied to the device. */
+HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* cfg, const float* h_window, const float* h_mel,
+                                   const float* h_dct, const float* h_lifter, int32_t device,
+                                   hipfeat_plan** plan);
+HIPFEAT_API hipfeat_status hipfeat_plan_destroy(hipfeat_plan* plan);
+/* Columns written per frame: M (+1 with use_energy) | C | fft/2+1. */
+HIPFEAT_API int32_t hipfeat_plan_feature_dim(const hipfeat_plan* plan);
+/* Human-readable name of the kernel variant the plan dispatches to (e.g. "generic",
+ * "fft512"); tests use it to assert that the specialised path is the one exercised. */
+HIPFEAT_API const char* hipfeat_plan_kernel_name(const hipfeat_plan* plan);
+
+/* ---- layout: the shape of a batch ------------------------------------------------ */
+/*
+ * A batch is `batch` cuts.  Cut b occupies h_wave_offsets[b] .. + h_num_samples[b] (in
+ * float32 elements) of the waveform buffer -- this covers both the packed form
+ * (offsets = prefix sums) and the padded (B, Smax) form (offsets = b * Smax).
+ *
+ * h_padded_len (nullable): the row length the edge reflection is taken on.
+ *   NULL / == num_samples : every cut is reflected on its own, as Fbank.extract
+ *                           (extractors.py:92-115) and kaldifeat do;
+ *   == max(num_samples)   : reproduces _extract_batch (extractors.py:531-537): shorter
+ *                           items read zeros past their end, and only
+ *                           compute_num_frames_from_samples(num_samples) rows are produced.
+ *
+ * Output: cut b's features are written to rows h_out_rows[b] .. + num_frames(b) of a
+ * row-major matrix with `out_row_stride` floats per row (>= feature_dim).  h_out_rows
+ * NULL = packed back to back.  This covers the packed (sum T_b, F) form and the padded
+ * (B, Tmax, F) form (out_rows = b * Tmax).
+ */
+HIPFEAT_API hipfeat_status hipfeat_layout_create(const hipfeat_plan* plan, int64_t batch, const int64_t* h_wave_offsets,
+                                     const int64_t* h_num_samples, const int64_t* h_padded_len,
+                                     const int64_t* h_out_rows, int64_t out_row_stride, void* stream,
+                                     hipfeat_layout** layout);
+HIPFEAT_API hipfeat_status hipfeat_layout_destroy(hipfeat_layout* layout);
+HIPFEAT_API int64_t hipfeat_layout_total_frames(const hipfeat_layout* layout);
+/* Writes the per-cut frame counts into h_num_frames[batch]. */
+HIPFEAT_API hipfeat_status hipfeat_layout_num_frames(const hipfeat_layout* layout, int64_t* h_num_frames);
+
+/* ---- the hot path ---------------------------------------------------------------- */
+/* One asynchronous pass over the batch described by `layout`: d_wave -> d_out. */
+HIPFEAT_API hipfeat_status hipfeat_extract_layout(const hipfeat_plan* plan, const hipfeat_layout* layout,
+                                      const float* d_wave, float* d_out, void* stream);
+
+/* Convenience: build a transient layout from host arrays and run it (same semantics). */
+HIPFEAT_API hipfeat_status hipfeat_extract(const hipfeat_plan* plan, const float* d_wave, const int64_t* h_wave_offsets,
+                               const int64_t* h_num_samples, const int64_t* h_padded_len, int64_t batch,
+                               float* d_out, const int64_t* h_out_rows, int64_t out_row_stride, void* stream);
+
+/* Host-memory form: h_wave / h_out are HOST buffers (pinned or pageable); the library
+ * stages them through the device (H2D, kernel, D2H) on `stream` and waits for completion.
+ * `wave_elems` / `out_elems` are the total buffer sizes in float32 elements. */
+HIPFEAT_API hipfeat_status hipfeat_extract_host(const hipfeat_plan* plan, const float* h_wave, int64_t wave_elems,
+                                    const int64_t* h_wave_offsets, const int64_t* h_num_samples,
+                                    const int64_t* h_padded_len, int64_t batch, float* h_out,
+                                    int64_t out_elems, const int64_t* h_out_rows, int64_t out_row_stride,
+                                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPFEAT_H_ */

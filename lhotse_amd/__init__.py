@@ -1,0 +1,28 @@
+"""
+lhotse_amd -- MI355X-native batched audio feature extraction behind lhotse's
+FeatureExtractor interface (see DESIGN.md / INTEGRATION.md).
+
+Importing the package never touches the GPU; extractors create their device plan lazily.
+"""
+from .extractors import (  # noqa: F401
+    HipFbank,
+    HipFbankConfig,
+    HipLogSpectrogram,
+    HipLogSpectrogramConfig,
+    HipMfcc,
+    HipMfccConfig,
+    HipSpectrogram,
+    HipSpectrogramConfig,
+)
+
+__all__ = [
+    "HipFbank",
+    "HipFbankConfig",
+    "HipMfcc",
+    "HipMfccConfig",
+    "HipSpectrogram",
+    "HipSpectrogramConfig",
+    "HipLogSpectrogram",
+    "HipLogSpectrogramConfig",
+]
+__version__ = "0.1.0"

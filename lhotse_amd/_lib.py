@@ -1,0 +1,219 @@
+"""
+Thin FFI layer over libhipfeat.so (include/hipfeat.h).
+
+Loader policy: cffi (ABI mode) when the package is importable, otherwise ctypes -- the
+FFI convention the reference itself uses (lhotse/tools/libsox.py:74-117).  Both back-ends
+see the same convention: every pointer argument is a plain integer address (or None),
+every scalar a Python int/float, so the wrappers above this file contain no FFI types.
+
+There is NO CPU fallback: if the library cannot be built/loaded, or a call fails, a
+``HipFeatError`` is raised with the library's own message.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import build as _build
+
+ABI_VERSION = 1
+
+# name -> (return C type, [argument C types]) ; mirrors include/hipfeat.h one to one.
+_SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
+    "hipfeat_abi_version": ("int32_t", []),
+    "hipfeat_last_error": ("const char*", []),
+    "hipfeat_device_count": ("int", ["int32_t*"]),
+    "hipfeat_num_frames": ("int64_t", ["int64_t", "int32_t", "int32_t", "int32_t"]),
+    "hipfeat_check_length": ("int", ["int64_t", "int32_t", "int32_t", "int32_t"]),
+    "hipfeat_plan_create": (
+        "int",
+        ["const hipfeat_config*", "const float*", "const float*", "const float*", "const float*", "int32_t", "hipfeat_plan**"],
+    ),
+    "hipfeat_plan_destroy": ("int", ["hipfeat_plan*"]),
+    "hipfeat_plan_feature_dim": ("int32_t", ["const hipfeat_plan*"]),
+    "hipfeat_plan_kernel_name": ("const char*", ["const hipfeat_plan*"]),
+    "hipfeat_layout_create": (
+        "int",
+        ["const hipfeat_plan*", "int64_t", "const int64_t*", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "void*", "hipfeat_layout**"],
+    ),
+    "hipfeat_layout_destroy": ("int", ["hipfeat_layout*"]),
+    "hipfeat_layout_total_frames": ("int64_t", ["const hipfeat_layout*"]),
+    "hipfeat_layout_num_frames": ("int", ["const hipfeat_layout*", "int64_t*"]),
+    "hipfeat_extract_layout": ("int", ["const hipfeat_plan*", "const hipfeat_layout*", "const float*", "float*", "void*"]),
+    "hipfeat_extract": (
+        "int",
+        ["const hipfeat_plan*", "const float*", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "const int64_t*", "int64_t", "void*"],
+    ),
+    "hipfeat_extract_host": (
+        "int",
+        ["const hipfeat_plan*", "const float*", "int64_t", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "int64_t", "const int64_t*", "int64_t", "void*"],
+    ),
+}
+
+# numpy mirror of `struct hipfeat_config` (include/hipfeat.h); field order and sizes must match.
+CONFIG_DTYPE = np.dtype(
+    [
+        ("struct_size", "<i4"),
+        ("kind", "<i4"),
+        ("frame_length", "<i4"),
+        ("frame_shift", "<i4"),
+        ("fft_length", "<i4"),
+        ("num_filters", "<i4"),
+        ("num_ceps", "<i4"),
+        ("snip_edges", "<i4"),
+        ("remove_dc_offset", "<i4"),
+        ("use_energy", "<i4"),
+        ("raw_energy", "<i4"),
+        ("use_fft_mag", "<i4"),
+        ("apply_lifter", "<i4"),
+        ("preemph_coeff", "<f4"),
+        ("energy_floor", "<f4"),
+        ("mel_floor", "<f4"),
+        ("log_offset", "<f4"),
+        ("dither", "<f4"),
+    ],
+    align=True,
+)
+
+STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "HIP", 3: "UNSUPPORTED", 4: "TOO_SHORT"}
+ERR_TOO_SHORT = 4
+ERR_UNSUPPORTED = 3
+
+
+class HipFeatError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libhipfeat: {STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+def _is_ptr(ctype: str) -> bool:
+    return ctype.endswith("*")
+
+
+class _CtypesBackend:
+    name = "ctypes"
+    _SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64}
+
+    def __init__(self, path: str):
+        self.dll = ctypes.CDLL(path)
+        self.fns = {}
+        for name, (ret, args) in _SIGNATURES.items():
+            fn = getattr(self.dll, name)  # AttributeError here == a symbol the header declares is missing
+            fn.restype = ctypes.c_char_p if ret == "const char*" else self._SCALARS[ret]
+            fn.argtypes = [ctypes.c_void_p if _is_ptr(a) else self._SCALARS[a] for a in args]
+            self.fns[name] = fn
+
+    def call(self, name: str, *args):
+        return self.fns[name](*args)
+
+    @staticmethod
+    def string(v) -> str:
+        return v.decode() if v else ""
+
+
+class _CffiBackend:
+    name = "cffi"
+
+    def __init__(self, path: str):
+        import cffi  # noqa: F401  (ImportError -> caller falls back to ctypes)
+
+        self.ffi = cffi.FFI()
+        header = (_build.PKG.parent / "include" / "hipfeat.h").read_text()
+        decl = []
+        for line in header.splitlines():
+            s = line.strip()
+            if s.startswith("#") or s.startswith('extern "C"') or s == "}":
+                continue
+            decl.append(line.replace("HIPFEAT_API ", ""))
+        self.ffi.cdef("\n".join(decl))
+        self.dll = self.ffi.dlopen(path)
+        self.fns = {name: getattr(self.dll, name) for name in _SIGNATURES}
+
+    def call(self, name: str, *args):
+        sig = _SIGNATURES[name][1]
+        conv = []
+        for a, t in zip(args, sig):
+            if _is_ptr(t):
+                conv.append(self.ffi.NULL if a is None else self.ffi.cast(t, int(a)))
+            else:
+                conv.append(a)
+        return self.fns[name](*conv)
+
+    def string(self, v) -> str:
+        return self.ffi.string(v).decode() if v != self.ffi.NULL else ""
+
+
+class Lib:
+    """Loaded libhipfeat with status checking."""
+
+    def __init__(self, path: str, prefer: Optional[str] = None):
+        self.path = path
+        backend = None
+        if prefer in (None, "cffi"):
+            try:
+                backend = _CffiBackend(path)
+            except ImportError:
+                if prefer == "cffi":
+                    raise
+        if backend is None:
+            backend = _CtypesBackend(path)
+        self.backend = backend
+        v = self.raw("hipfeat_abi_version")
+        if v != ABI_VERSION:
+            raise HipFeatError(1, f"ABI version {v} of {path} != {ABI_VERSION} expected by the Python host")
+
+    def raw(self, name: str, *args):
+        return self.backend.call(name, *args)
+
+    def last_error(self) -> str:
+        return self.backend.string(self.raw("hipfeat_last_error"))
+
+    def check(self, name: str, *args) -> None:
+        st = self.raw(name, *args)
+        if st != 0:
+            raise HipFeatError(int(st), self.last_error())
+
+    def string(self, name: str, *args) -> str:
+        return self.backend.string(self.raw(name, *args))
+
+
+_lock = threading.Lock()
+_lib: Optional[Lib] = None
+
+
+def load(prefer: Optional[str] = None) -> Lib:
+    """Load (building in-tree first if needed).  Raises if neither is possible: the product
+    path has no CPU fallback."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        # torch ships its own libamdhip64.so.7; importing it first makes libhipfeat bind to
+        # the SAME HIP runtime instance (same SONAME) so device pointers and streams are shared.
+        import torch  # noqa: F401
+
+        path = str(_build.LIB_PATH)
+        if _build.needs_build():
+            try:
+                _build.build()
+            except Exception as e:  # stale or missing library and no way to build it
+                if not os.path.exists(path):
+                    raise HipFeatError(2, f"libhipfeat.so is not built and cannot be built here: {e}") from e
+        _lib = Lib(path, prefer=os.environ.get("HIPFEAT_FFI", prefer))
+        return _lib
+
+
+def addr(a: Optional[np.ndarray]) -> Optional[int]:
+    """Address of a C-contiguous numpy array (None passes NULL)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+def i64(values) -> np.ndarray:
+    return np.ascontiguousarray(values, dtype=np.int64)

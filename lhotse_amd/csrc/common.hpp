@@ -1,0 +1,66 @@
+// Shared device/host definitions for libhipfeat (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hipfeat {
+
+// One cut of a batch, as the kernels see it (32 bytes, device resident).
+struct CutDesc {
+  int64_t wave_off;     // first sample of the cut in the waveform buffer (elements)
+  int64_t out_row;      // first output row of the cut
+  int32_t num_samples;  // S
+  int32_t padded_len;   // P: row length the edge reflection is taken on (== S unless batch_zero_pad)
+  int32_t num_frames;   // rows to produce
+  int32_t first_block;  // index of the cut's first workgroup in the grid (exclusive prefix sum)
+};
+
+enum : int32_t {
+  F_REMOVE_DC = 1 << 0,
+  F_USE_ENERGY = 1 << 1,
+  F_RAW_ENERGY = 1 << 2,
+  F_FFT_MAG = 1 << 3,
+  F_LIFTER = 1 << 4,
+  F_POW2 = 1 << 5,
+};
+
+// Kernel arguments of the generic kernel (passed by value; lives in the kernarg segment).
+struct GenericParams {
+  const float* wave;
+  float* out;
+  const CutDesc* cuts;
+  const float* window;     // [N]
+  const float2* tw;        // pow2: W_fft^k, k < fft/2 ; otherwise W_fft^k, k < fft
+  const float* mel;        // [K][M]
+  const int2* mel_range;   // [M] first bin, one-past-last bin with a non-zero weight
+  const float* dct;        // [M][C]
+  const float* lifter;     // [C]
+  int64_t out_stride;      // floats per output row
+  int32_t num_cuts;
+  int32_t uniform_bpc;     // >0: every cut has exactly this many workgroups (no search needed)
+  int32_t N, shift, fft, H, log2H, K, M, C;
+  int32_t kind, flags, fpb, npad_left;
+  float preemph, log_energy_floor, mel_floor, log_offset;
+  // LDS carve-up (float offsets)
+  int32_t span, off_z, off_p, off_tw, off_stat, off_mel;
+};
+
+__device__ __forceinline__ float load_sample(const float* __restrict__ w, int64_t j, int32_t S, int32_t P) {
+  // Index restatement of the flip/cat of layers.py:756-764 (see oracle/kaldi_ref.py frame_indices):
+  // j<0 -> -j-1, j>=P -> 2P-1-j; indices in [S, P) are the zero padding of a batch row.
+  if (j < 0) j = -j - 1;
+  if (j >= P) j = 2 * (int64_t)P - 1 - j;
+  return (j >= 0 && j < S) ? w[j] : 0.0f;
+}
+
+// Locate the cut that owns workgroup `blk` (binary search over first_block).
+__device__ __forceinline__ int find_cut(const CutDesc* __restrict__ cuts, int num_cuts, int blk) {
+  int lo = 0, hi = num_cuts - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (cuts[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+}  // namespace hipfeat

@@ -1,0 +1,553 @@
+// libhipfeat: C ABI (include/hipfeat.h) + kernel dispatch.  gfx950 only; no torch, no Python.
+#include "../../include/hipfeat.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "kernel_generic.hpp"
+
+using namespace hipfeat;
+
+// --------------------------------------------------------------------------------------
+// error plumbing
+// --------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static hipfeat_status fail(hipfeat_status st, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return st;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(HIPFEAT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorName(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+// --------------------------------------------------------------------------------------
+// objects
+// --------------------------------------------------------------------------------------
+struct StagingSlot {
+  void* h = nullptr;  // pinned host
+  void* d = nullptr;  // device
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool busy = false;
+};
+
+struct hipfeat_plan {
+  hipfeat_config cfg{};
+  int device = 0;
+  int feature_dim = 0;
+  int K = 0, H = 0, log2H = 0;
+  bool pow2 = false;
+  int npad_left = 0;
+  const char* kernel_name = "generic";
+  // device constants
+  float* d_window = nullptr;
+  float2* d_tw = nullptr;
+  float* d_mel = nullptr;
+  int2* d_mel_range = nullptr;
+  float* d_dct = nullptr;
+  float* d_lifter = nullptr;
+  // generic kernel geometry
+  int fpb = 8;
+  int span = 0, off_z = 0, off_p = 0, off_tw = 0, off_stat = 0, off_mel = 0;
+  size_t lds_bytes = 0;
+  // transient-layout staging ring (hipfeat_extract)
+  mutable std::mutex mu;
+  mutable StagingSlot slots[4];
+  mutable int next_slot = 0;
+  // host-form scratch (hipfeat_extract_host)
+  mutable float* d_scratch_wave = nullptr;
+  mutable size_t scratch_wave_cap = 0;
+  mutable float* d_scratch_out = nullptr;
+  mutable size_t scratch_out_cap = 0;
+};
+
+struct hipfeat_layout {
+  int device = 0;
+  int64_t batch = 0;
+  int64_t total_frames = 0;
+  int64_t total_blocks = 0;
+  int64_t out_row_stride = 0;
+  int uniform_bpc = 0;
+  int fpb = 0;
+  CutDesc* d_cuts = nullptr;
+  bool owns = true;
+  std::vector<int64_t> num_frames;
+};
+
+// --------------------------------------------------------------------------------------
+// library / pure helpers
+// --------------------------------------------------------------------------------------
+extern "C" HIPFEAT_API int32_t hipfeat_abi_version(void) { return HIPFEAT_ABI_VERSION; }
+extern "C" HIPFEAT_API const char* hipfeat_last_error(void) { return g_err; }
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_device_count(int32_t* count) {
+  if (!count) return fail(HIPFEAT_ERR_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(HIPFEAT_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorName(e));
+  }
+  *count = n;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API int64_t hipfeat_num_frames(int64_t num_samples, int32_t frame_length, int32_t frame_shift,
+                                      int32_t snip_edges) {
+  if (frame_shift <= 0 || frame_length <= 0 || num_samples < 0) return 0;
+  if (snip_edges) return num_samples < frame_length ? 0 : 1 + (num_samples - frame_length) / frame_shift;
+  return (num_samples + frame_shift / 2) / frame_shift;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_check_length(int64_t padded_len, int32_t frame_length, int32_t frame_shift,
+                                               int32_t snip_edges) {
+  if (snip_edges) return HIPFEAT_OK;
+  const int64_t t = hipfeat_num_frames(padded_len, frame_length, frame_shift, 0);
+  if (t <= 0)
+    return fail(HIPFEAT_ERR_TOO_SHORT, "waveform of %lld samples yields no frames", (long long)padded_len);
+  const int64_t npad_left = (frame_length - frame_shift) / 2;
+  const int64_t npad_right = (t - 1) * frame_shift + frame_length - padded_len - npad_left;
+  if (npad_left > padded_len || npad_right > padded_len)
+    return fail(HIPFEAT_ERR_TOO_SHORT,
+                "waveform of %lld samples is shorter than the reflect padding (%lld left, %lld right)",
+                (long long)padded_len, (long long)npad_left, (long long)npad_right);
+  return HIPFEAT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// plan
+// --------------------------------------------------------------------------------------
+template <typename T>
+static hipfeat_status upload(T** dst, const T* src, size_t n) {
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(n, 1) * sizeof(T)));
+  if (n) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+  return HIPFEAT_OK;
+}
+
+static void plan_free(hipfeat_plan* p) {
+  if (!p) return;
+  DeviceGuard g(p->device);
+  (void)hipFree(p->d_window);
+  (void)hipFree(p->d_tw);
+  (void)hipFree(p->d_mel);
+  (void)hipFree(p->d_mel_range);
+  (void)hipFree(p->d_dct);
+  (void)hipFree(p->d_lifter);
+  (void)hipFree(p->d_scratch_wave);
+  (void)hipFree(p->d_scratch_out);
+  for (auto& s : p->slots) {
+    if (s.h) (void)hipHostFree(s.h);
+    if (s.d) (void)hipFree(s.d);
+    if (s.ev) (void)hipEventDestroy(s.ev);
+  }
+  delete p;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* cfg, const float* h_window,
+                                              const float* h_mel, const float* h_dct, const float* h_lifter,
+                                              int32_t device, hipfeat_plan** out) {
+  if (!cfg || !out) return fail(HIPFEAT_ERR_INVALID, "cfg/plan pointer is NULL");
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(hipfeat_config))
+    return fail(HIPFEAT_ERR_INVALID, "hipfeat_config.struct_size %d != %zu (ABI mismatch)", cfg->struct_size,
+                sizeof(hipfeat_config));
+  const int N = cfg->frame_length, shift = cfg->frame_shift, fft = cfg->fft_length;
+  if (cfg->kind < 0 || cfg->kind > 3) return fail(HIPFEAT_ERR_INVALID, "unknown kind %d", cfg->kind);
+  if (N <= 0 || shift <= 0 || fft < N)
+    return fail(HIPFEAT_ERR_INVALID, "need frame_length>0, frame_shift>0, fft_length>=frame_length (got %d, %d, %d)",
+                N, shift, fft);
+  if (shift > N)
+    return fail(HIPFEAT_ERR_UNSUPPORTED, "frame_shift (%d) > frame_length (%d) is not supported", shift, N);
+  if (!h_window) return fail(HIPFEAT_ERR_INVALID, "window is NULL");
+  if (cfg->dither != 0.0f)
+    return fail(HIPFEAT_ERR_UNSUPPORTED, "dither != 0 is not supported in ABI v%d", HIPFEAT_ABI_VERSION);
+  const bool need_mel = cfg->kind == HIPFEAT_FBANK || cfg->kind == HIPFEAT_MFCC;
+  if (need_mel && (cfg->num_filters <= 0 || !h_mel))
+    return fail(HIPFEAT_ERR_INVALID, "fbank/mfcc need num_filters>0 and a mel matrix");
+  if (cfg->kind == HIPFEAT_MFCC) {
+    if (cfg->num_ceps <= 0 || !h_dct) return fail(HIPFEAT_ERR_INVALID, "mfcc needs num_ceps>0 and a dct matrix");
+    if (cfg->apply_lifter && !h_lifter) return fail(HIPFEAT_ERR_INVALID, "apply_lifter set but lifter is NULL");
+    if (cfg->use_energy)
+      return fail(HIPFEAT_ERR_UNSUPPORTED,
+                  "MFCC with use_energy=True raises in the reference (layers.py:721-722) and is not defined here");
+  }
+  if (fft > 8192) return fail(HIPFEAT_ERR_UNSUPPORTED, "fft_length %d > 8192 is not supported", fft);
+
+  hipfeat_plan* p = new (std::nothrow) hipfeat_plan();
+  if (!p) return fail(HIPFEAT_ERR_INVALID, "out of host memory");
+  p->cfg = *cfg;
+  p->device = device;
+  p->K = fft / 2 + 1;
+  p->pow2 = (fft & (fft - 1)) == 0 && fft >= 2;
+  p->H = p->pow2 ? fft / 2 : 0;
+  p->log2H = 0;
+  while (p->pow2 && (1 << p->log2H) < p->H) ++p->log2H;
+  p->npad_left = cfg->snip_edges ? 0 : (N - shift) / 2;
+  const int M = need_mel ? cfg->num_filters : 0;
+  const int C = cfg->kind == HIPFEAT_MFCC ? cfg->num_ceps : 0;
+  p->feature_dim = cfg->kind == HIPFEAT_FBANK ? M + (cfg->use_energy ? 1 : 0) : (cfg->kind == HIPFEAT_MFCC ? C : p->K);
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    delete p;
+    return fail(HIPFEAT_ERR_HIP, "device %d not available (%d HIP devices visible)", device, ndev);
+  }
+  DeviceGuard g(device);
+  hipfeat_status st = HIPFEAT_OK;
+  auto bail = [&](hipfeat_status s) {
+    plan_free(p);
+    return s;
+  };
+
+  // twiddles, computed in double: W_fft^k = exp(-2 pi i k / fft)
+  {
+    const int nt = p->pow2 ? std::max(p->H, 1) : fft;
+    std::vector<float2> tw(nt);
+    for (int k = 0; k < nt; ++k) {
+      const double a = -2.0 * M_PI * (double)k / (double)fft;
+      tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    if ((st = upload(&p->d_tw, tw.data(), tw.size())) != HIPFEAT_OK) return bail(st);
+  }
+  if ((st = upload(&p->d_window, h_window, (size_t)N)) != HIPFEAT_OK) return bail(st);
+  if (need_mel) {
+    if ((st = upload(&p->d_mel, h_mel, (size_t)p->K * M)) != HIPFEAT_OK) return bail(st);
+    // band of each filter: [first non-zero bin, last non-zero bin + 1)
+    std::vector<int2> rng(M);
+    for (int j = 0; j < M; ++j) {
+      int lo = p->K, hi = 0;
+      for (int k = 0; k < p->K; ++k)
+        if (h_mel[(size_t)k * M + j] != 0.0f) {
+          lo = std::min(lo, k);
+          hi = std::max(hi, k + 1);
+        }
+      if (hi == 0) lo = 0;
+      rng[j] = make_int2(lo, hi);
+    }
+    if ((st = upload(&p->d_mel_range, rng.data(), rng.size())) != HIPFEAT_OK) return bail(st);
+  }
+  if (C) {
+    if ((st = upload(&p->d_dct, h_dct, (size_t)M * C)) != HIPFEAT_OK) return bail(st);
+    if (cfg->apply_lifter && (st = upload(&p->d_lifter, h_lifter, (size_t)C)) != HIPFEAT_OK) return bail(st);
+  }
+
+  // LDS carve-up of the generic kernel; shrink frames-per-block until it fits 160 KiB
+  for (p->fpb = 8; p->fpb >= 1; p->fpb >>= 1) {
+    auto al = [](int v) { return (v + 3) & ~3; };
+    p->span = (p->fpb - 1) * shift + N;
+    p->off_z = al(p->span);
+    p->off_p = p->off_z + al(p->fpb * fft);
+    p->off_tw = p->off_p + al(p->fpb * p->K);
+    p->off_stat = p->off_tw + (p->pow2 ? al(2 * std::max(p->H, 1)) : 0);
+    p->off_mel = p->off_stat + al(2 * p->fpb);
+    const int end = p->off_mel + al(p->fpb * std::max(M, 1));
+    p->lds_bytes = (size_t)end * sizeof(float);
+    if (p->lds_bytes <= 160 * 1024) break;
+  }
+  if (p->fpb < 1) return bail(fail(HIPFEAT_ERR_UNSUPPORTED, "configuration does not fit in LDS"));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
+  if (e != hipSuccess) return bail(fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", p->lds_bytes, hipGetErrorName(e)));
+
+  *out = p;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_destroy(hipfeat_plan* plan) {
+  plan_free(plan);
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API int32_t hipfeat_plan_feature_dim(const hipfeat_plan* plan) { return plan ? plan->feature_dim : 0; }
+extern "C" HIPFEAT_API const char* hipfeat_plan_kernel_name(const hipfeat_plan* plan) { return plan ? plan->kernel_name : ""; }
+
+// --------------------------------------------------------------------------------------
+// layout
+// --------------------------------------------------------------------------------------
+// Validates the batch and fills the host-side descriptor table.
+static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const int64_t* offs, const int64_t* ns,
+                                  const int64_t* padded, const int64_t* out_rows, int64_t out_row_stride,
+                                  std::vector<CutDesc>& descs, hipfeat_layout* lay) {
+  if (!plan) return fail(HIPFEAT_ERR_INVALID, "plan is NULL");
+  if (batch < 0 || (batch > 0 && (!offs || !ns))) return fail(HIPFEAT_ERR_INVALID, "bad batch arguments");
+  if (out_row_stride < plan->feature_dim)
+    return fail(HIPFEAT_ERR_INVALID, "out_row_stride %lld < feature_dim %d", (long long)out_row_stride, plan->feature_dim);
+  const hipfeat_config& c = plan->cfg;
+  descs.resize((size_t)batch);
+  lay->num_frames.resize((size_t)batch);
+  int64_t row = 0, blocks = 0;
+  int uniform = -1;
+  for (int64_t b = 0; b < batch; ++b) {
+    const int64_t S = ns[b], P = padded ? padded[b] : ns[b];
+    if (S < 0 || P < S || P > INT32_MAX)
+      return fail(HIPFEAT_ERR_INVALID, "cut %lld: num_samples=%lld padded_len=%lld out of range", (long long)b, (long long)S, (long long)P);
+    int64_t T = hipfeat_num_frames(S, c.frame_length, c.frame_shift, c.snip_edges);
+    if (padded) {
+      // _extract_batch (extractors.py:499-537): the padded row of P samples is framed as a whole and
+      // item b keeps the first compute_num_frames_from_samples(S) rows (lhotse/utils.py:424-434) --
+      // with snip_edges that is NOT the snip_edges count, and it is capped by what the row yields.
+      T = std::min<int64_t>((S + c.frame_shift / 2) / c.frame_shift,
+                            hipfeat_num_frames(P, c.frame_length, c.frame_shift, c.snip_edges));
+    }
+    if (!c.snip_edges && T > 0) {
+      hipfeat_status st = hipfeat_check_length(P, c.frame_length, c.frame_shift, 0);
+      if (st != HIPFEAT_OK) return st;
+    }
+    if (!c.snip_edges && T == 0)
+      return fail(HIPFEAT_ERR_TOO_SHORT, "cut %lld: %lld samples yield no frames", (long long)b, (long long)S);
+    CutDesc& d = descs[(size_t)b];
+    d.wave_off = offs[b];
+    d.out_row = out_rows ? out_rows[b] : row;
+    d.num_samples = (int32_t)S;
+    d.padded_len = (int32_t)P;
+    d.num_frames = (int32_t)T;
+    if (blocks > INT32_MAX - (1 << 24)) return fail(HIPFEAT_ERR_INVALID, "batch too large for one launch");
+    d.first_block = (int32_t)blocks;
+    const int64_t nb = (T + plan->fpb - 1) / plan->fpb;
+    blocks += nb;
+    row += T;
+    lay->num_frames[(size_t)b] = T;
+    if (uniform == -1) uniform = (int)nb;
+    else if (uniform != (int)nb) uniform = 0;
+  }
+  lay->batch = batch;
+  lay->total_frames = row;
+  lay->total_blocks = blocks;
+  lay->out_row_stride = out_row_stride;
+  lay->uniform_bpc = uniform > 0 ? uniform : 0;
+  lay->fpb = plan->fpb;
+  lay->device = plan->device;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_layout_create(const hipfeat_plan* plan, int64_t batch, const int64_t* h_wave_offsets,
+                                                const int64_t* h_num_samples, const int64_t* h_padded_len,
+                                                const int64_t* h_out_rows, int64_t out_row_stride, void* stream,
+                                                hipfeat_layout** layout) {
+  if (!layout) return fail(HIPFEAT_ERR_INVALID, "layout pointer is NULL");
+  *layout = nullptr;
+  hipfeat_layout* lay = new (std::nothrow) hipfeat_layout();
+  if (!lay) return fail(HIPFEAT_ERR_INVALID, "out of host memory");
+  std::vector<CutDesc> descs;
+  hipfeat_status st = build_descs(plan, batch, h_wave_offsets, h_num_samples, h_padded_len, h_out_rows, out_row_stride, descs, lay);
+  if (st != HIPFEAT_OK) {
+    delete lay;
+    return st;
+  }
+  DeviceGuard g(plan->device);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&lay->d_cuts), std::max<size_t>(descs.size(), 1) * sizeof(CutDesc));
+  if (e == hipSuccess && !descs.empty()) {
+    // synchronous w.r.t. the host (pageable source), ordered on `stream`
+    e = hipMemcpyAsync(lay->d_cuts, descs.data(), descs.size() * sizeof(CutDesc), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(lay->d_cuts);
+    delete lay;
+    return fail(HIPFEAT_ERR_HIP, "layout upload failed: %s", hipGetErrorName(e));
+  }
+  *layout = lay;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_layout_destroy(hipfeat_layout* layout) {
+  if (!layout) return HIPFEAT_OK;
+  if (layout->owns && layout->d_cuts) {
+    DeviceGuard g(layout->device);
+    (void)hipFree(layout->d_cuts);
+  }
+  delete layout;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API int64_t hipfeat_layout_total_frames(const hipfeat_layout* layout) { return layout ? layout->total_frames : 0; }
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_layout_num_frames(const hipfeat_layout* layout, int64_t* h_num_frames) {
+  if (!layout || !h_num_frames) return fail(HIPFEAT_ERR_INVALID, "NULL argument");
+  std::copy(layout->num_frames.begin(), layout->num_frames.end(), h_num_frames);
+  return HIPFEAT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// launch
+// --------------------------------------------------------------------------------------
+static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay, const float* d_wave, float* d_out,
+                             hipStream_t stream) {
+  if (lay->total_blocks == 0) return HIPFEAT_OK;
+  if (!d_wave || !d_out) return fail(HIPFEAT_ERR_INVALID, "wave/out pointer is NULL");
+  if (lay->fpb != plan->fpb || lay->device != plan->device)
+    return fail(HIPFEAT_ERR_INVALID, "layout was created for a different plan");
+  const hipfeat_config& c = plan->cfg;
+  GenericParams gp{};
+  gp.wave = d_wave;
+  gp.out = d_out;
+  gp.cuts = lay->d_cuts;
+  gp.window = plan->d_window;
+  gp.tw = plan->d_tw;
+  gp.mel = plan->d_mel;
+  gp.mel_range = plan->d_mel_range;
+  gp.dct = plan->d_dct;
+  gp.lifter = plan->d_lifter;
+  gp.out_stride = lay->out_row_stride;
+  gp.num_cuts = (int32_t)lay->batch;
+  gp.uniform_bpc = lay->uniform_bpc;
+  gp.N = c.frame_length;
+  gp.shift = c.frame_shift;
+  gp.fft = c.fft_length;
+  gp.H = plan->H;
+  gp.log2H = plan->log2H;
+  gp.K = plan->K;
+  gp.M = c.num_filters;
+  gp.C = c.num_ceps;
+  gp.kind = c.kind;
+  gp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0) | (c.use_energy ? F_USE_ENERGY : 0) | (c.raw_energy ? F_RAW_ENERGY : 0) |
+             (c.use_fft_mag ? F_FFT_MAG : 0) | (c.apply_lifter ? F_LIFTER : 0) | (plan->pow2 ? F_POW2 : 0);
+  gp.fpb = plan->fpb;
+  gp.npad_left = plan->npad_left;
+  gp.preemph = c.preemph_coeff;
+  gp.log_energy_floor = c.energy_floor > 0.0f ? logf(c.energy_floor) : -INFINITY;
+  gp.mel_floor = c.mel_floor;
+  gp.log_offset = c.log_offset;
+  gp.span = plan->span;
+  gp.off_z = plan->off_z;
+  gp.off_p = plan->off_p;
+  gp.off_tw = plan->off_tw;
+  gp.off_stat = plan->off_stat;
+  gp.off_mel = plan->off_mel;
+  DeviceGuard g(plan->device);
+  hipLaunchKernelGGL(generic_kernel, dim3((unsigned)lay->total_blocks), dim3(256), plan->lds_bytes, stream, gp);
+  HIP_TRY(hipGetLastError());
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_extract_layout(const hipfeat_plan* plan, const hipfeat_layout* layout,
+                                                 const float* d_wave, float* d_out, void* stream) {
+  if (!plan || !layout) return fail(HIPFEAT_ERR_INVALID, "plan/layout is NULL");
+  return launch(plan, layout, d_wave, d_out, (hipStream_t)stream);
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_extract(const hipfeat_plan* plan, const float* d_wave, const int64_t* h_wave_offsets,
+                                          const int64_t* h_num_samples, const int64_t* h_padded_len, int64_t batch,
+                                          float* d_out, const int64_t* h_out_rows, int64_t out_row_stride, void* stream) {
+  if (!plan) return fail(HIPFEAT_ERR_INVALID, "plan is NULL");
+  hipfeat_layout lay;
+  lay.owns = false;
+  std::vector<CutDesc> descs;
+  hipfeat_status st = build_descs(plan, batch, h_wave_offsets, h_num_samples, h_padded_len, h_out_rows, out_row_stride, descs, &lay);
+  if (st != HIPFEAT_OK) return st;
+  if (lay.total_blocks == 0) return HIPFEAT_OK;
+  DeviceGuard g(plan->device);
+  // stage the descriptor table through a pinned ring slot so the call stays asynchronous
+  const size_t bytes = descs.size() * sizeof(CutDesc);
+  std::lock_guard<std::mutex> lk(plan->mu);
+  StagingSlot& s = plan->slots[plan->next_slot];
+  plan->next_slot = (plan->next_slot + 1) % 4;
+  if (s.busy) {
+    HIP_TRY(hipEventSynchronize(s.ev));
+    s.busy = false;
+  }
+  if (!s.ev) HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  if (s.cap < bytes) {
+    if (s.h) (void)hipHostFree(s.h);
+    if (s.d) (void)hipFree(s.d);
+    s.h = s.d = nullptr;
+    s.cap = 0;
+    const size_t cap = std::max<size_t>(bytes * 2, 1 << 16);
+    HIP_TRY(hipHostMalloc(&s.h, cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&s.d, cap));
+    s.cap = cap;
+  }
+  std::memcpy(s.h, descs.data(), bytes);
+  HIP_TRY(hipMemcpyAsync(s.d, s.h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  lay.d_cuts = static_cast<CutDesc*>(s.d);
+  st = launch(plan, &lay, d_wave, d_out, (hipStream_t)stream);
+  hipError_t e = hipEventRecord(s.ev, (hipStream_t)stream);
+  s.busy = (e == hipSuccess);
+  return st;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_extract_host(const hipfeat_plan* plan, const float* h_wave, int64_t wave_elems,
+                                               const int64_t* h_wave_offsets, const int64_t* h_num_samples,
+                                               const int64_t* h_padded_len, int64_t batch, float* h_out,
+                                               int64_t out_elems, const int64_t* h_out_rows, int64_t out_row_stride,
+                                               void* stream) {
+  if (!plan) return fail(HIPFEAT_ERR_INVALID, "plan is NULL");
+  if (wave_elems < 0 || out_elems < 0 || (wave_elems && !h_wave) || (out_elems && !h_out))
+    return fail(HIPFEAT_ERR_INVALID, "bad host buffers");
+  for (int64_t b = 0; b < batch; ++b) {
+    if (h_wave_offsets[b] < 0 || h_wave_offsets[b] + h_num_samples[b] > wave_elems)
+      return fail(HIPFEAT_ERR_INVALID, "cut %lld lies outside the waveform buffer", (long long)b);
+  }
+  for (int64_t b = 0, row = 0; b < batch; ++b) {
+    const hipfeat_config& c = plan->cfg;
+    int64_t T = hipfeat_num_frames(h_num_samples[b], c.frame_length, c.frame_shift, c.snip_edges);
+    if (h_padded_len) T = std::min<int64_t>((h_num_samples[b] + c.frame_shift / 2) / c.frame_shift,
+                                            hipfeat_num_frames(h_padded_len[b], c.frame_length, c.frame_shift, c.snip_edges));
+    const int64_t r0 = h_out_rows ? h_out_rows[b] : row;
+    if (r0 < 0 || (T > 0 && ((r0 + T - 1) * out_row_stride + plan->feature_dim) > out_elems))
+      return fail(HIPFEAT_ERR_INVALID, "cut %lld: output rows lie outside the output buffer", (long long)b);
+    row += T;
+  }
+  DeviceGuard g(plan->device);
+  hipStream_t st_ = (hipStream_t)stream;
+  float *dw, *dout;
+  {
+    std::lock_guard<std::mutex> lk(plan->mu);
+    if (plan->scratch_wave_cap < (size_t)wave_elems) {
+      (void)hipFree(plan->d_scratch_wave);
+      plan->d_scratch_wave = nullptr;
+      plan->scratch_wave_cap = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&plan->d_scratch_wave), std::max<size_t>(wave_elems, 1) * sizeof(float)));
+      plan->scratch_wave_cap = (size_t)wave_elems;
+    }
+    if (plan->scratch_out_cap < (size_t)out_elems) {
+      (void)hipFree(plan->d_scratch_out);
+      plan->d_scratch_out = nullptr;
+      plan->scratch_out_cap = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&plan->d_scratch_out), std::max<size_t>(out_elems, 1) * sizeof(float)));
+      plan->scratch_out_cap = (size_t)out_elems;
+    }
+    dw = plan->d_scratch_wave;
+    dout = plan->d_scratch_out;
+  }
+  // rows / columns no cut covers come back as zeros
+  if (out_elems) HIP_TRY(hipMemsetAsync(dout, 0, (size_t)out_elems * sizeof(float), st_));
+  if (wave_elems) HIP_TRY(hipMemcpyAsync(dw, h_wave, (size_t)wave_elems * sizeof(float), hipMemcpyHostToDevice, st_));
+  hipfeat_status st = hipfeat_extract(plan, dw, h_wave_offsets, h_num_samples, h_padded_len, batch, dout, h_out_rows,
+                                      out_row_stride, stream);
+  if (st != HIPFEAT_OK) return st;
+  if (out_elems) HIP_TRY(hipMemcpyAsync(h_out, dout, (size_t)out_elems * sizeof(float), hipMemcpyDeviceToHost, st_));
+  HIP_TRY(hipStreamSynchronize(st_));
+  return HIPFEAT_OK;
+}

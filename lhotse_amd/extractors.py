@@ -1,0 +1,529 @@
+"""
+Drop-in lhotse feature extractors backed by the MI355X HIP library.
+
+    HipFbank            <->  lhotse.features.kaldi.extractors.Fbank            ("kaldi-fbank")
+    HipMfcc             <->  ...Mfcc                                           ("kaldi-mfcc")
+    HipSpectrogram      <->  ...Spectrogram                                    ("kaldi-spectrogram")
+    HipLogSpectrogram   <->  ...LogSpectrogram                                 ("kaldi-log-spectrogram")
+
+Same config fields (lhotse/features/kaldi/extractors.py:23-63, 155-197, 265-293, 375-403),
+same ``extract`` / ``extract_batch`` / ``frame_shift`` / ``feature_dim`` / ``device`` /
+``mix`` / ``compute_energy`` / ``scale`` / ``to_dict`` / ``from_dict`` surface
+(lhotse/features/base.py:37-365), same input/return conventions (numpy in -> numpy out,
+torch in -> torch out, list / stacked / bare item; extractors.py:485-554).  What differs:
+
+  * the arithmetic runs in hand-written HIP kernels through the C ABI of include/hipfeat.h
+    (one fused launch per batch instead of ~12 full-tensor torch ops);
+  * ``edge_rule`` selects how the right edge of SHORTER batch items is treated:
+    "reflect" (default) frames every item on its own -- identical to ``extract()`` and to
+    kaldifeat -- while "batch_zero_pad" reproduces ``_extract_batch``'s zero-padded batch
+    (SURVEY.md section 8a, quirk Q1);
+  * there is no CPU fallback: without a GPU / the built library, calls raise.
+
+Objects are cheap, picklable (config only; the device plan is created lazily on first use)
+and default-constructible without a GPU, as lhotse requires of registered extractors
+(lhotse/features/base.py:381-388).
+"""
+from __future__ import annotations
+
+import warnings
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib, constants
+from .compat import EPSILON, FeatureExtractor, Seconds, asdict_nonull, compute_num_frames_from_samples, register_extractor
+
+KIND_SPECTROGRAM, KIND_LOG_SPECTROGRAM, KIND_FBANK, KIND_MFCC = 0, 1, 2, 3
+EDGE_RULES = ("reflect", "batch_zero_pad")
+
+ArrayLike = Union[np.ndarray, torch.Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# configs
+# --------------------------------------------------------------------------------------
+def _check_common(cfg) -> None:
+    if cfg.snip_edges:
+        warnings.warn(
+            "`snip_edges` is set to True, which may cause issues in duration to num-frames conversion in Lhotse."
+        )
+    if cfg.edge_rule not in EDGE_RULES:
+        raise ValueError(f"edge_rule must be one of {EDGE_RULES}, got {cfg.edge_rule!r}")
+
+
+@dataclass
+class HipSpectrogramConfig:
+    sampling_rate: int = 16000
+    frame_length: Seconds = 0.025
+    frame_shift: Seconds = 0.01
+    round_to_power_of_two: bool = True
+    remove_dc_offset: bool = True
+    preemph_coeff: float = 0.97
+    window_type: str = "povey"
+    dither: float = 0.0
+    snip_edges: bool = False
+    energy_floor: float = EPSILON
+    raw_energy: bool = True
+    use_energy: bool = False
+    use_fft_mag: bool = False
+    device: str = "cuda"
+    edge_rule: str = "reflect"
+
+    def __post_init__(self):
+        _check_common(self)
+
+    def to_dict(self) -> Dict[str, Any]:
+        return asdict_nonull(self)
+
+    @staticmethod
+    def from_dict(data: Dict[str, Any]) -> "HipSpectrogramConfig":
+        return HipSpectrogramConfig(**data)
+
+
+@dataclass
+class HipLogSpectrogramConfig(HipSpectrogramConfig):
+    @staticmethod
+    def from_dict(data: Dict[str, Any]) -> "HipLogSpectrogramConfig":
+        return HipLogSpectrogramConfig(**data)
+
+
+@dataclass
+class HipFbankConfig:
+    sampling_rate: int = 16000
+    frame_length: Seconds = 0.025
+    frame_shift: Seconds = 0.01
+    round_to_power_of_two: bool = True
+    remove_dc_offset: bool = True
+    preemph_coeff: float = 0.97
+    window_type: str = "povey"
+    dither: float = 0.0
+    snip_edges: bool = False
+    energy_floor: float = EPSILON
+    raw_energy: bool = True
+    use_energy: bool = False
+    use_fft_mag: bool = False
+    low_freq: float = 20.0
+    high_freq: float = -400.0
+    num_filters: int = 80
+    num_mel_bins: Optional[int] = None  # do not use (alias kept for FbankConfig compatibility)
+    norm_filters: bool = False
+    torchaudio_compatible_mel_scale: bool = True
+    device: str = "cuda"
+    edge_rule: str = "reflect"
+
+    def __post_init__(self):
+        if self.num_mel_bins is not None:
+            self.num_filters = self.num_mel_bins
+            self.num_mel_bins = None
+        _check_common(self)
+
+    def to_dict(self) -> Dict[str, Any]:
+        return asdict_nonull(self)
+
+    @staticmethod
+    def from_dict(data: Dict[str, Any]) -> "HipFbankConfig":
+        return HipFbankConfig(**data)
+
+
+@dataclass
+class HipMfccConfig:
+    sampling_rate: int = 16000
+    frame_length: Seconds = 0.025
+    frame_shift: Seconds = 0.01
+    round_to_power_of_two: bool = True
+    remove_dc_offset: bool = True
+    preemph_coeff: float = 0.97
+    window_type: str = "povey"
+    dither: float = 0.0
+    snip_edges: bool = False
+    energy_floor: float = EPSILON
+    raw_energy: bool = True
+    use_energy: bool = False
+    use_fft_mag: bool = False
+    low_freq: float = 20.0
+    high_freq: float = -400.0
+    num_filters: int = 23
+    torchaudio_compatible_mel_scale: bool = True
+    num_mel_bins: Optional[int] = None  # do not use
+    norm_filters: bool = False
+    num_ceps: int = 13
+    cepstral_lifter: int = 22
+    device: str = "cuda"
+    edge_rule: str = "reflect"
+
+    def __post_init__(self):
+        if self.num_mel_bins is not None:
+            self.num_filters = self.num_mel_bins
+            self.num_mel_bins = None
+        _check_common(self)
+
+    def to_dict(self) -> Dict[str, Any]:
+        return asdict_nonull(self)
+
+    @staticmethod
+    def from_dict(data: Dict[str, Any]) -> "HipMfccConfig":
+        return HipMfccConfig(**data)
+
+
+# --------------------------------------------------------------------------------------
+# device plan (lazy, per extractor instance)
+# --------------------------------------------------------------------------------------
+class _Plan:
+    """Owns one ``hipfeat_plan`` (constants resident in HBM + kernel selection)."""
+
+    def __init__(self, cfg, kind: int, device: torch.device):
+        self.lib = _lib.load()
+        self.handle = 0
+        if device.type != "cuda":
+            raise _lib.HipFeatError(1, f"Hip* extractors run on an AMD GPU ('cuda[:i]' device), got device={device}")
+        if not torch.cuda.is_available():
+            raise _lib.HipFeatError(2, "no HIP device is visible (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device.index is None else device.index)
+        n, shift, fft = constants.frame_sizes(cfg.sampling_rate, cfg.frame_length, cfg.frame_shift, cfg.round_to_power_of_two)
+        self.n, self.shift, self.fft = n, shift, fft
+        window = constants.make_window(n, cfg.window_type)
+        mel = dct = lifter = None
+        num_filters = num_ceps = 0
+        apply_lifter = 0
+        if kind in (KIND_FBANK, KIND_MFCC):
+            num_filters = int(cfg.num_filters)
+            if cfg.torchaudio_compatible_mel_scale:
+                mel = constants.make_kaldi_mel(num_filters, fft, cfg.sampling_rate, cfg.low_freq, cfg.high_freq)
+            else:
+                mel = constants.make_htk_mel(num_filters, fft, cfg.sampling_rate, cfg.low_freq, cfg.high_freq, cfg.norm_filters)
+        if kind == KIND_MFCC:
+            num_ceps = int(cfg.num_ceps)
+            dct = constants.make_dct(num_ceps, num_filters)
+            apply_lifter = 1 if cfg.cepstral_lifter > 0 else 0
+            lifter = constants.make_lifter(num_ceps, cfg.cepstral_lifter)
+        c = np.zeros((), dtype=_lib.CONFIG_DTYPE)
+        c["struct_size"] = _lib.CONFIG_DTYPE.itemsize
+        c["kind"] = kind
+        c["frame_length"], c["frame_shift"], c["fft_length"] = n, shift, fft
+        c["num_filters"], c["num_ceps"] = num_filters, num_ceps
+        c["snip_edges"] = int(cfg.snip_edges)
+        c["remove_dc_offset"] = int(cfg.remove_dc_offset)
+        c["use_energy"] = int(cfg.use_energy)
+        c["raw_energy"] = int(cfg.raw_energy)
+        c["use_fft_mag"] = int(cfg.use_fft_mag)
+        c["apply_lifter"] = apply_lifter
+        c["preemph_coeff"] = cfg.preemph_coeff
+        c["energy_floor"] = cfg.energy_floor
+        c["mel_floor"] = constants.MEL_FLOOR
+        c["log_offset"] = constants.LOG_SPEC_OFFSET
+        c["dither"] = cfg.dither
+        cbuf = np.ascontiguousarray(c).reshape(1)
+        out = np.zeros(1, dtype=np.uint64)
+        self.lib.check(
+            "hipfeat_plan_create",
+            _lib.addr(cbuf),
+            _lib.addr(window),
+            _lib.addr(mel),
+            _lib.addr(dct),
+            _lib.addr(lifter),
+            int(self.device.index),
+            _lib.addr(out),
+        )
+        self.handle = int(out[0])
+        self.feature_dim = int(self.lib.raw("hipfeat_plan_feature_dim", self.handle))
+        self.kernel_name = self.lib.string("hipfeat_plan_kernel_name", self.handle)
+        self.snip_edges = int(cfg.snip_edges)
+
+    def num_frames(self, num_samples: int) -> int:
+        return int(self.lib.raw("hipfeat_num_frames", int(num_samples), self.n, self.shift, self.snip_edges))
+
+    def run(self, wave: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray, padded: Optional[np.ndarray]) -> Tuple[torch.Tensor, np.ndarray]:
+        """wave: float32 tensor on self.device holding every cut; returns the packed
+        (sum T_b, F) feature matrix (same device, same stream) and the per-cut frame counts."""
+        assert wave.dtype == torch.float32 and wave.is_contiguous() and wave.device == self.device
+        lengths = _lib.i64(lengths)
+        offsets = _lib.i64(offsets)
+        n, shift, snip = self.n, self.shift, self.snip_edges
+        if padded is None:
+            frames = np.array([self.lib.raw("hipfeat_num_frames", int(s), n, shift, snip) for s in lengths], dtype=np.int64)
+        else:
+            padded = _lib.i64(padded)
+            own = (lengths + shift // 2) // shift
+            row = np.array([self.lib.raw("hipfeat_num_frames", int(p), n, shift, snip) for p in padded], dtype=np.int64)
+            frames = np.minimum(own, row)
+        total = int(frames.sum())
+        with torch.cuda.device(self.device):
+            out = torch.empty((total, self.feature_dim), dtype=torch.float32, device=self.device)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.lib.check(
+                "hipfeat_extract",
+                self.handle,
+                wave.data_ptr(),
+                _lib.addr(offsets),
+                _lib.addr(lengths),
+                _lib.addr(padded),
+                int(len(lengths)),
+                out.data_ptr(),
+                None,
+                self.feature_dim,
+                int(stream),
+            )
+        return out, frames
+
+    def close(self):
+        if self.handle:
+            try:
+                self.lib.raw("hipfeat_plan_destroy", self.handle)
+            finally:
+                self.handle = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------------------
+# shared extractor implementation
+# --------------------------------------------------------------------------------------
+def _as_1d_float(x: ArrayLike, what: str) -> ArrayLike:
+    """(T,), (1,T) or (C,T) -> (T,) of channel 0, as Fbank.extract does with ``[0]``
+    (extractors.py:107-110).  Only float32 is accepted, as in the reference."""
+    if isinstance(x, torch.Tensor):
+        if x.dtype != torch.float32:
+            raise TypeError(f"{what}: expected float32 samples, got {x.dtype}")
+        return x[0] if x.ndim == 2 else x.reshape(-1)
+    x = np.asarray(x)
+    if x.dtype != np.float32:
+        raise TypeError(f"{what}: expected float32 samples, got {x.dtype}")
+    return x[0] if x.ndim == 2 else x.reshape(-1)
+
+
+class _HipExtractor(FeatureExtractor):
+    kind: int = -1
+    _cpu_outputs: bool = False  # Spectrogram/LogSpectrogram.extract return .cpu() (extractors.py:338-341)
+
+    def __init__(self, config: Optional[Any] = None):
+        super().__init__(config=config)
+        self._plan: Optional[_Plan] = None
+
+    # -- lhotse surface -------------------------------------------------------------------
+    @property
+    def device(self) -> Union[str, torch.device]:
+        return self.config.device
+
+    @property
+    def frame_shift(self) -> Seconds:
+        return self.config.frame_shift
+
+    def to(self, device: Union[str, torch.device]):
+        self.config.device = device
+        self._drop_plan()
+        return self
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_plan"] = None  # the device handle is per process
+        return st
+
+    def _drop_plan(self):
+        if self._plan is not None:
+            self._plan.close()
+            self._plan = None
+
+    @property
+    def plan(self) -> _Plan:
+        if self._plan is None:
+            self._plan = _Plan(self.config, self.kind, torch.device(self.config.device))
+        return self._plan
+
+    @property
+    def kernel_name(self) -> str:
+        return self.plan.kernel_name
+
+    def _check_sr(self, sampling_rate: int):
+        assert sampling_rate == self.config.sampling_rate, (
+            f"{type(self).__name__} was instantiated for sampling_rate "
+            f"{self.config.sampling_rate}, but sampling_rate={sampling_rate} was passed to extract(). "
+            "Note you can use CutSet/RecordingSet.resample() to change the audio sampling rate."
+        )
+
+    # -- device plumbing --------------------------------------------------------------------
+    def _pack(self, items: Sequence[ArrayLike]) -> Tuple[torch.Tensor, np.ndarray, np.ndarray]:
+        """Concatenate 1-D waveforms into one device buffer (one H2D copy for host inputs)."""
+        dev = self.plan.device
+        lens = np.array([int(x.shape[0]) for x in items], dtype=np.int64)
+        offs = np.zeros(len(items), dtype=np.int64)
+        np.cumsum(lens[:-1], out=offs[1:])
+        total = int(lens.sum())
+        if all(isinstance(x, torch.Tensor) and x.device == dev for x in items):
+            wave = torch.cat([x.contiguous() for x in items]) if len(items) > 1 else items[0].contiguous()
+            return wave, offs, lens
+        host = torch.empty(total, dtype=torch.float32, pin_memory=True)
+        hv = host.numpy()
+        for x, o, n in zip(items, offs, lens):
+            if isinstance(x, torch.Tensor):
+                host[o : o + n].copy_(x.detach().reshape(-1))
+            else:
+                hv[o : o + n] = x
+        return host.to(dev, non_blocking=True), offs, lens
+
+    def _extract_items(self, items: Sequence[ArrayLike], padded_len: Optional[int] = None) -> Tuple[torch.Tensor, np.ndarray]:
+        wave, offs, lens = self._pack(items)
+        padded = None if padded_len is None else np.full(len(items), padded_len, dtype=np.int64)
+        try:
+            return self.plan.run(wave, offs, lens, padded)
+        except _lib.HipFeatError as e:
+            if e.status == _lib.ERR_TOO_SHORT:
+                raise ValueError(str(e)) from e
+            raise
+
+    # -- extract ----------------------------------------------------------------------------
+    def extract(self, samples: ArrayLike, sampling_rate: int) -> ArrayLike:
+        self._check_sr(sampling_rate)
+        is_numpy = not isinstance(samples, torch.Tensor)
+        x = _as_1d_float(samples, "extract()")
+        with torch.no_grad():
+            feats, _ = self._extract_items([x])
+        if is_numpy:
+            return feats.cpu().numpy()
+        return feats.cpu() if self._cpu_outputs else feats
+
+    def extract_batch(
+        self,
+        samples: Union[np.ndarray, torch.Tensor, Sequence[np.ndarray], Sequence[torch.Tensor]],
+        sampling_rate: int,
+        lengths: Optional[Union[np.ndarray, torch.Tensor]] = None,
+    ) -> Union[np.ndarray, torch.Tensor, List[np.ndarray], List[torch.Tensor]]:
+        self._check_sr(sampling_rate)
+        zero_pad = self.config.edge_rule == "batch_zero_pad"
+        input_is_list = False
+        input_is_torch = False
+        with torch.no_grad():
+            if lengths is not None:
+                assert isinstance(samples, torch.Tensor), "If `lengths` is provided, `samples` must be a batched and padded torch.Tensor."
+                if samples.dtype != torch.float32:
+                    raise TypeError(f"extract_batch(): expected float32 samples, got {samples.dtype}")
+                lens = np.asarray(lengths.cpu() if isinstance(lengths, torch.Tensor) else lengths).astype(np.int64).reshape(-1)
+                assert samples.ndim == 2 and samples.shape[0] == len(lens)
+                smax = int(samples.shape[1])
+                assert int(lens.max(initial=0)) <= smax
+                dev = self.plan.device
+                wave = samples.contiguous()
+                if wave.device != dev:
+                    wave = (wave.pin_memory() if wave.device.type == "cpu" else wave).to(dev, non_blocking=True)
+                offs = np.arange(len(lens), dtype=np.int64) * smax
+                padded = np.full(len(lens), smax, dtype=np.int64) if zero_pad else None
+                try:
+                    packed, frames = self.plan.run(wave.reshape(-1), offs, lens, padded)
+                except _lib.HipFeatError as e:
+                    if e.status == _lib.ERR_TOO_SHORT:
+                        raise ValueError(str(e)) from e
+                    raise
+                # with `lengths` the reference always hands back numpy (extractors.py:539-540)
+            else:
+                if isinstance(samples, (list, tuple)):
+                    input_is_list = True
+                    items = list(samples)
+                elif samples.ndim > 1:
+                    items = list(samples)
+                else:
+                    items = [samples.reshape(1, -1)]
+                input_is_torch = any(isinstance(x, torch.Tensor) for x in items)
+                # the reference squeezes every item (extractors.py:519-522)
+                items = [_as_1d_float(x.squeeze() if x.ndim > 1 else x, "extract_batch()") for x in items]
+                pmax = max(int(x.shape[0]) for x in items) if zero_pad else None
+                packed, frames = self._extract_items(items, pmax)
+
+            if not input_is_torch:
+                packed = packed.cpu().numpy()
+            elif self._cpu_outputs:
+                packed = packed.cpu()
+            bounds = np.concatenate([[0], np.cumsum(frames)])
+            result = [packed[int(bounds[i]) : int(bounds[i + 1])] for i in range(len(frames))]
+
+        if len(result) == 1:
+            return result if input_is_list else result[0]
+        if all(item.shape == result[0].shape for item in result[1:]):
+            # equal lengths: the packed matrix already is the stacked batch
+            return packed.reshape(len(result), *result[0].shape)
+        return result
+
+
+def _log_mix(features_a: np.ndarray, features_b: np.ndarray, energy_scaling_factor_b: float) -> np.ndarray:
+    # extractors.py:134-144
+    return np.log(np.maximum(EPSILON, np.exp(features_a) + energy_scaling_factor_b * np.exp(features_b)))
+
+
+# --------------------------------------------------------------------------------------
+# the four registered extractors
+# --------------------------------------------------------------------------------------
+@register_extractor
+class HipFbank(_HipExtractor):
+    """Log-mel filterbank energies; drop-in for ``Fbank`` (extractors.py:66-152)."""
+
+    name = "hip-fbank"
+    config_type = HipFbankConfig
+    kind = KIND_FBANK
+
+    def feature_dim(self, sampling_rate: int) -> int:
+        return self.config.num_filters
+
+    mix = staticmethod(_log_mix)
+
+    @staticmethod
+    def compute_energy(features: np.ndarray) -> float:
+        return float(np.sum(np.exp(features)))
+
+    @staticmethod
+    def scale(features: np.ndarray, energy_scaling_factor: float) -> np.ndarray:
+        return features + np.log(energy_scaling_factor)
+
+
+@register_extractor
+class HipMfcc(_HipExtractor):
+    """MFCC (log-mel -> DCT -> lifter); drop-in for ``Mfcc`` (extractors.py:200-262)."""
+
+    name = "hip-mfcc"
+    config_type = HipMfccConfig
+    kind = KIND_MFCC
+
+    def feature_dim(self, sampling_rate: int) -> int:
+        return self.config.num_ceps
+
+
+class _SpecMixin:
+    def feature_dim(self, sampling_rate: int) -> int:
+        c = self.config
+        return constants.frame_sizes(c.sampling_rate, c.frame_length, c.frame_shift, c.round_to_power_of_two)[2] // 2 + 1
+
+    @staticmethod
+    def mix(features_a: np.ndarray, features_b: np.ndarray, energy_scaling_factor_b: float) -> np.ndarray:
+        return features_a + energy_scaling_factor_b * features_b
+
+    @staticmethod
+    def compute_energy(features: np.ndarray) -> float:
+        return float(np.sum(features))
+
+    @staticmethod
+    def scale(features: np.ndarray, energy_scaling_factor: float) -> np.ndarray:
+        return energy_scaling_factor * features
+
+
+@register_extractor
+class HipSpectrogram(_SpecMixin, _HipExtractor):
+    """Power / magnitude spectrogram; drop-in for ``Spectrogram`` (extractors.py:296-372)."""
+
+    name = "hip-spectrogram"
+    config_type = HipSpectrogramConfig
+    kind = KIND_SPECTROGRAM
+    _cpu_outputs = True
+
+
+@register_extractor
+class HipLogSpectrogram(_SpecMixin, _HipExtractor):
+    """Log spectrogram; drop-in for ``LogSpectrogram`` (extractors.py:406-482)."""
+
+    name = "hip-log-spectrogram"
+    config_type = HipLogSpectrogramConfig
+    kind = KIND_LOG_SPECTROGRAM
+    _cpu_outputs = True

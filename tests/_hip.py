@@ -1,0 +1,40 @@
+"""Helpers for the GPU tests: build Hip* extractors from golden-case descriptions."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import torch
+
+import lhotse_amd as LA
+
+_TABLE = {
+    "fbank": (LA.HipFbank, LA.HipFbankConfig),
+    "mfcc": (LA.HipMfcc, LA.HipMfccConfig),
+    "spectrogram": (LA.HipSpectrogram, LA.HipSpectrogramConfig),
+    "log-spectrogram": (LA.HipLogSpectrogram, LA.HipLogSpectrogramConfig),
+}
+
+
+def make_hip(kind: str, cfg: dict, **extra):
+    cls, ccls = _TABLE[kind]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return cls(ccls(**cfg, **extra))
+
+
+def run_case(case, waves):
+    """Run the HIP path through the same entry point the reference was run through."""
+    sr = case["cfg"].get("sampling_rate", 16000)
+    if case["mode"] == "extract":
+        ex = make_hip(case["kind"], case["cfg"])
+        return [ex.extract(w, sr) for w in waves]
+    ex = make_hip(case["kind"], case["cfg"], edge_rule="batch_zero_pad")
+    if case["mode"] == "batch":
+        res = ex.extract_batch(list(waves), sr)
+        return list(res) if not (isinstance(res, np.ndarray) and res.ndim == 2) else [res]
+    lens = torch.tensor([len(w) for w in waves], dtype=torch.int32)
+    padded = torch.zeros(len(waves), int(lens.max()))
+    for i, w in enumerate(waves):
+        padded[i, : len(w)] = torch.from_numpy(w)
+    return list(ex.extract_batch(padded, sr, lengths=lens))

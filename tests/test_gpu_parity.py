@@ -1,0 +1,198 @@
+"""
+GPU parity tests (run on a real MI355X): the HIP path, called through the Hip* extractors
+and the C ABI, against
+  (1) the committed golden vectors produced by the reference itself,
+  (2) the oracle (CPU restatement) on fresh seeded inputs,
+both judged relative to float64 arithmetic: the tolerance north_star states is 1e-4
+relative; log features of near-silent bins carry the reference's own float32 noise
+(SURVEY section 7 "parity metric"), so the bar is
+     rel_l2(hip, ref)  <= max(1e-4, 3 * rel_l2(ref, float64 truth))
+     max_abs(hip, ref) <= max(2e-3, 3 * max_abs(ref, float64 truth)).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _golden import CASES, err_stats, golden_rows, load_case, ref_config
+from oracle.kaldi_ref import RefConfig, RefExtractor
+
+pytestmark = pytest.mark.gpu
+
+CASE_NAMES = [c["name"] for c in CASES]
+REL_TOL = 1e-4
+ABS_TOL = 2e-3
+
+
+def assert_parity(got, want, truth, ctx):
+    s = err_stats(got, want)
+    floor = err_stats(want, truth)
+    own = err_stats(got, truth)
+    assert np.isfinite(np.asarray(got)).all(), ctx
+    assert s["rel_l2"] <= max(REL_TOL, 3 * floor["rel_l2"]), (ctx, s, floor, own)
+    assert s["max_abs"] <= max(ABS_TOL, 3 * floor["max_abs"]), (ctx, s, floor, own)
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_hip_matches_reference_golden(name):
+    from _hip import run_case
+
+    case, waves, z = load_case(name)
+    outs = run_case(case, waves)
+    ex64 = RefExtractor(ref_config(case), np.float64)
+    truth = [ex64.extract(w) for w in waves] if case["mode"] == "extract" else ex64.extract_batch(waves, "batch_zero_pad")
+    assert len(outs) == len(waves)
+    for i, o in enumerate(outs):
+        o = np.asarray(o)
+        assert o.dtype == np.float32
+        got, want = golden_rows(z, i, o)
+        tr, _ = golden_rows(z, i, truth[i])
+        assert_parity(got, want, tr, (name, i))
+
+
+@pytest.mark.parametrize("kind,cfg", [("fbank", {}), ("mfcc", {"num_filters": 40, "num_ceps": 40}), ("spectrogram", {}), ("log-spectrogram", {})])
+def test_hip_matches_oracle_ragged_batch(kind, cfg):
+    """Mixed-length batch, per-item reflect rule == every item extracted on its own."""
+    from _hip import make_hip
+
+    rs = np.random.RandomState(7)
+    lens = [140, 161, 400, 1599, 1600, 1601, 16000, 31999, 48000, 7777, 160 * 33, 160 * 32 + 79]
+    waves = [(rs.rand(n).astype(np.float32) - 0.5) for n in lens]
+    ex = make_hip(kind, cfg)
+    outs = ex.extract_batch(waves, 16000)
+    rc = dict(cfg)
+    o32 = RefExtractor(RefConfig(kind=kind, **rc), np.float32)
+    o64 = RefExtractor(RefConfig(kind=kind, **rc), np.float64)
+    assert isinstance(outs, list) and len(outs) == len(waves)
+    for w, o in zip(waves, outs):
+        want, truth = o32.extract(w), o64.extract(w)
+        assert o.shape == want.shape
+        assert_parity(o, want, truth, (kind, len(w)))
+        # batch result == single-item result, bit for bit (same kernel, same arithmetic)
+        np.testing.assert_array_equal(o, ex.extract(w, 16000))
+
+
+def test_full_size_properties():
+    """BASELINE config-2 sized cuts (10 s): properties that do not need a CPU pass over everything."""
+    from _hip import make_hip
+
+    ex = make_hip("fbank", {})
+    g = torch.Generator().manual_seed(0)
+    B, S = 64, 160000
+    x = (torch.rand(B, S, generator=g) * 2 - 1) * 0.5
+    y = ex.extract_batch(x, 16000)
+    assert isinstance(y, torch.Tensor) and y.shape == (B, 1000, 80) and y.dtype == torch.float32
+    assert torch.isfinite(y).all()
+    # determinism
+    y2 = ex.extract_batch(x, 16000)
+    assert torch.equal(y, y2)
+    # batch invariance: row b of a batch == the cut on its own == the cut inside a ragged batch
+    y5 = ex.extract(x[5], 16000)
+    assert torch.equal(y[5], y5)
+    rag = ex.extract_batch([x[5], x[6][:100000], x[7][:1234]], 16000)
+    assert torch.equal(rag[0], y[5])
+    # time-shift covariance: shifting by k*160 samples shifts interior frames by k rows
+    k = 3
+    ys = ex.extract(x[0][k * 160 :], 16000)
+    assert torch.allclose(ys[2:900], y[0][2 + k : 900 + k], atol=1e-5, rtol=0)
+    # scaling: x -> a*x adds 2*log(a) to every log-mel above the floor
+    a = 0.25
+    ya = ex.extract(x[1] * a, 16000)
+    assert torch.allclose(ya, y[1] + 2 * np.log(a), atol=2e-4, rtol=0)
+    # sampled oracle parity on a few full-size cuts
+    o32 = RefExtractor(RefConfig(kind="fbank"), np.float32)
+    o64 = RefExtractor(RefConfig(kind="fbank"), np.float64)
+    for b in (0, 31, 63):
+        w = x[b].numpy()
+        assert_parity(y[b].cpu().numpy(), o32.extract(w), o64.extract(w), ("full", b))
+
+
+def test_too_short_and_errors():
+    from _hip import make_hip
+
+    ex = make_hip("fbank", {})
+    with pytest.raises(ValueError):
+        ex.extract(np.zeros(139, dtype=np.float32), 16000)
+    assert ex.extract(np.zeros(140, dtype=np.float32), 16000).shape == (1, 80)
+    with pytest.raises(AssertionError):
+        ex.extract(np.zeros(1600, dtype=np.float32), 8000)
+    with pytest.raises(TypeError):
+        ex.extract(np.zeros(1600, dtype=np.float64), 16000)
+    from lhotse_amd._lib import HipFeatError
+
+    with pytest.raises(HipFeatError):
+        make_hip("mfcc", {"use_energy": True}).extract(np.zeros(1600, dtype=np.float32), 16000)
+    with pytest.raises(HipFeatError):
+        make_hip("fbank", {"dither": 1.0}).extract(np.zeros(1600, dtype=np.float32), 16000)
+
+
+def test_return_conventions():
+    """extractors.py:485-554: list/stack/bare-item and numpy/torch conventions."""
+    from _hip import make_hip
+
+    ex = make_hip("fbank", {})
+    a = np.random.RandomState(0).rand(1600).astype(np.float32)
+    b = np.random.RandomState(1).rand(3200).astype(np.float32)
+    r = ex.extract_batch([a], 16000)
+    assert isinstance(r, list) and len(r) == 1 and isinstance(r[0], np.ndarray) and r[0].shape == (10, 80)
+    r = ex.extract_batch(a, 16000)
+    assert isinstance(r, np.ndarray) and r.shape == (10, 80)
+    r = ex.extract_batch(np.stack([a, a]), 16000)
+    assert isinstance(r, np.ndarray) and r.shape == (2, 10, 80)
+    r = ex.extract_batch([a, b], 16000)
+    assert isinstance(r, list) and [x.shape for x in r] == [(10, 80), (20, 80)]
+    r = ex.extract_batch([torch.from_numpy(a), torch.from_numpy(b)], 16000)
+    assert isinstance(r, list) and all(isinstance(x, torch.Tensor) for x in r)
+    r = ex.extract_batch([torch.from_numpy(a)[None], torch.from_numpy(a)[None]], 16000)
+    assert isinstance(r, torch.Tensor) and r.shape == (2, 10, 80)
+    # (C, T) input: channel 0 only
+    st = np.stack([a, b[:1600]])
+    np.testing.assert_array_equal(ex.extract(st, 16000), ex.extract(a, 16000))
+    # torch in -> torch out on the device for fbank, .cpu() for spectrogram (extractors.py:338-341)
+    assert ex.extract(torch.from_numpy(a), 16000).device.type == "cuda"
+    assert make_hip("spectrogram", {}).extract(torch.from_numpy(a), 16000).device.type == "cpu"
+    # device tensors are accepted as they are
+    r = ex.extract_batch([torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()], 16000)
+    assert r[1].device.type == "cuda" and r[1].shape == (20, 80)
+
+
+def test_c_abi_padded_output_and_host_form():
+    """The C ABI directly: padded (B, Tmax, F) output with a row stride, and the host-pointer form."""
+    from _hip import make_hip
+    from lhotse_amd import _lib
+
+    ex = make_hip("fbank", {})
+    plan = ex.plan
+    L = plan.lib
+    rs = np.random.RandomState(3)
+    lens = np.array([16000, 8000, 12000], dtype=np.int64)
+    waves = [(rs.rand(n).astype(np.float32) - 0.5) for n in lens]
+    want = ex.extract_batch(waves, 16000)
+    # host form, packed
+    flat = np.concatenate(waves)
+    offs = np.array([0, 16000, 24000], dtype=np.int64)
+    T = np.array([100, 50, 75])
+    out = np.empty((int(T.sum()), 80), dtype=np.float32)
+    L.check("hipfeat_extract_host", plan.handle, _lib.addr(flat), flat.size, _lib.addr(offs), _lib.addr(lens), None, 3,
+            _lib.addr(out), out.size, None, 80, None)
+    np.testing.assert_array_equal(out, np.concatenate(want))
+    # device form, padded output (B, Tmax, 96) with stride 96 > 80
+    d_wave = torch.from_numpy(flat).cuda()
+    d_out = torch.full((3, 100, 96), -1.0, device="cuda")
+    rows = np.array([0, 100, 200], dtype=np.int64)
+    L.check("hipfeat_extract", plan.handle, d_wave.data_ptr(), _lib.addr(offs), _lib.addr(lens), None, 3,
+            d_out.data_ptr(), _lib.addr(rows), 96, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    o = d_out.cpu().numpy()
+    for b in range(3):
+        np.testing.assert_array_equal(o[b, : T[b], :80], want[b])
+        assert (o[b, T[b] :, :] == -1).all() and (o[b, :, 80:] == -1).all()
+    # layout object reuse
+    h = np.zeros(1, dtype=np.uint64)
+    L.check("hipfeat_layout_create", plan.handle, 3, _lib.addr(offs), _lib.addr(lens), None, None, 80, None, _lib.addr(h))
+    assert L.raw("hipfeat_layout_total_frames", int(h[0])) == 225
+    d_o2 = torch.empty((225, 80), device="cuda")
+    for _ in range(3):
+        L.check("hipfeat_extract_layout", plan.handle, int(h[0]), d_wave.data_ptr(), d_o2.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_o2.cpu().numpy(), np.concatenate(want))
+    L.check("hipfeat_layout_destroy", int(h[0]))
