@@ -15,6 +15,7 @@
 
 #include "common.hpp"
 #include "kernel_generic.hpp"
+#include "kernel_fft512.hpp"
 
 using namespace hipfeat;
 
@@ -81,6 +82,17 @@ struct hipfeat_plan {
   int fpb = 8;
   int span = 0, off_z = 0, off_p = 0, off_tw = 0, off_stat = 0, off_mel = 0;
   size_t lds_bytes = 0;
+  // fft512 fast path
+  int variant = 0;  // 0 generic, 1 fft512 fbank
+  int nrows = 0;    // template instance: pass-1 rows that can be non-zero
+  int tiles_per_block = 4;
+  int xs_floats = 0;
+  size_t fast_lds_bytes = 0;
+  float* d_window_half = nullptr;
+  float2* d_tw_pass = nullptr;
+  float2* d_tw_split = nullptr;
+  float* d_mel_a = nullptr;
+  WaveWork* d_work = nullptr;
   // transient-layout staging ring (hipfeat_extract)
   mutable std::mutex mu;
   mutable StagingSlot slots[4];
@@ -166,12 +178,121 @@ static void plan_free(hipfeat_plan* p) {
   (void)hipFree(p->d_lifter);
   (void)hipFree(p->d_scratch_wave);
   (void)hipFree(p->d_scratch_out);
+  (void)hipFree(p->d_window_half);
+  (void)hipFree(p->d_tw_pass);
+  (void)hipFree(p->d_tw_split);
+  (void)hipFree(p->d_mel_a);
+  (void)hipFree(p->d_work);
   for (auto& s : p->slots) {
     if (s.h) (void)hipHostFree(s.h);
     if (s.d) (void)hipFree(s.d);
     if (s.ev) (void)hipEventDestroy(s.ev);
   }
   delete p;
+}
+
+// --------------------------------------------------------------------------------------
+// fft512 fast path: eligibility, constants, mel work split
+// --------------------------------------------------------------------------------------
+template <int NROWS>
+static const void* fft512_entry() {
+  return reinterpret_cast<const void*>(&fft512_fbank_kernel<NROWS>);
+}
+
+static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const float* h_mel) {
+  const hipfeat_config& c = p->cfg;
+  const char* force = getenv("HIPFEAT_FORCE_GENERIC");
+  if (force && force[0] == '1') return HIPFEAT_OK;
+  const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
+  if (c.kind != HIPFEAT_FBANK || c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || c.use_fft_mag)
+    return HIPFEAT_OK;
+  const int need = (N + 31) / 32;
+  const int nrows = need <= 10 ? 10 : (need <= 13 ? 13 : 16);
+  const int ntiles = (M + 15) / 16;
+  if (ntiles > 8) return HIPFEAT_OK;
+
+  // band of every 16-mel tile, in 8-bin groups starting at an even bin
+  struct Seg { int tile, bin, ng; };
+  std::vector<Seg> segs;
+  for (int t = 0; t < ntiles; ++t) {
+    int lo = p->K, hi = 0;
+    for (int k = 0; k < p->K; ++k)
+      for (int j = 16 * t; j < std::min(M, 16 * t + 16); ++j)
+        if (h_mel[(size_t)k * M + j] != 0.0f) {
+          lo = std::min(lo, k);
+          hi = std::max(hi, k + 1);
+        }
+    if (hi == 0) lo = 0, hi = 1;
+    int lo2 = lo & ~1;
+    int ng = (hi - lo2 + 7) / 8;
+    if (lo2 + 8 * ng > kPRowStride) lo2 = (kPRowStride - 8 * ng) & ~1;  // keep reads inside the padded row
+    if (lo2 < 0 || ng > kMaxGroups) return HIPFEAT_OK;
+    segs.push_back({t, lo2, ng});
+  }
+  std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.ng > b.ng; });
+  WaveWork work[4];
+  std::memset(work, 0, sizeof(work));
+  int load[4] = {0, 0, 0, 0}, nseg[4] = {0, 0, 0, 0};
+  for (const Seg& sg : segs) {
+    int best = -1;
+    for (int w = 0; w < 4; ++w)
+      if (nseg[w] < 2 && load[w] + sg.ng <= kMaxGroups && (best < 0 || load[w] < load[best])) best = w;
+    if (best < 0) return HIPFEAT_OK;  // does not fit the static schedule -> generic kernel
+    if (nseg[best] == 0) {
+      work[best].tile0 = sg.tile; work[best].bin0 = sg.bin; work[best].ngroups0 = sg.ng;
+    } else {
+      work[best].tile1 = sg.tile; work[best].bin1 = sg.bin; work[best].ngroups1 = sg.ng;
+    }
+    nseg[best]++;
+    load[best] += sg.ng;
+  }
+  // MFMA A operands: lane (i = lane & 15, kk = lane >> 4) of step (2*gi + r) holds
+  // W[bin + 8*gi' + 2*kk + r][16*tile + i]
+  std::vector<float> mel_a((size_t)4 * 2 * kMaxGroups * 64, 0.0f);
+  for (int w = 0; w < 4; ++w) {
+    int gi = 0;
+    for (int sgm = 0; sgm < 2; ++sgm) {
+      const int tile = sgm ? work[w].tile1 : work[w].tile0, bin = sgm ? work[w].bin1 : work[w].bin0;
+      const int ng = sgm ? work[w].ngroups1 : work[w].ngroups0;
+      for (int g2 = 0; g2 < ng; ++g2, ++gi)
+        for (int r = 0; r < 2; ++r)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kk = lane >> 4;
+            const int b = bin + 8 * g2 + 2 * kk + r, m = 16 * tile + i;
+            if (b < p->K && m < M) mel_a[((size_t)w * 2 * kMaxGroups + 2 * gi + r) * 64 + lane] = h_mel[(size_t)b * M + m];
+          }
+    }
+  }
+  std::vector<float> wh(512, 0.0f);
+  for (int i = 0; i < N; ++i) wh[i] = 0.5f * h_window[i];
+  std::vector<float2> twp(256), tws(256);
+  for (int q = 0; q < 16; ++q)
+    for (int k1 = 0; k1 < 16; ++k1) {
+      const double a = -2.0 * M_PI * (double)(q * k1) / 256.0;
+      twp[q * 16 + k1] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+  for (int k = 0; k < 256; ++k) {  // -i * W_512^k = (sin(a), -cos(a)) with a = -2 pi k / 512
+    const double a = -2.0 * M_PI * (double)k / 512.0;
+    tws[k] = make_float2((float)std::sin(a), (float)(-std::cos(a)));
+  }
+  hipfeat_status st;
+  if ((st = upload(&p->d_window_half, wh.data(), wh.size())) != HIPFEAT_OK) return st;
+  if ((st = upload(&p->d_tw_pass, twp.data(), twp.size())) != HIPFEAT_OK) return st;
+  if ((st = upload(&p->d_tw_split, tws.data(), tws.size())) != HIPFEAT_OK) return st;
+  if ((st = upload(&p->d_mel_a, mel_a.data(), mel_a.size())) != HIPFEAT_OK) return st;
+  if ((st = upload(&p->d_work, work, 4)) != HIPFEAT_OK) return st;
+  p->nrows = nrows;
+  p->tiles_per_block = 4;
+  p->xs_floats = (15 * shift + 32 * nrows + 3) & ~3;
+  p->fast_lds_bytes = (size_t)(p->xs_floats + 4 * kWaveRegion) * sizeof(float);
+  if (p->fast_lds_bytes > 160 * 1024) return HIPFEAT_OK;
+  const void* fn = nrows == 10 ? fft512_entry<10>() : (nrows == 13 ? fft512_entry<13>() : fft512_entry<16>());
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->fast_lds_bytes);
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft512) failed: %s", hipGetErrorName(e));
+  p->variant = 1;
+  p->fpb = kTileFrames * p->tiles_per_block;
+  p->kernel_name = nrows == 10 ? "fft512_fbank<10>" : (nrows == 13 ? "fft512_fbank<13>" : "fft512_fbank<16>");
+  return HIPFEAT_OK;
 }
 
 extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* cfg, const float* h_window,
@@ -279,6 +400,9 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
   if (e != hipSuccess) return bail(fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", p->lds_bytes, hipGetErrorName(e)));
+
+  st = setup_fft512(p, h_window, h_mel);
+  if (st != HIPFEAT_OK) return bail(st);
 
   *out = p;
   return HIPFEAT_OK;
@@ -409,6 +533,39 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
   if (lay->fpb != plan->fpb || lay->device != plan->device)
     return fail(HIPFEAT_ERR_INVALID, "layout was created for a different plan");
   const hipfeat_config& c = plan->cfg;
+  if (plan->variant == 1) {
+    Fft512Params fp{};
+    fp.wave = d_wave;
+    fp.out = d_out;
+    fp.cuts = lay->d_cuts;
+    fp.window_half = plan->d_window_half;
+    fp.tw_pass = plan->d_tw_pass;
+    fp.tw_split = plan->d_tw_split;
+    fp.mel_a = plan->d_mel_a;
+    fp.work = plan->d_work;
+    fp.out_stride = lay->out_row_stride;
+    fp.num_cuts = (int32_t)lay->batch;
+    fp.uniform_bpc = lay->uniform_bpc;
+    fp.tiles_per_block = plan->tiles_per_block;
+    fp.N = c.frame_length;
+    fp.shift = c.frame_shift;
+    fp.npad_left = plan->npad_left;
+    fp.M = c.num_filters;
+    fp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0);
+    fp.preemph = c.preemph_coeff;
+    fp.mel_floor = c.mel_floor;
+    fp.xs_floats = plan->xs_floats;
+    DeviceGuard g(plan->device);
+    const dim3 grid((unsigned)lay->total_blocks), block(256);
+    if (plan->nrows == 10)
+      hipLaunchKernelGGL(fft512_fbank_kernel<10>, grid, block, plan->fast_lds_bytes, stream, fp);
+    else if (plan->nrows == 13)
+      hipLaunchKernelGGL(fft512_fbank_kernel<13>, grid, block, plan->fast_lds_bytes, stream, fp);
+    else
+      hipLaunchKernelGGL(fft512_fbank_kernel<16>, grid, block, plan->fast_lds_bytes, stream, fp);
+    HIP_TRY(hipGetLastError());
+    return HIPFEAT_OK;
+  }
   GenericParams gp{};
   gp.wave = d_wave;
   gp.out = d_out;
