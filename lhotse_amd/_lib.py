@@ -196,8 +196,8 @@ def load(prefer: Optional[str] = None) -> Lib:
         # the SAME HIP runtime instance (same SONAME) so device pointers and streams are shared.
         import torch  # noqa: F401
 
-        path = str(_build.LIB_PATH)
-        if _build.needs_build():
+        path = os.environ.get("HIPFEAT_LIB") or str(_build.LIB_PATH)  # HIPFEAT_LIB: experiment builds
+        if path == str(_build.LIB_PATH) and _build.needs_build():
             try:
                 _build.build()
             except Exception as e:  # stale or missing library and no way to build it

@@ -41,8 +41,11 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm); libhipfeat cannot be built")
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, extra_flags: List[str] = (), output: Path = None) -> Path:
+    """Compile libhipfeat.so.  ``extra_flags`` / ``output`` build experiment variants next to
+    the product library (loaded through the HIPFEAT_LIB environment variable)."""
+    out_path = Path(output) if output is not None else LIB_PATH
+    if output is None and not force and not needs_build():
         return LIB_PATH
     LIB_DIR.mkdir(exist_ok=True)
     cmd = [
@@ -56,9 +59,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         "-Wall",
         "-Wno-unused-function",
         "-DHIPFEAT_BUILD",
+        *list(extra_flags),
         *[str(s) for s in SOURCES],
         "-o",
-        str(LIB_PATH) + ".tmp",
+        str(out_path) + ".tmp",
     ]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
@@ -68,8 +72,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
     if verbose:
         print(res.stderr, file=sys.stderr)
-    os.replace(str(LIB_PATH) + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(str(out_path) + ".tmp", out_path)
+    return out_path
 
 
 if __name__ == "__main__":

@@ -135,8 +135,11 @@ __device__ __forceinline__ void fft16(const float (&xr)[16], const float (&xi)[1
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // NROWS = ceil(N / 32): rows n1 >= NROWS of pass 1 are structurally zero (zero padding to 512).
+#ifndef HIPFEAT_FFT512_WAVES_PER_SIMD
+#define HIPFEAT_FFT512_WAVES_PER_SIMD 2
+#endif
 template <int NROWS>
-__global__ __launch_bounds__(256) void fft512_fbank_kernel(const Fft512Params p) {
+__global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fbank_kernel(const Fft512Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;
   float* regions = smem + p.xs_floats;
