@@ -88,9 +88,8 @@ struct hipfeat_plan {
   int tiles_per_block = 4;
   int xs_floats = 0;
   size_t fast_lds_bytes = 0;
-  float* d_window_half = nullptr;
-  float2* d_tw_pass = nullptr;
-  float2* d_tw_split = nullptr;
+  int const_floats = 0;
+  float* d_lds_consts = nullptr;
   float* d_mel_a = nullptr;
   WaveWork* d_work = nullptr;
   // transient-layout staging ring (hipfeat_extract)
@@ -178,9 +177,7 @@ static void plan_free(hipfeat_plan* p) {
   (void)hipFree(p->d_lifter);
   (void)hipFree(p->d_scratch_wave);
   (void)hipFree(p->d_scratch_out);
-  (void)hipFree(p->d_window_half);
-  (void)hipFree(p->d_tw_pass);
-  (void)hipFree(p->d_tw_split);
+  (void)hipFree(p->d_lds_consts);
   (void)hipFree(p->d_mel_a);
   (void)hipFree(p->d_work);
   for (auto& s : p->slots) {
@@ -226,65 +223,81 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
     int lo2 = lo & ~1;
     int ng = (hi - lo2 + 7) / 8;
     if (lo2 + 8 * ng > kPRowStride) lo2 = (kPRowStride - 8 * ng) & ~1;  // keep reads inside the padded row
-    if (lo2 < 0 || ng > kMaxGroups) return HIPFEAT_OK;
+    if (lo2 < 0 || ng > kMaxGroups0) return HIPFEAT_OK;
     segs.push_back({t, lo2, ng});
   }
+  // the four widest tiles become the waves' first segment, the rest go to the least loaded waves
   std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.ng > b.ng; });
   WaveWork work[4];
   std::memset(work, 0, sizeof(work));
-  int load[4] = {0, 0, 0, 0}, nseg[4] = {0, 0, 0, 0};
-  for (const Seg& sg : segs) {
+  int load[4] = {0, 0, 0, 0};
+  bool has1[4] = {false, false, false, false};
+  for (size_t i = 0; i < segs.size(); ++i) {
+    const Seg& sg = segs[i];
+    if (i < 4) {
+      work[i].tile0 = sg.tile; work[i].bin0 = sg.bin; work[i].ngroups0 = sg.ng;
+      load[i] = sg.ng;
+      continue;
+    }
+    if (sg.ng > kMaxGroups1) return HIPFEAT_OK;  // does not fit the static schedule -> generic kernel
     int best = -1;
     for (int w = 0; w < 4; ++w)
-      if (nseg[w] < 2 && load[w] + sg.ng <= kMaxGroups && (best < 0 || load[w] < load[best])) best = w;
-    if (best < 0) return HIPFEAT_OK;  // does not fit the static schedule -> generic kernel
-    if (nseg[best] == 0) {
-      work[best].tile0 = sg.tile; work[best].bin0 = sg.bin; work[best].ngroups0 = sg.ng;
-    } else {
-      work[best].tile1 = sg.tile; work[best].bin1 = sg.bin; work[best].ngroups1 = sg.ng;
-    }
-    nseg[best]++;
+      if (!has1[w] && (best < 0 || load[w] < load[best])) best = w;
+    if (best < 0) return HIPFEAT_OK;
+    work[best].tile1 = sg.tile; work[best].bin1 = sg.bin; work[best].ngroups1 = sg.ng;
+    has1[best] = true;
     load[best] += sg.ng;
   }
   // MFMA A operands: lane (i = lane & 15, kk = lane >> 4) of step (2*gi + r) holds
-  // W[bin + 8*gi' + 2*kk + r][16*tile + i]
-  std::vector<float> mel_a((size_t)4 * 2 * kMaxGroups * 64, 0.0f);
-  for (int w = 0; w < 4; ++w) {
-    int gi = 0;
+  // W[bin + 8*gi + 2*kk + r][16*tile + i]; the second segment's steps start at 2*kMaxGroups0
+  std::vector<float> mel_a((size_t)4 * kMelARegs * 64, 0.0f);
+  for (int w = 0; w < 4; ++w)
     for (int sgm = 0; sgm < 2; ++sgm) {
       const int tile = sgm ? work[w].tile1 : work[w].tile0, bin = sgm ? work[w].bin1 : work[w].bin0;
       const int ng = sgm ? work[w].ngroups1 : work[w].ngroups0;
-      for (int g2 = 0; g2 < ng; ++g2, ++gi)
+      for (int g2 = 0; g2 < ng; ++g2)
         for (int r = 0; r < 2; ++r)
           for (int lane = 0; lane < 64; ++lane) {
             const int i = lane & 15, kk = lane >> 4;
             const int b = bin + 8 * g2 + 2 * kk + r, m = 16 * tile + i;
-            if (b < p->K && m < M) mel_a[((size_t)w * 2 * kMaxGroups + 2 * gi + r) * 64 + lane] = h_mel[(size_t)b * M + m];
+            const int step = 2 * ((sgm ? kMaxGroups0 : 0) + g2) + r;
+            if (b < p->K && m < M) mel_a[((size_t)w * kMelARegs + step) * 64 + lane] = h_mel[(size_t)b * M + m];
           }
     }
-  }
+  // LDS constant block: window/2 as (even, odd) sample pairs per (row n1, lane q); pass twiddles
+  // W_256^(q k1) per (row k1, lane q); split-step twiddles -i W_512^(q + 16 k2) per (row k2, lane q)
   std::vector<float> wh(512, 0.0f);
   for (int i = 0; i < N; ++i) wh[i] = 0.5f * h_window[i];
-  std::vector<float2> twp(256), tws(256);
-  for (int q = 0; q < 16; ++q)
-    for (int k1 = 0; k1 < 16; ++k1) {
-      const double a = -2.0 * M_PI * (double)(q * k1) / 256.0;
-      twp[q * 16 + k1] = make_float2((float)std::cos(a), (float)std::sin(a));
+  const int const_floats = (nrows * 16 + 512) * 2;
+  std::vector<float> lc((size_t)const_floats, 0.0f);
+  for (int n1 = 0; n1 < nrows; ++n1)
+    for (int q = 0; q < 16; ++q) {
+      lc[2 * (n1 * 16 + q)] = wh[32 * n1 + 2 * q];
+      lc[2 * (n1 * 16 + q) + 1] = wh[32 * n1 + 2 * q + 1];
     }
-  for (int k = 0; k < 256; ++k) {  // -i * W_512^k = (sin(a), -cos(a)) with a = -2 pi k / 512
-    const double a = -2.0 * M_PI * (double)k / 512.0;
-    tws[k] = make_float2((float)std::sin(a), (float)(-std::cos(a)));
-  }
+  float* twp = lc.data() + 2 * nrows * 16;
+  float* tws = twp + 512;
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int q = 0; q < 16; ++q) {
+      const double a = -2.0 * M_PI * (double)(q * k1) / 256.0;
+      twp[2 * (k1 * 16 + q)] = (float)std::cos(a);
+      twp[2 * (k1 * 16 + q) + 1] = (float)std::sin(a);
+    }
+  for (int k2 = 0; k2 < 16; ++k2)
+    for (int q = 0; q < 16; ++q) {  // -i * W_512^k = (sin(a), -cos(a)) with a = -2 pi k / 512
+      const double a = -2.0 * M_PI * (double)(q + 16 * k2) / 512.0;
+      tws[2 * (k2 * 16 + q)] = (float)std::sin(a);
+      tws[2 * (k2 * 16 + q) + 1] = (float)(-std::cos(a));
+    }
   hipfeat_status st;
-  if ((st = upload(&p->d_window_half, wh.data(), wh.size())) != HIPFEAT_OK) return st;
-  if ((st = upload(&p->d_tw_pass, twp.data(), twp.size())) != HIPFEAT_OK) return st;
-  if ((st = upload(&p->d_tw_split, tws.data(), tws.size())) != HIPFEAT_OK) return st;
+  if ((st = upload(&p->d_lds_consts, lc.data(), lc.size())) != HIPFEAT_OK) return st;
   if ((st = upload(&p->d_mel_a, mel_a.data(), mel_a.size())) != HIPFEAT_OK) return st;
   if ((st = upload(&p->d_work, work, 4)) != HIPFEAT_OK) return st;
   p->nrows = nrows;
   p->tiles_per_block = 4;
   p->xs_floats = (15 * shift + 32 * nrows + 3) & ~3;
-  p->fast_lds_bytes = (size_t)(p->xs_floats + 4 * kWaveRegion) * sizeof(float);
+  p->const_floats = const_floats;
+  p->fast_lds_bytes = (size_t)(p->xs_floats + const_floats + 4 * kWaveRegion) * sizeof(float);
   if (p->fast_lds_bytes > 160 * 1024) return HIPFEAT_OK;
   const void* fn = nrows == 10 ? fft512_entry<10>() : (nrows == 13 ? fft512_entry<13>() : fft512_entry<16>());
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->fast_lds_bytes);
@@ -538,9 +551,7 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.wave = d_wave;
     fp.out = d_out;
     fp.cuts = lay->d_cuts;
-    fp.window_half = plan->d_window_half;
-    fp.tw_pass = plan->d_tw_pass;
-    fp.tw_split = plan->d_tw_split;
+    fp.lds_consts = plan->d_lds_consts;
     fp.mel_a = plan->d_mel_a;
     fp.work = plan->d_work;
     fp.out_stride = lay->out_row_stride;
@@ -555,6 +566,7 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.preemph = c.preemph_coeff;
     fp.mel_floor = c.mel_floor;
     fp.xs_floats = plan->xs_floats;
+    fp.const_floats = plan->const_floats;
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(256);
     if (plan->nrows == 10)
