@@ -70,7 +70,8 @@ struct hipfeat_plan {
   int K = 0, H = 0, log2H = 0;
   bool pow2 = false;
   int npad_left = 0;
-  const char* kernel_name = "generic";
+  std::string kernel_name = "generic";
+  int blocks_per_cu = 0;  // hipOccupancyMaxActiveBlocksPerMultiprocessor for the selected kernel
   // device constants
   float* d_window = nullptr;
   float2* d_tw = nullptr;
@@ -304,7 +305,11 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft512) failed: %s", hipGetErrorName(e));
   p->variant = 1;
   p->fpb = kTileFrames * p->tiles_per_block;
-  p->kernel_name = nrows == 10 ? "fft512_fbank<10>" : (nrows == 13 ? "fft512_fbank<13>" : "fft512_fbank<16>");
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, p->fast_lds_bytes) == hipSuccess) p->blocks_per_cu = nb;
+  char nm[96];
+  snprintf(nm, sizeof(nm), "fft512_fbank<%d> lds=%zuB blocks/CU=%d", nrows, p->fast_lds_bytes, p->blocks_per_cu);
+  p->kernel_name = nm;
   return HIPFEAT_OK;
 }
 
@@ -427,7 +432,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_destroy(hipfeat_plan* plan) {
 }
 
 extern "C" HIPFEAT_API int32_t hipfeat_plan_feature_dim(const hipfeat_plan* plan) { return plan ? plan->feature_dim : 0; }
-extern "C" HIPFEAT_API const char* hipfeat_plan_kernel_name(const hipfeat_plan* plan) { return plan ? plan->kernel_name : ""; }
+extern "C" HIPFEAT_API const char* hipfeat_plan_kernel_name(const hipfeat_plan* plan) { return plan ? plan->kernel_name.c_str() : ""; }
 
 // --------------------------------------------------------------------------------------
 // layout

@@ -29,9 +29,12 @@
 namespace hipfeat {
 
 constexpr int kTileFrames = 16;
-constexpr int kExRowStride = 36;                      // dwords per exchange row (16 complex + 4 pad)
-constexpr int kExFrameStride = 16 * kExRowStride;     // 576
-constexpr int kWaveRegion = 4 * kExFrameStride + 16;  // 2320 dwords per wave (== 16 mod 64)
+// Exchange rows: 16 complex + 2 pad dwords.  With a row stride of 34 and a frame stride of 544
+// (== 32 mod 64) the 8-byte writes (16 lanes contiguous) and the 8-byte reads (lane q walks row q;
+// 2 x 16 lanes per LDS cycle) are both bank-conflict free.
+constexpr int kExRowStride = 34;
+constexpr int kExFrameStride = 16 * kExRowStride;     // 544
+constexpr int kWaveRegion = 4 * kExFrameStride + 16;  // 2192 dwords per wave (== 16 mod 64)
 constexpr int kPRowStride = 260;                      // dwords per power row (== 4 mod 64)
 constexpr int kMaxGroups0 = 16;                       // 8-bin MFMA groups of a wave's first / second mel tile
 constexpr int kMaxGroups1 = 4;
@@ -254,11 +257,7 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       v2 b[16];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(exf + q * kExRowStride + 4 * j);
-        b[2 * j] = v2{v.x, v.y};
-        b[2 * j + 1] = v2{v.z, v.w};
-      }
+      for (int n2 = 0; n2 < 16; ++n2) b[n2] = *reinterpret_cast<const v2*>(exf + q * kExRowStride + 2 * n2);
       v2 Z[16];
       fft16(b, Z);
       // all lanes must have finished reading the exchange rows before the power rows overwrite them
