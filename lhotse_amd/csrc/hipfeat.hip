@@ -284,11 +284,15 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
       twp[2 * (k1 * 16 + q)] = (float)std::cos(a);
       twp[2 * (k1 * 16 + q) + 1] = (float)std::sin(a);
     }
-  for (int k2 = 0; k2 < 16; ++k2)
-    for (int q = 0; q < 16; ++q) {  // -i * W_512^k = (sin(a), -cos(a)) with a = -2 pi k / 512
+  float* twsp = tws + 256;
+  for (int k2 = 0; k2 < 8; ++k2)
+    for (int q = 0; q < 16; ++q) {  // w = -i * W_512^k = (sin(a), -cos(a)) with a = -2 pi k / 512; wp = (-w.y, w.x)
       const double a = -2.0 * M_PI * (double)(q + 16 * k2) / 512.0;
-      tws[2 * (k2 * 16 + q)] = (float)std::sin(a);
-      tws[2 * (k2 * 16 + q) + 1] = (float)(-std::cos(a));
+      const float wx = (float)std::sin(a), wy = (float)(-std::cos(a));
+      tws[2 * (k2 * 16 + q)] = wx;
+      tws[2 * (k2 * 16 + q) + 1] = wy;
+      twsp[2 * (k2 * 16 + q)] = -wy;
+      twsp[2 * (k2 * 16 + q) + 1] = wx;
     }
   hipfeat_status st;
   if ((st = upload(&p->d_lds_consts, lc.data(), lc.size())) != HIPFEAT_OK) return st;

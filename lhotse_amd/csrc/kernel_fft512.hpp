@@ -84,10 +84,19 @@ __device__ __forceinline__ float row16_sum(float v) {  // every lane of the row 
 __device__ __forceinline__ float row16_negate_index(float v) { return dpp_mov<DPP_ROW_ROR1>(dpp_mov<DPP_ROW_MIRROR>(v)); }
 
 // ---- packed complex arithmetic ---------------------------------------------------------------
-__device__ __forceinline__ v2 cmul(v2 a, v2 w) {  // a * w
-  return v2{a.x, a.x} * w + v2{a.y, a.y} * v2{-w.y, w.x};
+// hipcc folds whole-register swaps / broadcasts of packed f32 operands into op_sel modifiers but not
+// a sign flip of ONE half, so conjugation and multiplication by +-i are written as a packed multiply
+// by the constant (1,-1) / (-1,1) (exact) feeding an op_sel-swapped add.
+#define HF_CJ (v2{1.f, -1.f})
+#define HF_NCJ (v2{-1.f, 1.f})
+__device__ __forceinline__ v2 swap2(v2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ v2 rot_mi(v2 a) { return swap2(a * HF_NCJ); }  // a * (-i) = (a.y, -a.x)
+__device__ __forceinline__ v2 cmulc(v2 a, v2 w, v2 wp) {  // a * w with wp = (-w.y, w.x) precomputed
+  return v2{a.x, a.x} * w + v2{a.y, a.y} * wp;
 }
-__device__ __forceinline__ v2 mul_mi(v2 a) { return v2{a.y, -a.x}; }  // a * (-i)
+__device__ __forceinline__ v2 cmul(v2 a, v2 w) {  // a * w, only w itself available: a*w.x + (i a)*w.y
+  return a * v2{w.x, w.x} + swap2(a * HF_CJ) * v2{w.y, w.y};
+}
 
 // 16-point complex FFT in registers (radix-4 x radix-4, natural order in and out)
 __device__ __forceinline__ void fft16(const v2 (&x)[16], v2 (&X)[16]) {
@@ -96,31 +105,41 @@ __device__ __forceinline__ void fft16(const v2 (&x)[16], v2 (&X)[16]) {
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
     const v2 s0 = x[n] + x[n + 8], s1 = x[n] - x[n + 8];
-    const v2 s2 = x[n + 4] + x[n + 12], s3 = mul_mi(x[n + 4] - x[n + 12]);
+    const v2 s2 = x[n + 4] + x[n + 12], s3 = rot_mi(x[n + 4] - x[n + 12]);
     y[n] = s0 + s2;
     y[8 + n] = s0 - s2;
     y[4 + n] = s1 + s3;
     y[12 + n] = s1 - s3;
   }
-  // twiddles W16^(n*m)
-  y[4 + 1] = cmul(y[4 + 1], v2{C1, -S1});     // n=1 m=1: W^1
-  y[8 + 1] = cmul(y[8 + 1], v2{R2, -R2});     // n=1 m=2: W^2
-  y[12 + 1] = cmul(y[12 + 1], v2{S1, -C1});   // n=1 m=3: W^3
-  y[4 + 2] = cmul(y[4 + 2], v2{R2, -R2});     // n=2 m=1: W^2
-  y[8 + 2] = mul_mi(y[8 + 2]);                // n=2 m=2: W^4 = -i
-  y[12 + 2] = cmul(y[12 + 2], v2{-R2, -R2});  // n=2 m=3: W^6
-  y[4 + 3] = cmul(y[4 + 3], v2{S1, -C1});     // n=3 m=1: W^3
-  y[8 + 3] = cmul(y[8 + 3], v2{-R2, -R2});    // n=3 m=2: W^6
-  y[12 + 3] = cmul(y[12 + 3], v2{-C1, S1});   // n=3 m=3: W^9
+  // twiddles W16^(n*m): w = (c, -s), wp = (s, c)
+  y[4 + 1] = cmulc(y[4 + 1], v2{C1, -S1}, v2{S1, C1});      // n=1 m=1: W^1
+  y[8 + 1] = cmulc(y[8 + 1], v2{R2, -R2}, v2{R2, R2});      // n=1 m=2: W^2
+  y[12 + 1] = cmulc(y[12 + 1], v2{S1, -C1}, v2{C1, S1});    // n=1 m=3: W^3
+  y[4 + 2] = cmulc(y[4 + 2], v2{R2, -R2}, v2{R2, R2});      // n=2 m=1: W^2
+  y[8 + 2] = rot_mi(y[8 + 2]);                              // n=2 m=2: W^4 = -i
+  y[12 + 2] = cmulc(y[12 + 2], v2{-R2, -R2}, v2{R2, -R2});  // n=2 m=3: W^6
+  y[4 + 3] = cmulc(y[4 + 3], v2{S1, -C1}, v2{C1, S1});      // n=3 m=1: W^3
+  y[8 + 3] = cmulc(y[8 + 3], v2{-R2, -R2}, v2{R2, -R2});    // n=3 m=2: W^6
+  y[12 + 3] = cmulc(y[12 + 3], v2{-C1, S1}, v2{-S1, -C1});  // n=3 m=3: W^9
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const v2 s0 = y[4 * m] + y[4 * m + 2], s1 = y[4 * m] - y[4 * m + 2];
-    const v2 s2 = y[4 * m + 1] + y[4 * m + 3], s3 = mul_mi(y[4 * m + 1] - y[4 * m + 3]);
+    const v2 s2 = y[4 * m + 1] + y[4 * m + 3], s3 = rot_mi(y[4 * m + 1] - y[4 * m + 3]);
     X[m] = s0 + s2;       // k' = 0
     X[m + 4] = s1 + s3;   // k' = 1
     X[m + 8] = s0 - s2;   // k' = 2
     X[m + 12] = s1 - s3;  // k' = 3
   }
+}
+
+// natural log of a normal positive float: v_log_f32 (log2, 1 ulp) times ln 2.  The argument is
+// >= mel_floor (1.19e-7), so the denormal path of the library logf is never needed.
+__device__ __forceinline__ float fast_log(float x) {
+#ifdef HIPFEAT_ACCURATE_LOG
+  return logf(x);
+#else
+  return __builtin_amdgcn_logf(x) * 0.69314718055994531f;
+#endif
 }
 
 #ifndef HIPFEAT_FFT512_WAVES_PER_SIMD
@@ -134,7 +153,8 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
   float* xs = smem;
   const v2* cwin = reinterpret_cast<const v2*>(smem + p.xs_floats);  // [NROWS][16]
   const v2* ctwp = cwin + NROWS * 16;                                // [16][16] row k1, column q
-  const v2* ctws = ctwp + 256;                                       // [16][16] row k2, column q
+  const v2* ctws = ctwp + 256;                                       // [8][16] row k2 < 8, column q: w = -i W_512^(q+16 k2)
+  const v2* ctwsp = ctws + 128;                                      // [8][16] (-w.y, w.x)
   float* regions = smem + p.xs_floats + p.const_floats;
 
   const int tid = threadIdx.x;
@@ -263,24 +283,36 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
       // all lanes must have finished reading the exchange rows before the power rows overwrite them
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      float* prow = myreg + g * kPRowStride + q;
-      if (q < 3) prow[257] = 0.f;  // pad columns 257..259 are read (with zero weight) by the last k-group
+      // Split step on bin PAIRS.  For k = q + 16 k2 (k2 < 8) the mirror bin 256-k is register 15-k2
+      // of lane (16-q)%16; with a = Z[k], b = Z[256-k], s = a + conj(b), d = a - conj(b), t = (-i W^k) d:
+      //   X[k] = s + t   and   X[256-k] = conj(s - t),
+      // so each lane evaluates 8 pairs and stores 16 power values (8 in its own column, 8 in its
+      // partner's).  Lane 0 (column 0) is its own partner with registers (16-k2)%16; its k2 = 0 pair
+      // yields DC and Nyquist, and bin 128 (register 8, self-paired, W = -i) is added separately.
+      float* prow = myreg + g * kPRowStride;
+      float* pown = prow + q;
+      float* ppar = prow + ((16 - q) & 15) + (q == 0 ? 16 : 0);
+      if (q < 3) prow[257 + q] = 0.f;  // pad columns 257..259 are read (with zero weight) by the last k-group
+      float t1[16];
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) {
-        // mirror bin Z[256 - k], k = q + 16 k2: lane (16-q)%16, register 15-k2 (q != 0);
-        // lane 0 pairs bin 16 k2 with bin 16 (16 - k2): its own register (16 - k2) % 16
-        v2 m = v2{row16_negate_index(Z[15 - k2].x), row16_negate_index(Z[15 - k2].y)};
-        if (q == 0) m = Z[(16 - k2) & 15];
-        const v2 s = Z[k2] + v2{m.x, -m.y};  // a + conj(b)
-        const v2 d = Z[k2] - v2{m.x, -m.y};  // a - conj(b)
-        const v2 tt = cmul(d, ctws[k2 * 16 + q]);
-        const v2 X = s + tt;
-        prow[16 * k2] = X.x * X.x + X.y * X.y;
-        if (k2 == 0 && q == 0) {
-          const v2 nq = s - tt;  // Nyquist bin 256
-          prow[256] = nq.x * nq.x + nq.y * nq.y;
-        }
+      for (int k2 = 0; k2 < 8; ++k2) {
+        t1[2 * k2] = dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].x);
+        t1[2 * k2 + 1] = dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].y);
       }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t1[i] = dpp_mov<DPP_ROW_ROR1>(t1[i]);
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        v2 m = v2{t1[2 * k2], t1[2 * k2 + 1]};
+        if (q == 0) m = Z[(16 - k2) & 15];
+        const v2 sp = m * HF_CJ + Z[k2];   // a + conj(b)
+        const v2 dm = m * HF_NCJ + Z[k2];  // a - conj(b)
+        const v2 tt = cmulc(dm, ctws[k2 * 16 + q], ctwsp[k2 * 16 + q]);
+        const v2 xp = sp + tt, xm = sp - tt;
+        pown[16 * k2] = xp.x * xp.x + xp.y * xp.y;
+        ppar[16 * (15 - k2)] = xm.x * xm.x + xm.y * xm.y;
+      }
+      if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
     }
     __syncthreads();
 
@@ -293,10 +325,10 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
       auto epilogue = [&](const f32x4 acc, int tile) {
         const int m0 = tile * 16 + 4 * kk;
         f32x4 v;
-        v.x = logf(fmaxf(acc.x, p.mel_floor));
-        v.y = logf(fmaxf(acc.y, p.mel_floor));
-        v.z = logf(fmaxf(acc.z, p.mel_floor));
-        v.w = logf(fmaxf(acc.w, p.mel_floor));
+        v.x = fast_log(fmaxf(acc.x, p.mel_floor));
+        v.y = fast_log(fmaxf(acc.y, p.mel_floor));
+        v.z = fast_log(fmaxf(acc.z, p.mel_floor));
+        v.w = fast_log(fmaxf(acc.w, p.mel_floor));
         if (j < nf) {
           if (vec_ok && m0 + 3 < p.M) {
             *reinterpret_cast<f32x4*>(orow + m0) = v;
