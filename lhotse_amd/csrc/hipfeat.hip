@@ -729,3 +729,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_extract_host(const hipfeat_plan* p
   HIP_TRY(hipStreamSynchronize(st_));
   return HIPFEAT_OK;
 }
+
+#ifdef HIPFEAT_PHASE_TIMERS
+// experiment builds only: install the per-wave phase-clock buffer ([waves][8] uint64, device memory)
+extern "C" HIPFEAT_API int hipfeat_debug_set_phase_buffer(unsigned long long* d_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(hipfeat::g_phase_buf), &d_buf, sizeof(d_buf)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -34,9 +34,13 @@ constexpr int kTileFrames = 16;
 // 2 x 16 lanes per LDS cycle) are both bank-conflict free.
 constexpr int kExRowStride = 34;
 constexpr int kExFrameStride = 16 * kExRowStride;     // 544
+#ifdef HIPFEAT_EXPERIMENT_REGION  // perf-only experiment (results are garbage): smaller LDS footprint
+constexpr int kWaveRegion = HIPFEAT_EXPERIMENT_REGION;
+#else
 constexpr int kWaveRegion = 4 * kExFrameStride + 16;  // 2192 dwords per wave (== 16 mod 64)
+#endif
 constexpr int kPRowStride = 260;                      // dwords per power row (== 4 mod 64)
-constexpr int kMaxGroups0 = 16;                       // 8-bin MFMA groups of a wave's first / second mel tile
+constexpr int kMaxGroups0 = 14;                       // 8-bin MFMA groups of a wave's first / second mel tile
 constexpr int kMaxGroups1 = 4;
 constexpr int kMelARegs = 2 * (kMaxGroups0 + kMaxGroups1);
 constexpr int kPrefetch = 3;                          // float4 per lane per tile (256 * 3 * 4 >= span)
@@ -142,6 +146,28 @@ __device__ __forceinline__ float fast_log(float x) {
 #endif
 }
 
+// Optional phase timers (experiment builds only): per-phase shader-clock totals over all waves.
+#ifdef HIPFEAT_PHASE_TIMERS
+__device__ unsigned long long* g_phase_buf;  // [grid * 4 waves][8], written once per wave (no atomics)
+#define HF_T(i) const unsigned long long t##i = __builtin_readcyclecounter()
+#define HF_ACC(slot, a, b) hf_acc[slot] += (unsigned long long)((b) - (a))
+#ifdef HIPFEAT_PHASE_TIMERS2
+#define HF_U(i) u##i = __builtin_readcyclecounter()
+#else
+#define HF_U(i)
+#endif
+#else
+#define HF_T(i)
+#define HF_U(i)
+#define HF_ACC(slot, a, b)
+#endif
+
+#ifndef HIPFEAT_HOIST_TW
+#define HIPFEAT_HOIST_TW 0
+#endif
+#ifndef HIPFEAT_S5_CHUNK
+#define HIPFEAT_S5_CHUNK 4
+#endif
 #ifndef HIPFEAT_FFT512_WAVES_PER_SIMD
 #define HIPFEAT_FFT512_WAVES_PER_SIMD 3
 #endif
@@ -189,7 +215,7 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
 
   float* myreg = regions + wv * kWaveRegion;
   const bool dc = (p.flags & F_REMOVE_DC) != 0;
-  const float fN = (float)N;
+  const float inv_n = 1.0f / (float)N;
   const float c = p.preemph;
 
   // ---- tile loop with register prefetch of the next span ---------------------------------
@@ -210,12 +236,16 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
     have_pre = true;
   }
 
+#ifdef HIPFEAT_PHASE_TIMERS
+  unsigned long long hf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int t = 0; t < p.tiles_per_block; ++t) {
     const int f0 = (first_tile + t) * kTileFrames;
     if (f0 >= cd.num_frames) break;  // uniform across the workgroup
     const int nf = min(kTileFrames, cd.num_frames - f0);
 
     // ---- S1: sample span -> LDS ---------------------------------------------------------
+    HF_T(0);
     if (have_pre) {
 #pragma unroll
       for (int i = 0; i < kPrefetch; ++i) {
@@ -231,26 +261,39 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
       have_pre = (t + 1 < p.tiles_per_block) && fn < cd.num_frames && tile_is_interior(fn);
       if (have_pre) issue_prefetch(fn);
     }
+    HF_T(1);
     __syncthreads();
+    HF_T(2);
 
     // ---- S3: one frame per 16 lanes -------------------------------------------------------
+#ifdef HIPFEAT_PHASE_TIMERS2
+    unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0, u5 = 0;
+#endif
     {
       const float* x = xs + (4 * wv + g) * shift + 2 * q;
       v2 z[16];
+      v2 win[NROWS];
       v2 sum2 = {0.f, 0.f};
+      // the sample rows and the window are requested together up front
 #pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) {
-        v2 v = *reinterpret_cast<const v2*>(x + 32 * n1);
-        if (n1 == NROWS - 1) {  // only the last row can cross N
-          const int m0 = 32 * n1 + 2 * q;
-          if (m0 >= N) v.x = 0.f;
-          if (m0 + 1 >= N) v.y = 0.f;
-        }
-        z[n1] = v;
-        sum2 += v;
+      for (int n1 = 0; n1 < NROWS; ++n1) z[n1] = *reinterpret_cast<const v2*>(x + 32 * n1);
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = cwin[n1 * 16 + q];
+#if HIPFEAT_HOIST_TW
+      v2 twp[16];  // pass twiddles: in flight while the window / first FFT run
+#pragma unroll
+      for (int k1 = 1; k1 < 16; ++k1) twp[k1] = ctwp[k1 * 16 + q];
+#endif
+      {  // only the last row can cross N
+        const int m0 = 32 * (NROWS - 1) + 2 * q;
+        if (m0 >= N) z[NROWS - 1].x = 0.f;
+        if (m0 + 1 >= N) z[NROWS - 1].y = 0.f;
       }
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) sum2 += z[n1];
+      HF_U(0);
       float mu = 0.f;
-      if (dc) mu = row16_sum(sum2.x + sum2.y) / fN;
+      if (dc) mu = row16_sum(sum2.x + sum2.y) * inv_n;
       float tprev = 0.f;
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) {
@@ -260,26 +303,43 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
         // lane 15's second element of the previous row; the very first sample replicates itself
         const float dp = (q == 0) ? (n1 == 0 ? d.x : tprev) : tcur;
         tprev = tcur;
-        z[n1] = (d - v2{c, c} * v2{dp, d.x}) * cwin[n1 * 16 + q];
+        z[n1] = (d - v2{c, c} * v2{dp, d.x}) * win[n1];
       }
 #pragma unroll
       for (int n1 = NROWS; n1 < 16; ++n1) z[n1] = v2{0.f, 0.f};
+      HF_U(1);
       v2 a[16];
       fft16(z, a);
+      HF_U(2);
 #pragma unroll
+#if HIPFEAT_HOIST_TW
+      for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], twp[k1]);
+#else
       for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], ctwp[k1 * 16 + q]);
+#endif
       // exchange: row k1 of this frame's block receives this lane's A[k1] at column q
       float* exf = myreg + g * kExFrameStride;
 #pragma unroll
       for (int k1 = 0; k1 < 16; ++k1) *reinterpret_cast<v2*>(exf + k1 * kExRowStride + 2 * q) = a[k1];
+      HF_U(3);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       v2 b[16];
 #pragma unroll
       for (int n2 = 0; n2 < 16; ++n2) b[n2] = *reinterpret_cast<const v2*>(exf + q * kExRowStride + 2 * n2);
+      HF_U(4);
+#if HIPFEAT_HOIST_TW
+      v2 tsw[8], tswp[8];  // split-step twiddles: in flight while the second FFT runs
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        tsw[k2] = ctws[k2 * 16 + q];
+        tswp[k2] = ctwsp[k2 * 16 + q];
+      }
+#endif
       v2 Z[16];
       fft16(b, Z);
+      HF_U(5);
       // all lanes must have finished reading the exchange rows before the power rows overwrite them
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -307,14 +367,20 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
         if (q == 0) m = Z[(16 - k2) & 15];
         const v2 sp = m * HF_CJ + Z[k2];   // a + conj(b)
         const v2 dm = m * HF_NCJ + Z[k2];  // a - conj(b)
+#if HIPFEAT_HOIST_TW
+        const v2 tt = cmulc(dm, tsw[k2], tswp[k2]);
+#else
         const v2 tt = cmulc(dm, ctws[k2 * 16 + q], ctwsp[k2 * 16 + q]);
+#endif
         const v2 xp = sp + tt, xm = sp - tt;
         pown[16 * k2] = xp.x * xp.x + xp.y * xp.y;
         ppar[16 * (15 - k2)] = xm.x * xm.x + xm.y * xm.y;
       }
       if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
     }
+    HF_T(3);
     __syncthreads();
+    HF_T(4);
 
     // ---- S5: banded mel GEMM on the matrix cores + log + store ---------------------------
     {
@@ -340,36 +406,74 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
           }
         }
       };
+      // gfx950 counts loads and stores in ONE in-order counter (vmcnt).  Consume the prefetched
+      // span registers here, before this tile's output stores are issued: the loads were requested
+      // a whole S3 ago, so this wait is free, and the next S1 then never has to wait behind the
+      // (slow to retire) stores.
+#pragma unroll
+      for (int i = 0; i < kPrefetch; ++i) asm volatile("" : "+v"(pre[i]));
+      // Each segment is processed in chunks of HIPFEAT_S5_CHUNK groups: one burst of LDS reads per
+      // chunk (a single latency exposure), then its MFMAs; a chunk runs when the band reaches it
+      // (groups past the band inside a chunk carry zero weights and a clamped, valid bin offset).
+      // Two accumulators hide the 40-cycle dependent-MFMA latency behind the 32-cycle issue interval.
+      constexpr int CH = HIPFEAT_S5_CHUNK;
       if (ww.ngroups0 > 0) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        const float* pp = pb + ww.bin0;
 #pragma unroll
-        for (int gi = 0; gi < kMaxGroups0; ++gi) {
-          if (gi < ww.ngroups0) {
-            const v2 pv = *reinterpret_cast<const v2*>(pp + 8 * gi);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mela[2 * gi], pv.x, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(mela[2 * gi + 1], pv.y, acc2, 0, 0, 0);
+        for (int c0 = 0; c0 < kMaxGroups0; c0 += CH) {
+          if (c0 < ww.ngroups0) {
+            v2 pv[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+              if (c0 + i < kMaxGroups0) pv[i] = *reinterpret_cast<const v2*>(pb + min(ww.bin0 + 8 * (c0 + i), kPRowStride - 8));
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+              if (c0 + i < kMaxGroups0) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mela[2 * (c0 + i)], pv[i].x, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(mela[2 * (c0 + i) + 1], pv[i].y, acc2, 0, 0, 0);
+              }
           }
         }
         epilogue(acc + acc2, ww.tile0);
       }
       if (ww.ngroups1 > 0) {
+        v2 pv[kMaxGroups1];
+#pragma unroll
+        for (int gi = 0; gi < kMaxGroups1; ++gi) pv[gi] = *reinterpret_cast<const v2*>(pb + min(ww.bin1 + 8 * gi, kPRowStride - 8));
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        const float* pp = pb + ww.bin1;
 #pragma unroll
         for (int gi = 0; gi < kMaxGroups1; ++gi) {
-          if (gi < ww.ngroups1) {
-            const v2 pv = *reinterpret_cast<const v2*>(pp + 8 * gi);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mela[2 * (kMaxGroups0 + gi)], pv.x, acc, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(mela[2 * (kMaxGroups0 + gi) + 1], pv.y, acc2, 0, 0, 0);
-          }
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(mela[2 * (kMaxGroups0 + gi)], pv[gi].x, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(mela[2 * (kMaxGroups0 + gi) + 1], pv[gi].y, acc2, 0, 0, 0);
         }
         epilogue(acc + acc2, ww.tile1);
       }
     }
+    HF_T(5);
+    HF_ACC(0, t0, t1);  // S1 work
+    HF_ACC(1, t1, t2);  // barrier 1
+    HF_ACC(2, t2, t3);  // S3
+    HF_ACC(3, t3, t4);  // barrier 2
+    HF_ACC(4, t4, t5);  // S5
+    HF_ACC(5, t0, t0 + 1);  // tile count
+#ifdef HIPFEAT_PHASE_TIMERS2
+    hf_acc[0] = hf_acc[0] - (t1 - t0) + (u0 - t2);  // slot0: reads + sum
+    hf_acc[1] = hf_acc[1] - (t2 - t1) + (u1 - u0);  // slot1: mean + preprocess
+    hf_acc[2] = hf_acc[2] - (t3 - t2) + (u2 - u1);  // slot2: fft1
+    hf_acc[3] = hf_acc[3] - (t4 - t3) + (u3 - u2);  // slot3: twiddle + exchange write
+    hf_acc[4] = hf_acc[4] - (t5 - t4) + (u4 - u3);  // slot4: exchange read
+    hf_acc[6] += (u5 - u4);                          // slot6: fft2
+    hf_acc[7] += (t3 - u5);                          // slot7: mirror + split + P write
+#endif
     // the next tile's S1 only writes xs; its barrier separates this tile's P reads from the next
     // tile's exchange writes
   }
+#ifdef HIPFEAT_PHASE_TIMERS
+  if (lane == 0 && g_phase_buf) {
+    unsigned long long* o = g_phase_buf + ((size_t)blockIdx.x * 4 + wv) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = hf_acc[i];
+  }
+#endif
 }
 
 }  // namespace hipfeat
