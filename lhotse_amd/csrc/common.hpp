@@ -46,7 +46,7 @@ struct GenericParams {
 };
 
 __device__ __forceinline__ float load_sample(const float* __restrict__ w, int64_t j, int32_t S, int32_t P) {
-  // Index restatement of the flip/cat of layers.py:756-764 (see oracle/kaldi_ref.py frame_indices):
+  // Index restatement of the flip/cat of layers.py:756-764: frame t, tap i reads j = shift*t - npad_left + i,
   // j<0 -> -j-1, j>=P -> 2P-1-j; indices in [S, P) are the zero padding of a batch row.
   if (j < 0) j = -j - 1;
   if (j >= P) j = 2 * (int64_t)P - 1 - j;

@@ -358,7 +358,7 @@ class _HipExtractor(FeatureExtractor):
         if all(isinstance(x, torch.Tensor) and x.device == dev for x in items):
             wave = torch.cat([x.contiguous() for x in items]) if len(items) > 1 else items[0].contiguous()
             return wave, offs, lens
-        host = torch.empty(total, dtype=torch.float32, pin_memory=True)
+        host = torch.empty(total, dtype=torch.float32, pin_memory=(dev.type == "cuda"))
         hv = host.numpy()
         for x, o, n in zip(items, offs, lens):
             if isinstance(x, torch.Tensor):
@@ -410,7 +410,7 @@ class _HipExtractor(FeatureExtractor):
                 dev = self.plan.device
                 wave = samples.contiguous()
                 if wave.device != dev:
-                    wave = (wave.pin_memory() if wave.device.type == "cpu" else wave).to(dev, non_blocking=True)
+                    wave = (wave.pin_memory() if (wave.device.type == "cpu" and dev.type == "cuda") else wave).to(dev, non_blocking=True)
                 offs = np.arange(len(lens), dtype=np.int64) * smax
                 padded = np.full(len(lens), smax, dtype=np.int64) if zero_pad else None
                 try:
@@ -442,6 +442,11 @@ class _HipExtractor(FeatureExtractor):
             result = [packed[int(bounds[i]) : int(bounds[i + 1])] for i in range(len(frames))]
 
         if len(result) == 1:
+            # NB with `lengths` (a padded batch came in) a batch comes out, even for one item: the
+            # reference returns the bare matrix here (extractors.py:543-547), which its own batch
+            # driver then mis-iterates row by row (cut/set.py:2308, single-cut collated batches).
+            if lengths is not None:
+                return packed.reshape(1, *result[0].shape)
             return result if input_is_list else result[0]
         if all(item.shape == result[0].shape for item in result[1:]):
             # equal lengths: the packed matrix already is the stacked batch

@@ -1,0 +1,108 @@
+"""CPU tests of the C-ABI boundary: the header is valid C, the library loads and exports every
+declared symbol, the struct mirror matches, and the pure host helpers agree with the reference
+formulas.  No compute call is made (no GPU here)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from lhotse_amd import _lib, build
+from oracle import kaldi_ref as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "hipfeat.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    return sorted(set(re.findall(r"HIPFEAT_API\s+[\w\s\*]+?\b(hipfeat_\w+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    path = build.build()
+    assert os.path.exists(path)
+    names = declared_functions()
+    assert len(names) >= 16
+    assert set(names) == set(_lib._SIGNATURES), set(names) ^ set(_lib._SIGNATURES)
+    out = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (hipfeat_\w+)", out))
+    assert set(names) <= exported, set(names) - exported
+    # nothing else leaks out of the library (-fvisibility=hidden)
+    assert all(s.startswith("hipfeat_") for s in exported if not s.startswith("_")), exported
+
+
+def test_header_is_plain_c_and_struct_layout_matches(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "hipfeat.h"\n'
+        "int main(void){printf(\"%zu %zu %zu %zu %d\\n\", sizeof(hipfeat_config), offsetof(hipfeat_config, preemph_coeff),"
+        " offsetof(hipfeat_config, dither), offsetof(hipfeat_config, num_ceps), HIPFEAT_ABI_VERSION); return 0;}\n"
+    )
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    size, off_pre, off_dither, off_ceps, abi = map(int, subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    dt = _lib.CONFIG_DTYPE
+    assert size == dt.itemsize
+    assert off_pre == dt.fields["preemph_coeff"][1]
+    assert off_dither == dt.fields["dither"][1]
+    assert off_ceps == dt.fields["num_ceps"][1]
+    assert abi == _lib.ABI_VERSION
+
+
+def test_loader_and_pure_helpers():
+    lib = _lib.load()
+    assert lib.raw("hipfeat_abi_version") == _lib.ABI_VERSION
+    assert lib.backend.name in ("ctypes", "cffi")
+    for n, shift in [(400, 160), (200, 80), (551, 220), (1102, 441), (512, 128)]:
+        for s in list(range(0, 1300)) + [160000, 100050, 256640]:
+            for snip in (0, 1):
+                assert lib.raw("hipfeat_num_frames", s, n, shift, snip) == K.num_frames(s, n, shift, bool(snip))
+    # first valid length for 25/10 ms @ 16 kHz is 140 samples
+    assert lib.raw("hipfeat_check_length", 139, 400, 160, 0) == _lib.ERR_TOO_SHORT
+    assert "shorter than the reflect padding" in lib.last_error()
+    assert lib.raw("hipfeat_check_length", 140, 400, 160, 0) == 0
+    assert lib.raw("hipfeat_check_length", 10, 400, 160, 1) == 0
+    for s in range(1, 1000):
+        ok = lib.raw("hipfeat_check_length", s, 400, 160, 0) == 0
+        try:
+            K.frame_indices(s, 400, 160, False)
+            ref_ok = K.num_frames(s, 400, 160, False) > 0
+        except ValueError:
+            ref_ok = False
+        assert ok == ref_ok, s
+
+
+def test_plan_create_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    cfg = np.zeros(1, dtype=_lib.CONFIG_DTYPE)
+    cfg["struct_size"] = _lib.CONFIG_DTYPE.itemsize
+    cfg["kind"] = 2
+    cfg["frame_length"], cfg["frame_shift"], cfg["fft_length"], cfg["num_filters"] = 400, 160, 512, 80
+    win = np.ones(400, dtype=np.float32)
+    mel = np.zeros((257, 80), dtype=np.float32)
+    out = np.zeros(1, dtype=np.uint64)
+    st = lib.raw("hipfeat_plan_create", _lib.addr(cfg), _lib.addr(win), _lib.addr(mel), None, None, 0, _lib.addr(out))
+    assert st == 2 and out[0] == 0  # HIPFEAT_ERR_HIP: no device, no fallback
+    assert "device" in lib.last_error()
+    # ABI guard
+    cfg["struct_size"] = 4
+    assert lib.raw("hipfeat_plan_create", _lib.addr(cfg), _lib.addr(win), _lib.addr(mel), None, None, 0, _lib.addr(out)) == 1
+    assert "ABI mismatch" in lib.last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under lhotse_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "lhotse_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dirpath, f)
+                assert "kaldi_ref" not in text, os.path.join(dirpath, f)

@@ -1,0 +1,196 @@
+"""
+Drop-in check against the REAL lhotse package (authoring container only: needs /root/reference).
+
+The Hip* extractors must be usable, unchanged, by lhotse's own drivers:
+  CutSet.compute_and_store_features_batch   lhotse/cut/set.py:2197-2408
+  CutSet.compute_and_store_features         lhotse/cut/set.py:1981-2195
+  OnTheFlyFeatures                          lhotse/dataset/input_strategies.py:351-476
+There is no GPU here, so the DEVICE side (one class, extractors._Plan) is replaced by a CPU
+stand-in built on the oracle; everything above it -- input normalisation, packing, return
+conventions, registry, YAML, manifests, validate_features -- is the product code under test.
+GPU numerics are covered by tests/test_gpu_parity.py.
+"""
+import os
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.reference
+
+
+@pytest.fixture(scope="module")
+def lhotse_mod():
+    from oracle.make_golden import import_reference
+
+    import_reference()
+    import importlib
+
+    import lhotse
+    import lhotse_amd.compat as compat
+
+    if not compat.HAVE_LHOTSE:  # lhotse_amd was imported before the stubs were in place
+        import lhotse_amd
+        import lhotse_amd.extractors as ex
+
+        importlib.reload(compat)
+        importlib.reload(ex)
+        importlib.reload(lhotse_amd)
+    return lhotse
+
+
+@pytest.fixture()
+def cpu_device(monkeypatch, lhotse_mod):
+    """Replace the device plan by an oracle-backed stand-in (same interface)."""
+    import lhotse_amd.extractors as E
+    from oracle.kaldi_ref import RefConfig, RefExtractor
+
+    kinds = {0: "spectrogram", 1: "log-spectrogram", 2: "fbank", 3: "mfcc"}
+
+    class CpuPlan:
+        def __init__(self, cfg, kind, device):
+            fields = {k: getattr(cfg, k) for k in RefConfig.__dataclass_fields__ if hasattr(cfg, k)}
+            self.ref = RefExtractor(RefConfig(kind=kinds[kind], **fields), np.float32)
+            self.device = torch.device("cpu")
+            self.feature_dim = self.ref.feature_dim
+            self.kernel_name = "cpu-stand-in"
+            self.n, self.shift, self.snip_edges = self.ref.n, self.ref.shift, int(cfg.snip_edges)
+
+        def run(self, wave, offsets, lengths, padded):
+            outs = []
+            for i, (o, l) in enumerate(zip(offsets, lengths)):
+                f = self.ref.extract(wave[o : o + l].numpy(), padded_len=None if padded is None else int(padded[i]))
+                if padded is not None:
+                    f = f[: (int(l) + self.shift // 2) // self.shift]
+                outs.append(torch.from_numpy(np.ascontiguousarray(f)))
+            return torch.cat(outs), np.array([len(o) for o in outs], dtype=np.int64)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(E, "_Plan", CpuPlan)
+    return CpuPlan
+
+
+@pytest.fixture()
+def cutset(tmp_path, lhotse_mod):
+    from lhotse import CutSet, MonoCut, Recording
+    from lhotse.audio import AudioSource
+    from lhotse.audio.backend import AudioBackend, get_current_audio_backend, set_current_audio_backend
+
+    class StdlibWaveBackend(AudioBackend):  # soundfile is not installed here; int16 WAV via the stdlib
+        def read_audio(self, path_or_fd, offset=0.0, duration=None, force_opus_sampling_rate=None):
+            with wave.open(str(path_or_fd), "rb") as f:
+                sr, n, ch = f.getframerate(), f.getnframes(), f.getnchannels()
+                start = int(round(offset * sr))
+                f.setpos(start)
+                raw = f.readframes(n - start if duration is None else int(round(duration * sr)))
+            return np.frombuffer(raw, dtype=np.int16).reshape(-1, ch).T.astype(np.float32) / 32768.0, sr
+
+        def is_applicable(self, p):
+            return str(p).endswith(".wav")
+
+        handles_special_case = is_applicable
+
+    prev = get_current_audio_backend()
+    set_current_audio_backend(StdlibWaveBackend())
+    rs = np.random.RandomState(0)
+    cuts = []
+    for i, n in enumerate([16000, 24000, 12345, 32000, 8000]):
+        x = rs.rand(n) - 0.5
+        p = tmp_path / f"r{i}.wav"
+        with wave.open(str(p), "wb") as f:
+            f.setnchannels(1)
+            f.setsampwidth(2)
+            f.setframerate(16000)
+            f.writeframes((x * 32767).astype(np.int16).tobytes())
+        rec = Recording(id=f"rec{i}", sources=[AudioSource(type="file", channels=[0], source=str(p))], sampling_rate=16000,
+                        num_samples=n, duration=n / 16000)
+        cuts.append(MonoCut(id=f"cut{i}", start=0, duration=rec.duration, channel=0, recording=rec))
+    yield CutSet.from_cuts(cuts)
+    set_current_audio_backend(prev)
+
+
+def test_plugin_registration(lhotse_mod):
+    import lhotse_amd as LA
+    from lhotse.features.base import FEATURE_EXTRACTORS, FeatureExtractor, create_default_feature_extractor
+
+    for cls in (LA.HipFbank, LA.HipMfcc, LA.HipSpectrogram, LA.HipLogSpectrogram):
+        assert issubclass(cls, FeatureExtractor)
+        assert FEATURE_EXTRACTORS[cls.name] is cls  # -> shows up in `lhotse feat extract -f` (bin/modes/features.py:40)
+        assert isinstance(create_default_feature_extractor(cls.name), cls)  # no GPU needed (cut/mixed.py:1252)
+
+
+def test_yaml_through_lhotse(tmp_path, lhotse_mod):
+    import lhotse_amd as LA
+    from lhotse.features.base import FeatureExtractor
+    from lhotse.features.kaldi.extractors import Fbank
+
+    ex = LA.HipFbank(LA.HipFbankConfig(num_filters=40))
+    ex.to_yaml(tmp_path / "f.yml")
+    back = FeatureExtractor.from_yaml(tmp_path / "f.yml")
+    assert type(back) is LA.HipFbank and back.config == ex.config
+    # a kaldi-fbank config becomes a hip-fbank config by changing only feature_type
+    d = Fbank().to_dict()
+    d["feature_type"] = "hip-fbank"
+    assert type(FeatureExtractor.from_dict(d)) is LA.HipFbank
+
+
+@pytest.mark.parametrize("collate", [False, True])
+def test_compute_and_store_features_batch(tmp_path, cutset, cpu_device, collate):
+    import lhotse_amd as LA
+    from lhotse.features.io import NumpyFilesWriter
+    from lhotse.features.kaldi.extractors import Fbank
+
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cpu", edge_rule="batch_zero_pad"))
+    out = cutset.compute_and_store_features_batch(
+        extractor=ex, storage_path=tmp_path / "feats", manifest_path=tmp_path / "cuts.jsonl.gz", batch_duration=3.0,
+        num_workers=0, collate=collate, storage_type=NumpyFilesWriter,
+    )
+    ref = Fbank()
+    assert len(out) == len(cutset)
+    for c in out:
+        f = c.load_features()
+        assert c.features.type == "hip-fbank" and f.dtype == np.float32
+        assert f.shape == (c.features.num_frames, 80) == ((c.num_samples + 80) // 160, 80)  # validate_features contract
+    # the collated path zero pads like the reference's batch path, so it can be compared with it item by item
+    batch = [c.load_audio() for c in cutset]
+    want = ref.extract_batch([torch.from_numpy(b) for b in batch], 16000)
+    got = LA.HipFbank(LA.HipFbankConfig(device="cpu", edge_rule="batch_zero_pad")).extract_batch([torch.from_numpy(b) for b in batch], 16000)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g.numpy(), w.numpy(), atol=2e-3, rtol=1e-4)
+
+
+def test_batch_driver_resume(tmp_path, cutset, cpu_device):
+    import lhotse_amd as LA
+    from lhotse.features.io import NumpyFilesWriter
+
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cpu"))
+    kw = dict(extractor=ex, storage_path=tmp_path / "feats", manifest_path=tmp_path / "cuts.jsonl.gz", batch_duration=3.0,
+              num_workers=0, storage_type=NumpyFilesWriter)
+    first = cutset.subset(first=2).compute_and_store_features_batch(**kw)
+    assert len(first) == 2
+    allc = cutset.compute_and_store_features_batch(**kw, overwrite=False)  # resumes: only the missing cuts are computed
+    assert sorted(c.id for c in allc) == sorted(c.id for c in cutset)
+
+
+def test_per_cut_driver_and_on_the_fly(tmp_path, cutset, cpu_device):
+    import lhotse_amd as LA
+    from lhotse.dataset.input_strategies import OnTheFlyFeatures
+    from lhotse.features.io import NumpyFilesWriter
+    from lhotse.utils import LOG_EPSILON
+
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cpu"))
+    out = cutset.compute_and_store_features(extractor=ex, storage_path=tmp_path / "f1", num_jobs=1, storage_type=NumpyFilesWriter)
+    per_cut = {c.id: c.load_features() for c in out}
+    assert all(v.shape[1] == 80 for v in per_cut.values())
+    # OnTheFlyFeatures: list of 1-D tensors -> extract_batch -> padded with LOG_EPSILON
+    feats, lens = OnTheFlyFeatures(ex)(cutset)
+    assert feats.shape[0] == len(cutset) and feats.shape[2] == 80
+    for i, c in enumerate(cutset):
+        t = int(lens[i])
+        assert t == per_cut[c.id].shape[0]
+        np.testing.assert_allclose(feats[i, :t].numpy(), per_cut[c.id], atol=1e-5)  # per-item reflect == extract()
+        if t < feats.shape[1]:
+            assert torch.all(feats[i, t:] == LOG_EPSILON)

@@ -1,0 +1,85 @@
+"""CPU: the N>1 path.  Shard disjointness/coverage as the reference tests its samplers
+(test/dataset/test_multinode_resume.py style: explicit rank/world), plus a REAL world_size-2
+process group over gloo exercising rank discovery and the bookkeeping all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lhotse_amd import sharding as S
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 100, 12501])
+def test_round_robin_disjoint_and_complete(world, n):
+    shards = [list(S.shard_indices(n, r, world)) for r in range(world)]
+    flat = sorted(i for s in shards for i in s)
+    assert flat == list(range(n))
+    assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    items = [f"cut-{i}" for i in range(n)]
+    for r in range(world):
+        assert S.shard(items, r, world) == [items[i] for i in shards[r]] == list(S.shard_iter(items, r, world))
+
+
+def test_duration_balanced_sharding():
+    rs = np.random.RandomState(0)
+    dur = np.clip(np.exp(rs.randn(5000) * 0.5 + 2.4), 1, 35).tolist()  # LibriSpeech-like lengths
+    parts = S.shard_by_duration(dur, 8)
+    assert sorted(i for p in parts for i in p) == list(range(5000))
+    loads = [sum(dur[i] for i in p) for p in parts]
+    assert (max(loads) - min(loads)) / np.mean(loads) < 0.01
+    assert parts == S.shard_by_duration(dur, 8)  # deterministic
+
+
+def test_bad_rank():
+    with pytest.raises(ValueError):
+        S.shard_indices(10, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert S.rank_and_world() == (rank, world)
+        mine = list(S.shard_indices(n, *S.rank_and_world()))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        total, slowest = S.all_reduce_stats(len(mine), 1.0 + rank)
+        q.put((rank, gathered, total, slowest))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_gloo_group():
+    world, n = 2, 101
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, gathered, total, slowest in res:
+        assert sorted(i for g in gathered for i in g) == list(range(n))
+        assert not set(gathered[0]) & set(gathered[1])
+        assert total == n and slowest == 2.0
+
+
+def test_rank_from_env(monkeypatch):
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert S.rank_and_world() == (3, 8)
+    assert S.all_reduce_stats(5, 0.5) == (5, 0.5)
