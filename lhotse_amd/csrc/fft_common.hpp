@@ -1,0 +1,90 @@
+// Shared device primitives of the fft512 kernels: packed complex arithmetic, row-of-16 DPP moves,
+// the in-register 16-point FFT, fast log.
+#pragma once
+#include "common.hpp"
+
+namespace hipfeat {
+
+typedef float v2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- DPP helpers (row = 16 lanes) -------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_QUAD(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+constexpr int DPP_ROW_ROR1 = 0x121;
+constexpr int DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+
+__device__ __forceinline__ float row16_sum(float v) {  // every lane of the row gets the same total
+  v += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(v);
+  v += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(v);
+  v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_mov<DPP_ROW_MIRROR>(v);
+  return v;
+}
+// lane l <- lane (16 - l) % 16 of the same row
+__device__ __forceinline__ float row16_negate_index(float v) { return dpp_mov<DPP_ROW_ROR1>(dpp_mov<DPP_ROW_MIRROR>(v)); }
+
+// ---- packed complex arithmetic ---------------------------------------------------------------
+// hipcc folds whole-register swaps / broadcasts of packed f32 operands into op_sel modifiers but not
+// a sign flip of ONE half, so conjugation and multiplication by +-i are written as a packed multiply
+// by the constant (1,-1) / (-1,1) (exact) feeding an op_sel-swapped add.
+#define HF_CJ (v2{1.f, -1.f})
+#define HF_NCJ (v2{-1.f, 1.f})
+__device__ __forceinline__ v2 swap2(v2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ v2 rot_mi(v2 a) { return swap2(a * HF_NCJ); }  // a * (-i) = (a.y, -a.x)
+__device__ __forceinline__ v2 cmulc(v2 a, v2 w, v2 wp) {  // a * w with wp = (-w.y, w.x) precomputed
+  return v2{a.x, a.x} * w + v2{a.y, a.y} * wp;
+}
+__device__ __forceinline__ v2 cmul(v2 a, v2 w) {  // a * w, only w itself available: a*w.x + (i a)*w.y
+  return a * v2{w.x, w.x} + swap2(a * HF_CJ) * v2{w.y, w.y};
+}
+
+// 16-point complex FFT in registers (radix-4 x radix-4, natural order in and out)
+__device__ __forceinline__ void fft16(const v2 (&x)[16], v2 (&X)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+  v2 y[16];  // y[4*m + n]
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const v2 s0 = x[n] + x[n + 8], s1 = x[n] - x[n + 8];
+    const v2 s2 = x[n + 4] + x[n + 12], s3 = rot_mi(x[n + 4] - x[n + 12]);
+    y[n] = s0 + s2;
+    y[8 + n] = s0 - s2;
+    y[4 + n] = s1 + s3;
+    y[12 + n] = s1 - s3;
+  }
+  // twiddles W16^(n*m): w = (c, -s), wp = (s, c)
+  y[4 + 1] = cmulc(y[4 + 1], v2{C1, -S1}, v2{S1, C1});      // n=1 m=1: W^1
+  y[8 + 1] = cmulc(y[8 + 1], v2{R2, -R2}, v2{R2, R2});      // n=1 m=2: W^2
+  y[12 + 1] = cmulc(y[12 + 1], v2{S1, -C1}, v2{C1, S1});    // n=1 m=3: W^3
+  y[4 + 2] = cmulc(y[4 + 2], v2{R2, -R2}, v2{R2, R2});      // n=2 m=1: W^2
+  y[8 + 2] = rot_mi(y[8 + 2]);                              // n=2 m=2: W^4 = -i
+  y[12 + 2] = cmulc(y[12 + 2], v2{-R2, -R2}, v2{R2, -R2});  // n=2 m=3: W^6
+  y[4 + 3] = cmulc(y[4 + 3], v2{S1, -C1}, v2{C1, S1});      // n=3 m=1: W^3
+  y[8 + 3] = cmulc(y[8 + 3], v2{-R2, -R2}, v2{R2, -R2});    // n=3 m=2: W^6
+  y[12 + 3] = cmulc(y[12 + 3], v2{-C1, S1}, v2{-S1, -C1});  // n=3 m=3: W^9
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const v2 s0 = y[4 * m] + y[4 * m + 2], s1 = y[4 * m] - y[4 * m + 2];
+    const v2 s2 = y[4 * m + 1] + y[4 * m + 3], s3 = rot_mi(y[4 * m + 1] - y[4 * m + 3]);
+    X[m] = s0 + s2;       // k' = 0
+    X[m + 4] = s1 + s3;   // k' = 1
+    X[m + 8] = s0 - s2;   // k' = 2
+    X[m + 12] = s1 - s3;  // k' = 3
+  }
+}
+
+// natural log of a normal positive float: v_log_f32 (log2, 1 ulp) times ln 2.  The argument is
+// >= mel_floor (1.19e-7), so the denormal path of the library logf is never needed.
+__device__ __forceinline__ float fast_log(float x) {
+#ifdef HIPFEAT_ACCURATE_LOG
+  return logf(x);
+#else
+  return __builtin_amdgcn_logf(x) * 0.69314718055994531f;
+#endif
+}
+
+}  // namespace hipfeat

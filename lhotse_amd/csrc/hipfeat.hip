@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "kernel_generic.hpp"
 #include "kernel_fft512.hpp"
+#include "kernel_fft512b.hpp"
 
 using namespace hipfeat;
 
@@ -84,7 +85,8 @@ struct hipfeat_plan {
   int span = 0, off_z = 0, off_p = 0, off_tw = 0, off_stat = 0, off_mel = 0;
   size_t lds_bytes = 0;
   // fft512 fast path
-  int variant = 0;  // 0 generic, 1 fft512 fbank
+  int variant = 0;  // 0 generic, 1 fft512 fbank (register-resident weights), 2 fft512 fbank "b" (4 workgroups/CU)
+  float* d_mel_a4 = nullptr;
   int nrows = 0;    // template instance: pass-1 rows that can be non-zero
   int tiles_per_block = 4;
   int xs_floats = 0;
@@ -179,6 +181,7 @@ static void plan_free(hipfeat_plan* p) {
   (void)hipFree(p->d_scratch_wave);
   (void)hipFree(p->d_scratch_out);
   (void)hipFree(p->d_lds_consts);
+  (void)hipFree(p->d_mel_a4);
   (void)hipFree(p->d_mel_a);
   (void)hipFree(p->d_work);
   for (auto& s : p->slots) {
@@ -195,6 +198,10 @@ static void plan_free(hipfeat_plan* p) {
 template <int NROWS>
 static const void* fft512_entry() {
   return reinterpret_cast<const void*>(&fft512_fbank_kernel<NROWS>);
+}
+template <int NROWS>
+static const void* fft512b_entry() {
+  return reinterpret_cast<const void*>(&fft512b_fbank_kernel<NROWS>);
 }
 
 static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const float* h_mel) {
@@ -300,20 +307,36 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   if ((st = upload(&p->d_work, work, 4)) != HIPFEAT_OK) return st;
   p->nrows = nrows;
   p->tiles_per_block = 4;
-  p->xs_floats = (15 * shift + 32 * nrows + 3) & ~3;
   p->const_floats = const_floats;
-  p->fast_lds_bytes = (size_t)(p->xs_floats + const_floats + 4 * kWaveRegion) * sizeof(float);
+  const char* var = getenv("HIPFEAT_FFT512_VARIANT");
+  const bool use_b = !(var && var[0] == 'a');
+  const void* fn;
+  if (use_b) {
+    // weights as 16-byte vectors: [wave][step / 4][lane][step % 4]
+    std::vector<float> mel_a4(mel_a.size());
+    for (int w = 0; w < 4; ++w)
+      for (int st = 0; st < kMelARegs; ++st)
+        for (int lane = 0; lane < 64; ++lane)
+          mel_a4[(((size_t)w * kBMelVec + st / 4) * 64 + lane) * 4 + (st & 3)] = mel_a[((size_t)w * kMelARegs + st) * 64 + lane];
+    if ((st = upload(&p->d_mel_a4, mel_a4.data(), mel_a4.size())) != HIPFEAT_OK) return st;
+    p->xs_floats = (15 * shift + 32 * nrows + 255) & ~255;  // whole 1 KiB LDS-DMA chunks
+    p->fast_lds_bytes = (size_t)(p->xs_floats + const_floats + 4 * kBWaveRegion) * sizeof(float);
+    fn = nrows == 10 ? fft512b_entry<10>() : (nrows == 13 ? fft512b_entry<13>() : fft512b_entry<16>());
+  } else {
+    p->xs_floats = (15 * shift + 32 * nrows + 3) & ~3;
+    p->fast_lds_bytes = (size_t)(p->xs_floats + const_floats + 4 * kWaveRegion) * sizeof(float);
+    fn = nrows == 10 ? fft512_entry<10>() : (nrows == 13 ? fft512_entry<13>() : fft512_entry<16>());
+  }
   if (p->fast_lds_bytes > 160 * 1024) return HIPFEAT_OK;
-  const void* fn = nrows == 10 ? fft512_entry<10>() : (nrows == 13 ? fft512_entry<13>() : fft512_entry<16>());
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->fast_lds_bytes);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft512) failed: %s", hipGetErrorName(e));
-  p->variant = 1;
-  p->fpb = kTileFrames * p->tiles_per_block;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, p->fast_lds_bytes) == hipSuccess) p->blocks_per_cu = nb;
   char nm[96];
-  snprintf(nm, sizeof(nm), "fft512_fbank<%d> lds=%zuB blocks/CU=%d", nrows, p->fast_lds_bytes, p->blocks_per_cu);
+  snprintf(nm, sizeof(nm), "fft512%s_fbank<%d> lds=%zuB blocks/CU=%d", use_b ? "b" : "", nrows, p->fast_lds_bytes, p->blocks_per_cu);
   p->kernel_name = nm;
+  p->variant = use_b ? 2 : 1;
+  p->fpb = kTileFrames * p->tiles_per_block;
   return HIPFEAT_OK;
 }
 
@@ -555,13 +578,13 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
   if (lay->fpb != plan->fpb || lay->device != plan->device)
     return fail(HIPFEAT_ERR_INVALID, "layout was created for a different plan");
   const hipfeat_config& c = plan->cfg;
-  if (plan->variant == 1) {
+  if (plan->variant == 1 || plan->variant == 2) {
     Fft512Params fp{};
     fp.wave = d_wave;
     fp.out = d_out;
     fp.cuts = lay->d_cuts;
     fp.lds_consts = plan->d_lds_consts;
-    fp.mel_a = plan->d_mel_a;
+    fp.mel_a = plan->variant == 2 ? plan->d_mel_a4 : plan->d_mel_a;
     fp.work = plan->d_work;
     fp.out_stride = lay->out_row_stride;
     fp.num_cuts = (int32_t)lay->batch;
@@ -578,7 +601,14 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.const_floats = plan->const_floats;
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(256);
-    if (plan->nrows == 10)
+    if (plan->variant == 2) {
+      if (plan->nrows == 10)
+        hipLaunchKernelGGL(fft512b_fbank_kernel<10>, grid, block, plan->fast_lds_bytes, stream, fp);
+      else if (plan->nrows == 13)
+        hipLaunchKernelGGL(fft512b_fbank_kernel<13>, grid, block, plan->fast_lds_bytes, stream, fp);
+      else
+        hipLaunchKernelGGL(fft512b_fbank_kernel<16>, grid, block, plan->fast_lds_bytes, stream, fp);
+    } else if (plan->nrows == 10)
       hipLaunchKernelGGL(fft512_fbank_kernel<10>, grid, block, plan->fast_lds_bytes, stream, fp);
     else if (plan->nrows == 13)
       hipLaunchKernelGGL(fft512_fbank_kernel<13>, grid, block, plan->fast_lds_bytes, stream, fp);

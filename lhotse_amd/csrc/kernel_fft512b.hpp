@@ -1,0 +1,256 @@
+// fft512 fast path, occupancy-oriented variant ("b"): same arithmetic as kernel_fft512.hpp, organised so
+// that FOUR workgroups (16 waves) fit a CU.  Measured on MI355X (tools/ubench): one wave can issue a VALU
+// instruction only every ~5 clk while the SIMD accepts one every 2-3 clk, so the f32 FFT work needs >= 2
+// waves per SIMD inside their arithmetic phase at any time; the cheapest way there is more resident waves.
+//
+// What changes against kernel_fft512.hpp
+//   * nothing persistent in VGPRs besides addresses: the mel filter weights (MFMA A operands) are
+//     re-fetched from L2 with 9 x 16-byte loads per wave at the start of every S5 (they are only live
+//     there, where the FFT registers are dead);
+//   * the next tile's sample span is written straight into LDS by global_load_lds_dwordx4 (LDS-DMA)
+//     during S5, when the span buffer is dead -- no prefetch registers, no second buffer;
+//   * the FFT exchange runs in two halves (rows 0-7, then 8-15) through a 4.6 KB wave region;
+//   => <= 128 VGPRs and 35.8 KB LDS per workgroup.
+#pragma once
+#include "common.hpp"
+#include "fft_common.hpp"
+#include "kernel_fft512.hpp"  // Fft512Params, WaveWork, tile constants
+
+namespace hipfeat {
+
+constexpr int kBExRowStride = 34;                        // dwords per exchange row (16 complex + 2 pad)
+constexpr int kBExFrameStride = 8 * kBExRowStride + 16;  // 288 (== 32 mod 64): 8 rows per half
+constexpr int kBWaveRegion = 4 * kBExFrameStride + 16;   // 1168 dwords per wave (== 16 mod 64)
+constexpr int kBMelVec = kMelARegs / 4;                  // 16-byte loads of filter weights per lane per tile
+
+#ifndef HIPFEAT_FFT512B_WAVES_PER_SIMD
+#define HIPFEAT_FFT512B_WAVES_PER_SIMD 4
+#endif
+
+template <int NROWS>
+__global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_fbank_kernel(const Fft512Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  const v2* cwin = reinterpret_cast<const v2*>(smem + p.xs_floats);  // [NROWS][16]
+  const v2* ctwp = cwin + NROWS * 16;                                // [16][16] row k1, column q
+  const v2* ctws = ctwp + 256;                                       // [8][16] w = -i W_512^(q+16 k2)
+  const v2* ctwsp = ctws + 128;                                      // [8][16] (-w.y, w.x)
+  float* regions = smem + p.xs_floats + p.const_floats;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int blk = blockIdx.x;
+  int cut, fb;
+  if (p.uniform_bpc > 0) {
+    cut = blk / p.uniform_bpc;
+    fb = blk - cut * p.uniform_bpc;
+  } else {
+    cut = find_cut(p.cuts, p.num_cuts, blk);
+    fb = blk - p.cuts[cut].first_block;
+  }
+  const CutDesc cd = p.cuts[cut];
+  const float* __restrict__ w = p.wave + cd.wave_off;
+  const int N = p.N, shift = p.shift;
+  const int span = (kTileFrames - 1) * shift + N;
+  const int nchunks = (p.xs_floats + 255) >> 8;  // 1 KiB LDS-DMA chunks covering the span buffer
+  const bool aligned16 = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((shift & 3) == 0) && ((p.npad_left & 3) == 0);
+
+  for (int i = tid; i < p.const_floats; i += 256) smem[p.xs_floats + i] = p.lds_consts[i];
+  const WaveWork ww = p.work[wv];
+  const bool dc = (p.flags & F_REMOVE_DC) != 0;
+  const float inv_n = 1.0f / (float)N;
+  const float c = p.preemph;
+  // uniform (SGPR) base + 32-bit lane offset keeps global addresses out of the VGPR file
+  const char* __restrict__ mel_base = reinterpret_cast<const char*>(p.mel_a) + (size_t)wv * kBMelVec * 64 * 16;
+
+  // Stage the sample span of the tile starting at frame f0 into xs.  Interior tiles: LDS-DMA, each wave
+  // moves 1 KiB chunks (lane i supplies the global address of its 16 bytes; the hardware writes
+  // chunk base + 16 i).  Tiles touching a cut edge (reflection / zero padding): scalar loads.
+  auto stage_span = [&](int f0, unsigned lane16) {
+    const int64_t j0 = (int64_t)f0 * shift - p.npad_left;
+    if (aligned16 && j0 >= 0 && j0 + (int64_t)nchunks * 256 <= cd.num_samples) {
+      const char* src = reinterpret_cast<const char*>(w + j0);  // uniform
+      for (int ch = wv; ch < nchunks; ch += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)ch * 1024u + lane16)),
+                                         (__attribute__((address_space(3))) void*)(xs + ch * 256), 16, 0, 0);
+    } else {
+      for (int i = tid; i < span; i += 256) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
+    }
+  };
+
+  const int first_tile = fb * p.tiles_per_block;
+  if (first_tile * kTileFrames < cd.num_frames) stage_span(first_tile * kTileFrames, (unsigned)lane * 16u);
+
+  for (int t = 0; t < p.tiles_per_block; ++t) {
+    const int f0 = (first_tile + t) * kTileFrames;
+    if (f0 >= cd.num_frames) break;
+    const int nf = min(kTileFrames, cd.num_frames - f0);
+
+    // ---- S1: the span was requested one phase ago; wait for this wave's DMA, then for everyone's
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
+    // Re-derive every per-lane address inside the loop from an opaque copy of the lane id: LICM
+    // otherwise hoists ~25 loop-invariant LDS/global addresses into VGPRs for the whole kernel,
+    // which costs a wave of occupancy; recomputing them is a handful of VALU ops per tile.
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int q = lane_o & 15, g = lane_o >> 4;
+    const unsigned lane16 = (unsigned)lane_o * 16u;
+    float* myreg = regions + wv * kBWaveRegion;
+
+    // ---- S3 ---------------------------------------------------------------------------------
+    {
+      const float* x = xs + (4 * wv + g) * shift + 2 * q;
+      v2 z[16];
+      v2 win[NROWS];
+      v2 sum2 = {0.f, 0.f};
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) z[n1] = *reinterpret_cast<const v2*>(x + 32 * n1);
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = cwin[n1 * 16 + q];
+      {
+        const int m0 = 32 * (NROWS - 1) + 2 * q;
+        if (m0 >= N) z[NROWS - 1].x = 0.f;
+        if (m0 + 1 >= N) z[NROWS - 1].y = 0.f;
+      }
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) sum2 += z[n1];
+      float mu = 0.f;
+      if (dc) mu = row16_sum(sum2.x + sum2.y) * inv_n;
+      float tprev = 0.f;
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        const v2 d = z[n1] - v2{mu, mu};
+        const float tcur = dpp_mov<DPP_ROW_ROR1>(d.y);
+        const float dp = (q == 0) ? (n1 == 0 ? d.x : tprev) : tcur;
+        tprev = tcur;
+        z[n1] = (d - v2{c, c} * v2{dp, d.x}) * win[n1];
+      }
+#pragma unroll
+      for (int n1 = NROWS; n1 < 16; ++n1) z[n1] = v2{0.f, 0.f};
+      v2 a[16];
+      fft16(z, a);
+#pragma unroll
+      for (int k1 = 1; k1 < 16; ++k1) a[k1] = cmul(a[k1], ctwp[k1 * 16 + q]);
+
+      // exchange in two halves: rows k1 = 8h .. 8h+7 go through an 8-row block; lanes with
+      // (q >> 3) == h then read "their" row (all n2) back
+      float* exf = myreg + g * kBExFrameStride;
+      v2 b[16];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) *reinterpret_cast<v2*>(exf + r * kBExRowStride + 2 * q) = a[8 * h + r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if ((q >> 3) == h) {
+#pragma unroll
+          for (int n2 = 0; n2 < 16; ++n2) b[n2] = *reinterpret_cast<const v2*>(exf + (q & 7) * kBExRowStride + 2 * n2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      v2 Z[16];
+      fft16(b, Z);
+
+      float* prow = myreg + g * kPRowStride;
+      float* pown = prow + q;
+      float* ppar = prow + ((16 - q) & 15) + (q == 0 ? 16 : 0);
+      if (q < 3) prow[257 + q] = 0.f;
+      float t1[16];
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        t1[2 * k2] = dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].x);
+        t1[2 * k2 + 1] = dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].y);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t1[i] = dpp_mov<DPP_ROW_ROR1>(t1[i]);
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        v2 m = v2{t1[2 * k2], t1[2 * k2 + 1]};
+        if (q == 0) m = Z[(16 - k2) & 15];
+        const v2 sp = m * HF_CJ + Z[k2];
+        const v2 dm = m * HF_NCJ + Z[k2];
+        const v2 tt = cmulc(dm, ctws[k2 * 16 + q], ctwsp[k2 * 16 + q]);
+        const v2 xp = sp + tt, xm = sp - tt;
+        pown[16 * k2] = xp.x * xp.x + xp.y * xp.y;
+        ppar[16 * (15 - k2)] = xm.x * xm.x + xm.y * xm.y;
+      }
+      if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
+    }
+    __syncthreads();
+
+    // ---- S5 ---------------------------------------------------------------------------------
+    {
+      // xs is dead until the next tile: stage the next span now (lands during the mel GEMM)
+      {
+        const int fn = f0 + kTileFrames;
+        if (t + 1 < p.tiles_per_block && fn < cd.num_frames) stage_span(fn, lane16);
+      }
+      f32x4 ma[kBMelVec];
+#pragma unroll
+      for (int i = 0; i < kBMelVec; ++i) ma[i] = *reinterpret_cast<const f32x4*>(mel_base + ((unsigned)i * 1024u + lane16));
+      const int j = lane_o & 15, kk = lane_o >> 4;
+      const float* pb = regions + (j >> 2) * kBWaveRegion + (j & 3) * kPRowStride + 2 * kk;
+      float* orow = p.out + (cd.out_row + f0 + j) * p.out_stride;
+      const bool vec_ok = ((p.out_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+      auto epilogue = [&](const f32x4 acc, int tile) {
+        const int m0 = tile * 16 + 4 * kk;
+        f32x4 v;
+        v.x = fast_log(fmaxf(acc.x, p.mel_floor));
+        v.y = fast_log(fmaxf(acc.y, p.mel_floor));
+        v.z = fast_log(fmaxf(acc.z, p.mel_floor));
+        v.w = fast_log(fmaxf(acc.w, p.mel_floor));
+        if (j < nf) {
+          if (vec_ok && m0 + 3 < p.M) {
+            *reinterpret_cast<f32x4*>(orow + m0) = v;
+          } else {
+            if (m0 + 0 < p.M) orow[m0 + 0] = v.x;
+            if (m0 + 1 < p.M) orow[m0 + 1] = v.y;
+            if (m0 + 2 < p.M) orow[m0 + 2] = v.z;
+            if (m0 + 3 < p.M) orow[m0 + 3] = v.w;
+          }
+        }
+      };
+      auto wgt = [&](int step) -> float { return ma[step >> 2][step & 3]; };
+      constexpr int CH = 4;
+      if (ww.ngroups0 > 0) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c0 = 0; c0 < kMaxGroups0; c0 += CH) {
+          if (c0 < ww.ngroups0) {
+            v2 pv[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+              if (c0 + i < kMaxGroups0) pv[i] = *reinterpret_cast<const v2*>(pb + min(ww.bin0 + 8 * (c0 + i), kPRowStride - 8));
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+              if (c0 + i < kMaxGroups0) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt(2 * (c0 + i)), pv[i].x, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt(2 * (c0 + i) + 1), pv[i].y, acc2, 0, 0, 0);
+              }
+          }
+        }
+        epilogue(acc + acc2, ww.tile0);
+      }
+      if (ww.ngroups1 > 0) {
+        v2 pv[kMaxGroups1];
+#pragma unroll
+        for (int gi = 0; gi < kMaxGroups1; ++gi) pv[gi] = *reinterpret_cast<const v2*>(pb + min(ww.bin1 + 8 * gi, kPRowStride - 8));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gi = 0; gi < kMaxGroups1; ++gi) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt(2 * (kMaxGroups0 + gi)), pv[gi].x, acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt(2 * (kMaxGroups0 + gi) + 1), pv[gi].y, acc2, 0, 0, 0);
+        }
+        epilogue(acc + acc2, ww.tile1);
+      }
+    }
+    // the loop-top wait + barrier separates this tile's P reads from the next tile's exchange writes
+  }
+}
+
+}  // namespace hipfeat
