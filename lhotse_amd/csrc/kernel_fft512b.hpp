@@ -83,14 +83,20 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_f
   const int first_tile = fb * p.tiles_per_block;
   if (first_tile * kTileFrames < cd.num_frames) stage_span(first_tile * kTileFrames, (unsigned)lane * 16u);
 
+#ifdef HIPFEAT_PHASE_TIMERS
+  unsigned long long hf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int t = 0; t < p.tiles_per_block; ++t) {
     const int f0 = (first_tile + t) * kTileFrames;
     if (f0 >= cd.num_frames) break;
     const int nf = min(kTileFrames, cd.num_frames - f0);
 
     // ---- S1: the span was requested one phase ago; wait for this wave's DMA, then for everyone's
+    HF_T(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    HF_T(1);
     __syncthreads();
+    HF_T(2);
     // Re-derive every per-lane address inside the loop from an opaque copy of the lane id: LICM
     // otherwise hoists ~25 loop-invariant LDS/global addresses into VGPRs for the whole kernel,
     // which costs a wave of occupancy; recomputing them is a handful of VALU ops per tile.
@@ -181,18 +187,27 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_f
       }
       if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
     }
+    // the filter weights of this wave's band: requested now (the FFT registers are dead), so the L2
+    // latency hides behind the barrier and the start of S5
+    f32x4 ma[kBMelVec];
+#pragma unroll
+    for (int i = 0; i < kBMelVec; ++i) ma[i] = *reinterpret_cast<const f32x4*>(mel_base + ((unsigned)i * 1024u + lane16));
+    HF_T(3);
     __syncthreads();
+    HF_T(4);
 
     // ---- S5 ---------------------------------------------------------------------------------
     {
+      // gfx950 has ONE in-order counter for all vector-memory operations: take delivery of the weights
+      // (requested before the barrier) BEFORE the span DMA is issued, otherwise their first use would
+      // have to wait for the much slower HBM transfer queued behind them.
+#pragma unroll
+      for (int i = 0; i < kBMelVec; ++i) asm volatile("" : "+v"(ma[i]));
       // xs is dead until the next tile: stage the next span now (lands during the mel GEMM)
       {
         const int fn = f0 + kTileFrames;
         if (t + 1 < p.tiles_per_block && fn < cd.num_frames) stage_span(fn, lane16);
       }
-      f32x4 ma[kBMelVec];
-#pragma unroll
-      for (int i = 0; i < kBMelVec; ++i) ma[i] = *reinterpret_cast<const f32x4*>(mel_base + ((unsigned)i * 1024u + lane16));
       const int j = lane_o & 15, kk = lane_o >> 4;
       const float* pb = regions + (j >> 2) * kBWaveRegion + (j & 3) * kPRowStride + 2 * kk;
       float* orow = p.out + (cd.out_row + f0 + j) * p.out_stride;
@@ -249,8 +264,21 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_f
         epilogue(acc + acc2, ww.tile1);
       }
     }
+    HF_T(5);
+    HF_ACC(0, t0, t1);  // wait for DMA / stores (vmcnt)
+    HF_ACC(1, t1, t2);  // barrier 1
+    HF_ACC(2, t2, t3);  // S3
+    HF_ACC(3, t3, t4);  // barrier 2
+    HF_ACC(4, t4, t5);  // S5
+    HF_ACC(5, t0, t0 + 1);
     // the loop-top wait + barrier separates this tile's P reads from the next tile's exchange writes
   }
+#ifdef HIPFEAT_PHASE_TIMERS
+  if (lane == 0 && g_phase_buf) {
+    unsigned long long* o = g_phase_buf + ((size_t)blockIdx.x * 4 + wv) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = hf_acc[i];
+  }
+#endif
 }
 
 }  // namespace hipfeat
