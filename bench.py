@@ -85,7 +85,7 @@ def load_traffic(kernel_name: str):
     try:
         with open(path) as f:
             t = json.load(f)
-        if t.get("kernel") == kernel_name:
+        if kernel_name.split(" ")[0] == t.get("kernel"):  # plan.kernel_name = "<kernel> lds=... blocks/CU=..."
             return float(t["hbm_bytes_per_cut"])
     except Exception:
         pass
