@@ -43,39 +43,38 @@ ALGO_BYTES_PER_CUT = SAMPLES_PER_CUT * 4 + FRAMES_PER_CUT * NUM_MELS * 4  # 960 
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(seconds: float = 12.0):
-    """Time the oracle (numpy float32 restatement of lhotse's CPU Fbank path) on this host."""
-    import numpy as np
+def cpu_baseline(seconds: float = 12.0, procs: int = 0):
+    """Time the oracle (numpy float32 restatement of lhotse's CPU Fbank path, one cut per call as in
+    CutSet.compute_and_store_features) on this host: `procs` single-threaded processes in parallel,
+    mirroring `num_jobs=procs` with torch.set_num_threads(1) (lhotse/bin/modes/features.py:25-32).
+    Workers are plain subprocesses with a hard timeout, so a stuck worker can never hang the bench."""
+    import subprocess
 
-    from oracle.kaldi_ref import RefConfig, RefExtractor
-    from oracle.signals import make_signal
-
-    try:
-        from threadpoolctl import threadpool_limits
-    except ImportError:  # pragma: no cover
-        threadpool_limits = None
-    ex = RefExtractor(RefConfig(kind="fbank"), np.float32)
-    pool = [make_signal("uniform", SAMPLES_PER_CUT, seed) for seed in range(8)]
-
-    def loop():
-        ex.extract(pool[0])  # warm-up
-        n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
-            ex.extract(pool[n % len(pool)])
-            n += 1
-        return n, time.perf_counter() - t0
-
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            n, dt = loop()
-    else:
-        n, dt = loop()
+    ncpu = os.cpu_count() or 1
+    procs = procs or min(ncpu, 32)
+    worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
+    ps = [subprocess.Popen([sys.executable, worker, str(seconds), str(100 * i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+          for i in range(procs)]
+    res = []
+    deadline = time.time() + seconds + 90
+    for p in ps:
+        try:
+            out, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
+            n, dt = out.split()
+            res.append((int(n), float(dt)))
+        except Exception:
+            p.kill()
+    if not res:
+        return {"value": None, "unit": "cuts/s", "cores": 0, "kind": "port", "sample": "CPU baseline workers failed"}
+    rate = sum(n / dt for n, dt in res)
+    total = sum(n for n, _ in res)
     return {
-        "value": round(n / dt, 2),
+        "value": round(rate, 1),
         "unit": "cuts/s",
-        "cores": 1,
+        "cores": len(res),
         "kind": "port",
-        "sample": f"{n} x 10 s cuts (same distribution as the GPU workload) in {dt:.1f} s, numpy float32, 1 thread; host has {os.cpu_count()} logical cores",
+        "sample": f"{total} x 10 s cuts in {seconds:.0f} s wall: {len(res)} single-threaded processes of the numpy float32 oracle "
+        f"({rate / len(res):.0f} cuts/s per core); host has {ncpu} logical cores",
     }
 
 
@@ -100,6 +99,7 @@ def main():
     ap.add_argument("--cuts", type=int, default=10000, help="cuts per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="host processes of the CPU baseline (default min(cores, 32))")
     args = ap.parse_args()
 
     import numpy as np
@@ -211,7 +211,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.cpu_procs)
         print(json.dumps(res), flush=True)
     L.check("hipfeat_layout_destroy", layout)
     if dist is not None:

@@ -1,0 +1,35 @@
+"""TEST INFRASTRUCTURE -- one single-threaded host process of bench.py's CPU baseline.
+
+    python oracle/cpu_worker.py <seconds> <seed>
+
+Loops the numpy float32 oracle (one 10 s cut per call, as CutSet.compute_and_store_features does
+with the reference extractor) for <seconds> and prints "<cuts> <elapsed>".
+"""
+import os
+import sys
+import time
+
+for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ[k] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+
+from oracle.kaldi_ref import RefConfig, RefExtractor  # noqa: E402
+from oracle.signals import make_signal  # noqa: E402
+
+
+def main():
+    seconds, seed = float(sys.argv[1]), int(sys.argv[2])
+    ex = RefExtractor(RefConfig(kind="fbank"), np.float32)
+    pool = [make_signal("uniform", 160000, seed + s) for s in range(4)]
+    ex.extract(pool[0])
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        ex.extract(pool[n % len(pool)])
+        n += 1
+    print(n, time.perf_counter() - t0, flush=True)
+
+
+if __name__ == "__main__":
+    main()
