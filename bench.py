@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="host processes of the CPU baseline (default min(cores, 32))")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (self-test of the N>1 path on one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,6 +114,8 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} ...")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+    if args.dist_backend == "gloo":  # self-test mode: all ranks may share one GPU
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -120,7 +123,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     import lhotse_amd
     from lhotse_amd import _lib
@@ -166,7 +172,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))

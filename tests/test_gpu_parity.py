@@ -196,3 +196,61 @@ def test_c_abi_padded_output_and_host_form():
     torch.cuda.synchronize()
     np.testing.assert_array_equal(d_o2.cpu().numpy(), np.concatenate(want))
     L.check("hipfeat_layout_destroy", int(h[0]))
+
+
+def test_one_very_long_cut_and_many_short_ones():
+    """SURVEY section 5 'long recordings': one 20-minute cut (the kaldifeat wrapper's chunk_size case,
+    lhotse/features/kaldifeat.py:160-163) is just more frame tiles; and a batch of 3000 minimal cuts
+    exercises the ragged workgroup -> cut search."""
+    from _hip import make_hip
+
+    ex = make_hip("fbank", {})
+    g = torch.Generator().manual_seed(3)
+    S = 20 * 60 * 16000 + 77
+    x = (torch.rand(S, generator=g) - 0.5)
+    y = ex.extract(x, 16000)
+    T = (S + 80) // 160
+    assert y.shape == (T, 80) and torch.isfinite(y).all()
+    o32 = RefExtractor(RefConfig(kind="fbank"), np.float32)
+    o64 = RefExtractor(RefConfig(kind="fbank"), np.float64)
+    # the middle minute and both ends against the oracle (frames are independent: a segment that starts
+    # on a frame boundary reproduces the interior rows)
+    f0 = 60000
+    seg = x[f0 * 160 - 120 * 160 : (f0 + 700) * 160].numpy()
+    want, truth = o32.extract(seg), o64.extract(seg)
+    got = y[f0 - 120 : f0 - 120 + want.shape[0]].cpu().numpy()
+    assert_parity(got[5:-5], want[5:-5], truth[5:-5], "long-middle")
+    head = o32.extract(x[:32000].numpy())
+    assert_parity(y[:150].cpu().numpy(), head[:150], o64.extract(x[:32000].numpy())[:150], "long-head")
+    tail = x[-32000:].numpy()
+    assert_parity(y[-150:].cpu().numpy(), o32.extract(tail)[-150:], o64.extract(tail)[-150:], "long-tail")
+    # many short cuts of every length 140..3139
+    waves = [x[i * 100 : i * 100 + 140 + i] for i in range(3000)]
+    outs = ex.extract_batch(waves, 16000)
+    assert len(outs) == 3000
+    for i in (0, 1, 19, 20, 21, 179, 180, 1234, 2999):
+        w = waves[i].numpy()
+        assert outs[i].shape == ((len(w) + 80) // 160, 80)
+        assert_parity(outs[i].cpu().numpy(), o32.extract(w), o64.extract(w), ("short", i))
+
+
+def test_generic_and_fast_kernels_agree(monkeypatch):
+    """The specialised fft512 kernels and the generic kernel are two implementations of the same
+    arithmetic; HIPFEAT_FORCE_GENERIC / HIPFEAT_FFT512_VARIANT select them at plan creation."""
+    from _hip import make_hip
+
+    rs = np.random.RandomState(11)
+    waves = [(rs.rand(n).astype(np.float32) - 0.5) for n in (16000, 4000, 160000, 12345)]
+    outs = {}
+    for name, env in [("fast_b", {}), ("fast_a", {"HIPFEAT_FFT512_VARIANT": "a"}), ("generic", {"HIPFEAT_FORCE_GENERIC": "1"})]:
+        for k in ("HIPFEAT_FFT512_VARIANT", "HIPFEAT_FORCE_GENERIC"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ex = make_hip("fbank", {})
+        outs[name] = (ex.kernel_name, ex.extract_batch(waves, 16000))
+    assert outs["fast_b"][0].startswith("fft512b_fbank") and outs["fast_a"][0].startswith("fft512_fbank") and outs["generic"][0] == "generic"
+    for a, b in zip(outs["fast_b"][1], outs["generic"][1]):
+        assert err_stats(a, b)["rel_l2"] < 2e-6
+    for a, b in zip(outs["fast_b"][1], outs["fast_a"][1]):
+        assert err_stats(a, b)["rel_l2"] < 2e-6

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the drop-in API (never reported as bench `value`): HipFbank.extract_batch on
+host tensors, i.e. pack -> H2D -> kernel -> D2H, for the default 600 s batch (60 x 10 s) and a large one."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import lhotse_amd
+ex = lhotse_amd.HipFbank()
+for B in (60, 1024):
+    x = (torch.rand(B, 160000) - 0.5)
+    xs = [x[i] for i in range(B)]
+    xn = [x[i].numpy() for i in range(B)]
+    for name, arg, kw in [("padded tensor + lengths (collate=True)", x, dict(lengths=torch.full((B,), 160000, dtype=torch.int32))),
+                          ("list of torch tensors", xs, {}), ("list of numpy arrays", xn, {})]:
+        ex.extract_batch(arg, 16000, **kw); torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 3.0:
+            r = ex.extract_batch(arg, 16000, **kw)
+            if isinstance(r, torch.Tensor): r = r.cpu()
+            elif isinstance(r, list) and isinstance(r[0], torch.Tensor): r = [t.cpu() for t in r]
+            n += B
+        torch.cuda.synchronize()
+        print(f"B={B:5d} {name:42s} {n / (time.perf_counter() - t0):10.0f} cuts/s (host in, host out)")
