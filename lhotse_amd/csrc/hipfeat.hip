@@ -87,6 +87,9 @@ struct hipfeat_plan {
   // fft512 fast path
   int variant = 0;  // 0 generic, 1 fft512 fbank (register-resident weights), 2 fft512 fbank "b" (4 workgroups/CU)
   float* d_mel_a4 = nullptr;
+  float* d_dct_consts = nullptr;
+  bool fast_mfcc = false;
+  int lm_stride = 0, dct_groups = 0, dct_floats = 0;
   int nrows = 0;    // template instance: pass-1 rows that can be non-zero
   int tiles_per_block = 4;
   int xs_floats = 0;
@@ -182,6 +185,7 @@ static void plan_free(hipfeat_plan* p) {
   (void)hipFree(p->d_scratch_out);
   (void)hipFree(p->d_lds_consts);
   (void)hipFree(p->d_mel_a4);
+  (void)hipFree(p->d_dct_consts);
   (void)hipFree(p->d_mel_a);
   (void)hipFree(p->d_work);
   for (auto& s : p->slots) {
@@ -199,18 +203,21 @@ template <int NROWS>
 static const void* fft512_entry() {
   return reinterpret_cast<const void*>(&fft512_fbank_kernel<NROWS>);
 }
-template <int NROWS>
+template <int NROWS, bool MFCC>
 static const void* fft512b_entry() {
-  return reinterpret_cast<const void*>(&fft512b_fbank_kernel<NROWS>);
+  return reinterpret_cast<const void*>(&fft512b_kernel<NROWS, MFCC>);
 }
 
-static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const float* h_mel) {
+static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const float* h_mel, const float* h_dct,
+                                   const float* h_lifter) {
   const hipfeat_config& c = p->cfg;
   const char* force = getenv("HIPFEAT_FORCE_GENERIC");
   if (force && force[0] == '1') return HIPFEAT_OK;
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
-  if (c.kind != HIPFEAT_FBANK || c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || c.use_fft_mag)
+  const bool mfcc = c.kind == HIPFEAT_MFCC;
+  if ((c.kind != HIPFEAT_FBANK && !mfcc) || c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || c.use_fft_mag)
     return HIPFEAT_OK;
+  if (mfcc && (M > 8 * kMaxDctGroups || c.num_ceps > 64)) return HIPFEAT_OK;
   const int need = (N + 31) / 32;
   const int nrows = need <= 10 ? 10 : (need <= 13 ? 13 : 16);
   const int ntiles = (M + 15) / 16;
@@ -312,7 +319,7 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   if (const char* tpb = getenv("HIPFEAT_TILES_PER_BLOCK")) p->tiles_per_block = std::max(1, atoi(tpb));
   p->const_floats = const_floats;
   const char* var = getenv("HIPFEAT_FFT512_VARIANT");
-  const bool use_b = !(var && var[0] == 'a');
+  const bool use_b = mfcc || !(var && var[0] == 'a');
   const void* fn;
   if (use_b) {
     // weights as 16-byte vectors: [wave][step / 4][lane][step % 4]
@@ -323,8 +330,33 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
           mel_a4[(((size_t)w * kBMelVec + st / 4) * 64 + lane) * 4 + (st & 3)] = mel_a[((size_t)w * kMelARegs + st) * 64 + lane];
     if ((st = upload(&p->d_mel_a4, mel_a4.data(), mel_a4.size())) != HIPFEAT_OK) return st;
     p->xs_floats = (15 * shift + 32 * nrows + 255) & ~255;  // whole 1 KiB LDS-DMA chunks
-    p->fast_lds_bytes = (size_t)(p->xs_floats + const_floats + 4 * kBWaveRegion) * sizeof(float);
-    fn = nrows == 10 ? fft512b_entry<10>() : (nrows == 13 ? fft512b_entry<13>() : fft512b_entry<16>());
+    size_t lds_floats = (size_t)p->xs_floats + const_floats + 4 * kBWaveRegion;
+    if (mfcc) {
+      // DCT^T as MFMA A operands: lane (i = lane & 15, kk = lane >> 4) of group g, half r holds
+      // dct[mel = 8 g + 2 kk + r][ceps = 16 ct + i]  (Wav2MFCC._dct, layers.py:697-706)
+      const int C = c.num_ceps, nct = (C + 15) / 16;
+      p->dct_groups = (M + 7) / 8;
+      p->lm_stride = ntiles <= 4 ? 68 : 132;  // == 4 mod 64: conflict-free 8-byte reads of the log-mel tile
+      std::vector<float> da((size_t)nct * p->dct_groups * 64 * 2, 0.0f);
+      for (int ct = 0; ct < nct; ++ct)
+        for (int g2 = 0; g2 < p->dct_groups; ++g2)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int r = 0; r < 2; ++r) {
+              const int i = lane & 15, kk = lane >> 4, m = 8 * g2 + 2 * kk + r, cc = 16 * ct + i;
+              if (m < M && cc < C) da[(((size_t)ct * p->dct_groups + g2) * 64 + lane) * 2 + r] = h_dct[(size_t)m * C + cc];
+            }
+      for (int cc = 0; cc < 64; ++cc)  // lifter (layers.py:681-695), ones when cepstral_lifter == 0
+        da.push_back((c.apply_lifter && h_lifter && cc < C) ? h_lifter[cc] : 1.0f);
+      p->dct_floats = (int)da.size();
+      if ((st = upload(&p->d_dct_consts, da.data(), da.size())) != HIPFEAT_OK) return st;
+      lds_floats += (size_t)kTileFrames * p->lm_stride + da.size();
+      p->fast_mfcc = true;
+    }
+    p->fast_lds_bytes = lds_floats * sizeof(float);
+    if (mfcc)
+      fn = nrows == 10 ? fft512b_entry<10, true>() : (nrows == 13 ? fft512b_entry<13, true>() : fft512b_entry<16, true>());
+    else
+      fn = nrows == 10 ? fft512b_entry<10, false>() : (nrows == 13 ? fft512b_entry<13, false>() : fft512b_entry<16, false>());
   } else {
     p->xs_floats = (15 * shift + 32 * nrows + 3) & ~3;
     p->fast_lds_bytes = (size_t)(p->xs_floats + const_floats + 4 * kWaveRegion) * sizeof(float);
@@ -336,7 +368,8 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, p->fast_lds_bytes) == hipSuccess) p->blocks_per_cu = nb;
   char nm[96];
-  snprintf(nm, sizeof(nm), "fft512%s_fbank<%d> lds=%zuB blocks/CU=%d", use_b ? "b" : "", nrows, p->fast_lds_bytes, p->blocks_per_cu);
+  snprintf(nm, sizeof(nm), "fft512%s_%s<%d> lds=%zuB blocks/CU=%d", use_b ? "b" : "", mfcc ? "mfcc" : "fbank", nrows, p->fast_lds_bytes,
+           p->blocks_per_cu);
   p->kernel_name = nm;
   p->variant = use_b ? 2 : 1;
   p->fpb = kTileFrames * p->tiles_per_block;
@@ -449,7 +482,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
   if (e != hipSuccess) return bail(fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", p->lds_bytes, hipGetErrorName(e)));
 
-  st = setup_fft512(p, h_window, h_mel);
+  st = setup_fft512(p, h_window, h_mel, h_dct, h_lifter);
   if (st != HIPFEAT_OK) return bail(st);
 
   *out = p;
@@ -602,15 +635,25 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.mel_floor = c.mel_floor;
     fp.xs_floats = plan->xs_floats;
     fp.const_floats = plan->const_floats;
+    fp.dct_consts = plan->d_dct_consts;
+    fp.C = c.num_ceps;
+    fp.lm_stride = plan->lm_stride;
+    fp.dct_groups = plan->dct_groups;
+    fp.dct_floats = plan->dct_floats;
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(256);
     if (plan->variant == 2) {
-      if (plan->nrows == 10)
-        hipLaunchKernelGGL(fft512b_fbank_kernel<10>, grid, block, plan->fast_lds_bytes, stream, fp);
-      else if (plan->nrows == 13)
-        hipLaunchKernelGGL(fft512b_fbank_kernel<13>, grid, block, plan->fast_lds_bytes, stream, fp);
-      else
-        hipLaunchKernelGGL(fft512b_fbank_kernel<16>, grid, block, plan->fast_lds_bytes, stream, fp);
+#define HF_LAUNCH_B(NR, MF) hipLaunchKernelGGL((fft512b_kernel<NR, MF>), grid, block, plan->fast_lds_bytes, stream, fp)
+      if (plan->fast_mfcc) {
+        if (plan->nrows == 10) HF_LAUNCH_B(10, true);
+        else if (plan->nrows == 13) HF_LAUNCH_B(13, true);
+        else HF_LAUNCH_B(16, true);
+      } else {
+        if (plan->nrows == 10) HF_LAUNCH_B(10, false);
+        else if (plan->nrows == 13) HF_LAUNCH_B(13, false);
+        else HF_LAUNCH_B(16, false);
+      }
+#undef HF_LAUNCH_B
     } else if (plan->nrows == 10)
       hipLaunchKernelGGL(fft512_fbank_kernel<10>, grid, block, plan->fast_lds_bytes, stream, fp);
     else if (plan->nrows == 13)

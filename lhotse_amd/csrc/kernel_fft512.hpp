@@ -63,6 +63,9 @@ struct Fft512Params {
   float preemph, mel_floor;
   int32_t xs_floats;     // LDS floats reserved for the sample span
   int32_t const_floats;  // LDS floats of the constant block
+  // MFCC stage (kernel b only): DCT as a second MFMA GEMM over the log-mel tile
+  const float* dct_consts;  // [ceps tiles][mel groups of 8][64 lanes][2] MFMA A operands (DCT^T) | [64] lifter; copied to LDS
+  int32_t C, lm_stride, dct_groups, dct_floats;
 };
 
 // Optional phase timers (experiment builds only): per-phase shader-clock totals over all waves.

@@ -30,8 +30,12 @@ constexpr int kBMelVec = kMelARegs / 4;                  // 16-byte loads of fil
 #define HIPFEAT_FFT512B_WAVES_PER_SIMD 4
 #endif
 
-template <int NROWS>
-__global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_fbank_kernel(const Fft512Params p) {
+constexpr int kMaxDctGroups = 10;  // 8-mel groups of the DCT GEMM (num_filters <= 80)
+
+// MFCC = false: log-mel filterbank output.  MFCC = true: the log-mel tile goes to LDS instead of HBM and a
+// second banded-free (dense, tiny) MFMA GEMM applies the DCT (layers.py:716), then the lifter (:717-718).
+template <int NROWS, bool MFCC>
+__global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_kernel(const Fft512Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;
   const v2* cwin = reinterpret_cast<const v2*>(smem + p.xs_floats);  // [NROWS][16]
@@ -61,6 +65,10 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_f
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((shift & 3) == 0) && ((p.npad_left & 3) == 0);
 
   for (int i = tid; i < p.const_floats; i += 256) smem[p.xs_floats + i] = p.lds_consts[i];
+  float* lm = regions + 4 * kBWaveRegion;            // [16 frames][lm_stride] log-mel tile (MFCC only)
+  float* dctl = lm + kTileFrames * p.lm_stride;      // DCT A operands (MFCC only)
+  if (MFCC)
+    for (int i = tid; i < p.dct_floats; i += 256) dctl[i] = p.dct_consts[i];
   const WaveWork ww = p.work[wv];
   const bool dc = (p.flags & F_REMOVE_DC) != 0;
   const float inv_n = 1.0f / (float)N;
@@ -242,7 +250,9 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_f
         v.y = fast_log(fmaxf(acc.y, p.mel_floor));
         v.z = fast_log(fmaxf(acc.z, p.mel_floor));
         v.w = fast_log(fmaxf(acc.w, p.mel_floor));
-        if (j < nf) {
+        if (MFCC) {
+          *reinterpret_cast<f32x4*>(lm + j * p.lm_stride + m0) = v;  // every column < 16 * tiles gets a finite value
+        } else if (j < nf) {
           if (vec_ok && m0 + 3 < p.M) {
             *reinterpret_cast<f32x4*>(orow + m0) = v;
           } else {
@@ -292,6 +302,41 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_f
           acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wgt(2 * (kMaxGroups0 + gi) + 1), pv[gi].y, acc2, 0, 0, 0);
         }
         epilogue(acc + acc2, ww.tile1);
+      }
+      if (MFCC) {
+        // ---- S6: cepstra = DCT^T x log-mel on the matrix cores, lifter, store -------------------
+        __syncthreads();
+        const int nct = (p.C + 15) >> 4;
+        const float* lmb = lm + j * p.lm_stride + 2 * kk;  // B operand: frame j, mel slot kk
+        for (int ct = wv; ct < nct; ct += 4) {
+          const v2* da = reinterpret_cast<const v2*>(dctl) + (size_t)ct * p.dct_groups * 64 + lane_o;
+          v2 av[kMaxDctGroups], bv[kMaxDctGroups];
+#pragma unroll
+          for (int gi = 0; gi < kMaxDctGroups; ++gi) {
+            const int ge = min(gi, p.dct_groups - 1);
+            av[gi] = da[ge * 64];
+            bv[gi] = *reinterpret_cast<const v2*>(lmb + 8 * ge);
+          }
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int gi = 0; gi < kMaxDctGroups; ++gi) {
+            if (gi < p.dct_groups) {
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gi].x, bv[gi].x, acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[gi].y, bv[gi].y, acc2, 0, 0, 0);
+            }
+          }
+          const f32x4 r4 = acc + acc2;
+          const int c0 = 16 * ct + 4 * kk;  // D[row = ceps 4*(lane>>4)+r][col = frame lane&15]
+          if (j < nf) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (c0 + r < p.C) {
+                // lifter values sit behind the DCT operands in LDS (ones when liftering is off)
+                orow[c0 + r] = r4[r] * dctl[p.dct_floats - 64 + c0 + r];
+              }
+            }
+          }
+        }
       }
     }
 #ifdef HIPFEAT_S5_PRIO

@@ -255,3 +255,24 @@ def test_generic_and_fast_kernels_agree(monkeypatch):
         assert err_stats(a, b)["rel_l2"] < 2e-6
     for a, b in zip(outs["fast_b"][1], outs["fast_a"][1]):
         assert err_stats(a, b)["rel_l2"] < 2e-6
+
+
+@pytest.mark.parametrize("cfg,fast", [({}, False), ({"num_filters": 40, "num_ceps": 40}, True),
+                                      ({"num_filters": 80, "num_ceps": 20, "cepstral_lifter": 0}, True),
+                                      ({"num_filters": 40, "num_ceps": 13, "frame_length": 0.02}, True)])
+def test_mfcc_fast_path(cfg, fast):
+    """MFCC on the fft512 kernel (DCT as a second MFMA GEMM) against the oracle.  The 23-filter default
+    has 16-mel tiles whose bands exceed the kernel's static MFMA schedule and stays on the generic kernel."""
+    from _hip import make_hip
+
+    ex = make_hip("mfcc", cfg)
+    assert ex.kernel_name.startswith("fft512b_mfcc") == fast, ex.kernel_name
+    rs = np.random.RandomState(21)
+    waves = [(rs.rand(n).astype(np.float32) - 0.5) for n in (16000, 140, 31999, 160000, 5000)]
+    outs = ex.extract_batch(waves, 16000)
+    rc = dict(cfg)
+    rc.setdefault("num_filters", 23)
+    o32 = RefExtractor(RefConfig(kind="mfcc", **rc), np.float32)
+    o64 = RefExtractor(RefConfig(kind="mfcc", **rc), np.float64)
+    for w, o in zip(waves, outs):
+        assert_parity(o, o32.extract(w), o64.extract(w), ("mfcc-fast", cfg, len(w)))
