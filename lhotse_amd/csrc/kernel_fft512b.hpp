@@ -118,6 +118,9 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
     float* myreg = regions + wv * kBWaveRegion;
 
     // ---- S3 ---------------------------------------------------------------------------------
+#if defined(HIPFEAT_ABLATE) && (HIPFEAT_ABLATE & 2)
+    if (p.N < 0)  // experiment builds only: the phase is compiled but skipped at run time
+#endif
     {
       const float* x = xs + (4 * wv + g) * shift + 2 * q;
       v2 z[16];
@@ -265,7 +268,11 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
       };
       auto wgt = [&](int step) -> float { return ma[step >> 2][step & 3]; };
       constexpr int CH = 4;
+#if defined(HIPFEAT_ABLATE) && (HIPFEAT_ABLATE & 1)
+      if (false) {
+#else
       if (ww.ngroups0 > 0) {
+#endif
         // P values of ALL chunks are requested unconditionally (clamped, always valid offsets), one chunk
         // ahead of the MFMAs that use them, so a chunk's LDS latency hides behind the previous chunk's
         // matrix work; only the MFMAs are skipped past the band.
