@@ -276,3 +276,37 @@ def test_mfcc_fast_path(cfg, fast):
     o64 = RefExtractor(RefConfig(kind="mfcc", **rc), np.float64)
     for w, o in zip(waves, outs):
         assert_parity(o, o32.extract(w), o64.extract(w), ("mfcc-fast", cfg, len(w)))
+
+
+def test_c_abi_unaligned_offsets_and_staging_ring():
+    """Cuts that start at arbitrary (not 16-byte aligned) offsets take the scalar staging path and must
+    give the same bits as aligned ones; ten back-to-back asynchronous hipfeat_extract calls recycle the
+    pinned descriptor ring (4 slots) without a host sync in between."""
+    from _hip import make_hip
+    from lhotse_amd import _lib
+
+    ex = make_hip("fbank", {})
+    plan = ex.plan
+    L = plan.lib
+    rs = np.random.RandomState(9)
+    lens = np.array([16001, 48000, 7777, 160000], dtype=np.int64)
+    waves = [(rs.rand(n).astype(np.float32) - 0.5) for n in lens]
+    want = np.concatenate(ex.extract_batch(waves, 16000))
+    gaps = [1, 2, 3, 5]
+    offs, cur, parts = [], 0, []
+    for w, g in zip(waves, gaps):
+        parts.append(np.zeros(g, dtype=np.float32))
+        cur += g
+        offs.append(cur)
+        parts.append(w)
+        cur += len(w)
+    flat = torch.from_numpy(np.concatenate(parts)).cuda()
+    offs = np.array(offs, dtype=np.int64)
+    total = int(((lens + 80) // 160).sum())
+    outs = [torch.empty((total, 80), device="cuda") for _ in range(10)]
+    st = torch.cuda.current_stream().cuda_stream
+    for o in outs:
+        L.check("hipfeat_extract", plan.handle, flat.data_ptr(), _lib.addr(offs), _lib.addr(lens), None, 4, o.data_ptr(), None, 80, st)
+    torch.cuda.synchronize()
+    for o in outs:
+        np.testing.assert_array_equal(o.cpu().numpy(), want)
