@@ -13,7 +13,15 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// lane l >= 1 of a row receives lane l-1's `v`; lane 0 (no source lane, bound_ctrl off) keeps `keep`.
+// One DPP move instead of a DPP move plus a v_cndmask: on gfx950 the VOP2 form of v_cndmask_b32
+// (implicit VCC), which hipcc selects for lane-predicated selects, issues ~4x slower than any other VALU op
+// (tools/ubench/valu_rate.hip).
+__device__ __forceinline__ float dpp_shr1_keep(float keep, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, false));
+}
 constexpr int DPP_QUAD(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+constexpr int DPP_ROW_SHR1 = 0x111;
 constexpr int DPP_ROW_ROR1 = 0x121;
 constexpr int DPP_ROW_MIRROR = 0x140;
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;
@@ -50,11 +58,11 @@ __device__ __forceinline__ void fft16(const v2 (&x)[16], v2 (&X)[16]) {
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
     const v2 s0 = x[n] + x[n + 8], s1 = x[n] - x[n + 8];
-    const v2 s2 = x[n + 4] + x[n + 12], s3 = rot_mi(x[n + 4] - x[n + 12]);
+    const v2 s2 = x[n + 4] + x[n + 12], u3 = swap2(x[n + 4] - x[n + 12]);
     y[n] = s0 + s2;
     y[8 + n] = s0 - s2;
-    y[4 + n] = s1 + s3;
-    y[12 + n] = s1 - s3;
+    y[4 + n] = u3 * HF_CJ + s1;    // s1 + (-i) t : one packed fma, the swap folds into op_sel
+    y[12 + n] = u3 * HF_NCJ + s1;  // s1 - (-i) t
   }
   // twiddles W16^(n*m): w = (c, -s), wp = (s, c)
   y[4 + 1] = cmulc(y[4 + 1], v2{C1, -S1}, v2{S1, C1});      // n=1 m=1: W^1
@@ -69,11 +77,11 @@ __device__ __forceinline__ void fft16(const v2 (&x)[16], v2 (&X)[16]) {
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const v2 s0 = y[4 * m] + y[4 * m + 2], s1 = y[4 * m] - y[4 * m + 2];
-    const v2 s2 = y[4 * m + 1] + y[4 * m + 3], s3 = rot_mi(y[4 * m + 1] - y[4 * m + 3]);
-    X[m] = s0 + s2;       // k' = 0
-    X[m + 4] = s1 + s3;   // k' = 1
-    X[m + 8] = s0 - s2;   // k' = 2
-    X[m + 12] = s1 - s3;  // k' = 3
+    const v2 s2 = y[4 * m + 1] + y[4 * m + 3], u3 = swap2(y[4 * m + 1] - y[4 * m + 3]);
+    X[m] = s0 + s2;                // k' = 0
+    X[m + 4] = u3 * HF_CJ + s1;    // k' = 1
+    X[m + 8] = s0 - s2;            // k' = 2
+    X[m + 12] = u3 * HF_NCJ + s1;  // k' = 3
   }
 }
 

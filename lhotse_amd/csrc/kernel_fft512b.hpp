@@ -139,13 +139,15 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
       for (int n1 = 0; n1 < NROWS; ++n1) sum2 += z[n1];
       float mu = 0.f;
       if (dc) mu = row16_sum(sum2.x + sum2.y) * inv_n;
-      float tprev = 0.f;
+      // previous sample of the first element of each pair: lane q-1's second element; for lane 0 it is
+      // lane 15's second element of the previous row (fetched one row earlier with row_ror:1), and the
+      // very first sample of the frame replicates itself (layers.py:166)
+      float wrap = 0.f;
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) {
         const v2 d = z[n1] - v2{mu, mu};
-        const float tcur = dpp_mov<DPP_ROW_ROR1>(d.y);
-        const float dp = (q == 0) ? (n1 == 0 ? d.x : tprev) : tcur;
-        tprev = tcur;
+        const float dp = dpp_shr1_keep(n1 == 0 ? d.x : wrap, d.y);
+        if (n1 + 1 < NROWS) wrap = dpp_mov<DPP_ROW_ROR1>(d.y);
         z[n1] = (d - v2{c, c} * v2{dp, d.x}) * win[n1];
       }
 #pragma unroll
@@ -193,8 +195,13 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         t1[2 * k2] = dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].x);
         t1[2 * k2 + 1] = dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].y);
       }
+      // second half of the lane map l -> (16 - l) % 16: shift right by one; lane 0 has no source and
+      // keeps its own register (16 - k2) % 16 instead (its mirror partner is itself)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) t1[i] = dpp_mov<DPP_ROW_ROR1>(t1[i]);
+      for (int k2 = 0; k2 < 8; ++k2) {
+        t1[2 * k2] = dpp_shr1_keep(Z[(16 - k2) & 15].x, t1[2 * k2]);
+        t1[2 * k2 + 1] = dpp_shr1_keep(Z[(16 - k2) & 15].y, t1[2 * k2 + 1]);
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         v2 tw[4], twq[4];  // split-step twiddles of 4 bin pairs per burst
@@ -206,8 +213,7 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k2 = 4 * h + r;
-          v2 m = v2{t1[2 * k2], t1[2 * k2 + 1]};
-          if (q == 0) m = Z[(16 - k2) & 15];
+          const v2 m = v2{t1[2 * k2], t1[2 * k2 + 1]};
           const v2 sp = m * HF_CJ + Z[k2];
           const v2 dm = m * HF_NCJ + Z[k2];
           const v2 tt = cmulc(dm, tw[r], twq[r]);

@@ -63,6 +63,17 @@ __global__ void k(float* out, int iters, unsigned long long* clk) {
   }
   const unsigned long long c1 = __builtin_readcyclecounter();
   if ((threadIdx.x & 63) == 0 && clk) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = c1 - c0;
+  if (MODE == 18 || MODE == 19) {
+    asm volatile("v_cmp_gt_u32 vcc, 32, %0" :: "v"(threadIdx.x & 63) : "vcc");
+    for (int i = 0; i < iters; ++i) {
+      if (MODE == 18) { REP8(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                        "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc");) }
+      else { REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %8, vcc\n v_cndmask_b32_e64 %1, %1, %8, vcc\n v_cndmask_b32_e64 %2, %2, %8, vcc\n v_cndmask_b32_e64 %3, %3, %8, vcc\n"
+                        "v_cndmask_b32_e64 %4, %4, %8, vcc\n v_cndmask_b32_e64 %5, %5, %8, vcc\n v_cndmask_b32_e64 %6, %6, %8, vcc\n v_cndmask_b32_e64 %7, %7, %8, vcc\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc");) }
+    }
+  }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
 }
 template <int MODE>
@@ -105,6 +116,8 @@ int main() {
     run<5>(w, "v_mov_b32_dpp", 0);
     run<6>(w, "v_pk_add_f32 op_sel", 2);
     run<7>(w, "v_cndmask_b32", 0);
+    run<18>(w, "v_cndmask_b32 e32 vcc(def)", 0);
+    run<19>(w, "v_cndmask_b32_e64 vcc", 0);
     run<8>(w, "v_cndmask_b32_e64 sgpr", 0);
     run<9>(w, "v_fmac_f32", 2);
     run<10>(w, "v_mul_f32", 1);
