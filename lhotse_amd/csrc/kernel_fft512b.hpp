@@ -238,18 +238,33 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
     __builtin_amdgcn_s_setprio(HIPFEAT_S5_PRIO);
 #endif
     {
+      const int j = lane_o & 15, kk = lane_o >> 4;
+      const float* pb = regions + (j >> 2) * kBWaveRegion + (j & 3) * kPRowStride + 2 * kk;
+      // P values of the first segment: ALL chunks are requested unconditionally (clamped, always valid
+      // offsets), one chunk ahead of the MFMAs that use them; the first request goes out before anything
+      // else in this phase so that its LDS latency overlaps the weight hand-over and the DMA issue.
+      constexpr int CH = 4;
+      constexpr int NCH = (kMaxGroups0 + CH - 1) / CH;
+      v2 pv[NCH][CH];
+      auto load_chunk = [&](int ci) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) pv[ci][i] = *reinterpret_cast<const v2*>(pb + min(ww.bin0 + 8 * (ci * CH + i), kPRowStride - 8));
+      };
+      load_chunk(0);
       // gfx950 has ONE in-order counter for all vector-memory operations: take delivery of the weights
       // (requested before the barrier) BEFORE the span DMA is issued, otherwise their first use would
       // have to wait for the much slower HBM transfer queued behind them.
 #pragma unroll
       for (int i = 0; i < kBMelVec; ++i) asm volatile("" : "+v"(ma[i]));
+#ifdef HIPFEAT_PHASE_TIMERS3
+      const unsigned long long v0 = __builtin_readcyclecounter();
+      hf_acc[6] += v0 - t4;  // weights wait
+#endif
       // xs is dead until the next tile: stage the next span now (lands during the mel GEMM)
       {
         const int fn = f0 + kTileFrames;
         if (t + 1 < p.tiles_per_block && fn < cd.num_frames) stage_span(fn, lane16);
       }
-      const int j = lane_o & 15, kk = lane_o >> 4;
-      const float* pb = regions + (j >> 2) * kBWaveRegion + (j & 3) * kPRowStride + 2 * kk;
       float* orow = p.out + (cd.out_row + f0 + j) * p.out_stride;
       const bool vec_ok = ((p.out_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
       auto epilogue = [&](const f32x4 acc, int tile) {
@@ -273,23 +288,12 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         }
       };
       auto wgt = [&](int step) -> float { return ma[step >> 2][step & 3]; };
-      constexpr int CH = 4;
 #if defined(HIPFEAT_ABLATE) && (HIPFEAT_ABLATE & 1)
       if (false) {
 #else
       if (ww.ngroups0 > 0) {
 #endif
-        // P values of ALL chunks are requested unconditionally (clamped, always valid offsets), one chunk
-        // ahead of the MFMAs that use them, so a chunk's LDS latency hides behind the previous chunk's
-        // matrix work; only the MFMAs are skipped past the band.
-        constexpr int NCH = (kMaxGroups0 + CH - 1) / CH;
-        v2 pv[NCH][CH];
-        auto load_chunk = [&](int ci) {
-#pragma unroll
-          for (int i = 0; i < CH; ++i) pv[ci][i] = *reinterpret_cast<const v2*>(pb + min(ww.bin0 + 8 * (ci * CH + i), kPRowStride - 8));
-        };
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        load_chunk(0);
 #pragma unroll
         for (int ci = 0; ci < NCH; ++ci) {
           if (ci + 1 < NCH) load_chunk(ci + 1);
@@ -302,6 +306,11 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
               }
           }
         }
+#ifdef HIPFEAT_PHASE_TIMERS3
+        asm volatile("" : "+v"(acc), "+v"(acc2));
+        const unsigned long long v1 = __builtin_readcyclecounter();
+        hf_acc[7] += v1 - v0;  // DMA issue + P reads + MFMA chain of segment 0
+#endif
         epilogue(acc + acc2, ww.tile0);
       }
       if (ww.ngroups1 > 0) {
