@@ -368,8 +368,12 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, p->fast_lds_bytes) == hipSuccess) p->blocks_per_cu = nb;
   char nm[96];
-  snprintf(nm, sizeof(nm), "fft512%s_%s<%d> lds=%zuB blocks/CU=%d", use_b ? "b" : "", mfcc ? "mfcc" : "fbank", nrows, p->fast_lds_bytes,
-           p->blocks_per_cu);
+  // same spelling as the device symbol rocprofv3 reports (modulo the space after the comma)
+  if (use_b)
+    snprintf(nm, sizeof(nm), "fft512b_kernel<%d,%s> %s lds=%zuB blocks/CU=%d", nrows, mfcc ? "true" : "false", mfcc ? "mfcc" : "fbank",
+             p->fast_lds_bytes, p->blocks_per_cu);
+  else
+    snprintf(nm, sizeof(nm), "fft512_fbank_kernel<%d> fbank lds=%zuB blocks/CU=%d", nrows, p->fast_lds_bytes, p->blocks_per_cu);
   p->kernel_name = nm;
   p->variant = use_b ? 2 : 1;
   p->fpb = kTileFrames * p->tiles_per_block;
