@@ -22,6 +22,7 @@ enum : int32_t {
   F_FFT_MAG = 1 << 3,
   F_LIFTER = 1 << 4,
   F_POW2 = 1 << 5,
+  F_LOG_SPEC = 1 << 6,
 };
 
 // Kernel arguments of the generic kernel (passed by value; lives in the kernarg segment).

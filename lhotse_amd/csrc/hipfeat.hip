@@ -89,6 +89,7 @@ struct hipfeat_plan {
   float* d_mel_a4 = nullptr;
   float* d_dct_consts = nullptr;
   bool fast_mfcc = false;
+  int fast_out = 0;  // kernel b output stage: 0 fbank, 1 mfcc, 2 (log-)spectrogram
   int lm_stride = 0, dct_groups = 0, dct_floats = 0;
   int nrows = 0;    // template instance: pass-1 rows that can be non-zero
   int tiles_per_block = 4;
@@ -203,9 +204,9 @@ template <int NROWS>
 static const void* fft512_entry() {
   return reinterpret_cast<const void*>(&fft512_fbank_kernel<NROWS>);
 }
-template <int NROWS, bool MFCC>
+template <int NROWS, int OUT>
 static const void* fft512b_entry() {
-  return reinterpret_cast<const void*>(&fft512b_kernel<NROWS, MFCC>);
+  return reinterpret_cast<const void*>(&fft512b_kernel<NROWS, OUT>);
 }
 
 static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const float* h_mel, const float* h_dct,
@@ -215,12 +216,12 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   if (force && force[0] == '1') return HIPFEAT_OK;
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
   const bool mfcc = c.kind == HIPFEAT_MFCC;
-  if ((c.kind != HIPFEAT_FBANK && !mfcc) || c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || c.use_fft_mag)
-    return HIPFEAT_OK;
+  const bool spec = c.kind == HIPFEAT_SPECTROGRAM || c.kind == HIPFEAT_LOG_SPECTROGRAM;
+  if (c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || (!spec && c.use_fft_mag)) return HIPFEAT_OK;
   if (mfcc && (M > 8 * kMaxDctGroups || c.num_ceps > 64)) return HIPFEAT_OK;
   const int need = (N + 31) / 32;
   const int nrows = need <= 10 ? 10 : (need <= 13 ? 13 : 16);
-  const int ntiles = (M + 15) / 16;
+  const int ntiles = spec ? 0 : (M + 15) / 16;
   if (ntiles > 8) return HIPFEAT_OK;
 
   // band of every 16-mel tile, in 8-bin groups starting at an even bin
@@ -319,7 +320,7 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   if (const char* tpb = getenv("HIPFEAT_TILES_PER_BLOCK")) p->tiles_per_block = std::max(1, atoi(tpb));
   p->const_floats = const_floats;
   const char* var = getenv("HIPFEAT_FFT512_VARIANT");
-  const bool use_b = mfcc || !(var && var[0] == 'a');
+  const bool use_b = mfcc || spec || !(var && var[0] == 'a');
   const void* fn;
   if (use_b) {
     // weights as 16-byte vectors: [wave][step / 4][lane][step % 4]
@@ -353,10 +354,13 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
       p->fast_mfcc = true;
     }
     p->fast_lds_bytes = lds_floats * sizeof(float);
+    p->fast_out = mfcc ? 1 : (spec ? 2 : 0);
     if (mfcc)
-      fn = nrows == 10 ? fft512b_entry<10, true>() : (nrows == 13 ? fft512b_entry<13, true>() : fft512b_entry<16, true>());
+      fn = nrows == 10 ? fft512b_entry<10, 1>() : (nrows == 13 ? fft512b_entry<13, 1>() : fft512b_entry<16, 1>());
+    else if (spec)
+      fn = nrows == 10 ? fft512b_entry<10, 2>() : (nrows == 13 ? fft512b_entry<13, 2>() : fft512b_entry<16, 2>());
     else
-      fn = nrows == 10 ? fft512b_entry<10, false>() : (nrows == 13 ? fft512b_entry<13, false>() : fft512b_entry<16, false>());
+      fn = nrows == 10 ? fft512b_entry<10, 0>() : (nrows == 13 ? fft512b_entry<13, 0>() : fft512b_entry<16, 0>());
   } else {
     p->xs_floats = (15 * shift + 32 * nrows + 3) & ~3;
     p->fast_lds_bytes = (size_t)(p->xs_floats + const_floats + 4 * kWaveRegion) * sizeof(float);
@@ -370,8 +374,8 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   char nm[96];
   // same spelling as the device symbol rocprofv3 reports (modulo the space after the comma)
   if (use_b)
-    snprintf(nm, sizeof(nm), "fft512b_kernel<%d,%s> %s lds=%zuB blocks/CU=%d", nrows, mfcc ? "true" : "false", mfcc ? "mfcc" : "fbank",
-             p->fast_lds_bytes, p->blocks_per_cu);
+    snprintf(nm, sizeof(nm), "fft512b_kernel<%d,%d> %s lds=%zuB blocks/CU=%d", nrows, p->fast_out,
+             mfcc ? "mfcc" : (spec ? "spectrogram" : "fbank"), p->fast_lds_bytes, p->blocks_per_cu);
   else
     snprintf(nm, sizeof(nm), "fft512_fbank_kernel<%d> fbank lds=%zuB blocks/CU=%d", nrows, p->fast_lds_bytes, p->blocks_per_cu);
   p->kernel_name = nm;
@@ -634,7 +638,8 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.shift = c.frame_shift;
     fp.npad_left = plan->npad_left;
     fp.M = c.num_filters;
-    fp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0);
+    fp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0) | (c.use_fft_mag ? F_FFT_MAG : 0) | (c.kind == HIPFEAT_LOG_SPECTROGRAM ? F_LOG_SPEC : 0);
+    fp.log_offset = c.log_offset;
     fp.preemph = c.preemph_coeff;
     fp.mel_floor = c.mel_floor;
     fp.xs_floats = plan->xs_floats;
@@ -647,16 +652,17 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(256);
     if (plan->variant == 2) {
-#define HF_LAUNCH_B(NR, MF) hipLaunchKernelGGL((fft512b_kernel<NR, MF>), grid, block, plan->fast_lds_bytes, stream, fp)
-      if (plan->fast_mfcc) {
-        if (plan->nrows == 10) HF_LAUNCH_B(10, true);
-        else if (plan->nrows == 13) HF_LAUNCH_B(13, true);
-        else HF_LAUNCH_B(16, true);
-      } else {
-        if (plan->nrows == 10) HF_LAUNCH_B(10, false);
-        else if (plan->nrows == 13) HF_LAUNCH_B(13, false);
-        else HF_LAUNCH_B(16, false);
-      }
+#define HF_LAUNCH_B(NR, OUT) hipLaunchKernelGGL((fft512b_kernel<NR, OUT>), grid, block, plan->fast_lds_bytes, stream, fp)
+#define HF_LAUNCH_NR(OUT)                      \
+  do {                                         \
+    if (plan->nrows == 10) HF_LAUNCH_B(10, OUT);      \
+    else if (plan->nrows == 13) HF_LAUNCH_B(13, OUT); \
+    else HF_LAUNCH_B(16, OUT);                        \
+  } while (0)
+      if (plan->fast_out == 1) HF_LAUNCH_NR(1);
+      else if (plan->fast_out == 2) HF_LAUNCH_NR(2);
+      else HF_LAUNCH_NR(0);
+#undef HF_LAUNCH_NR
 #undef HF_LAUNCH_B
     } else if (plan->nrows == 10)
       hipLaunchKernelGGL(fft512_fbank_kernel<10>, grid, block, plan->fast_lds_bytes, stream, fp);

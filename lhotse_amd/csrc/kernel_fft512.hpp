@@ -60,7 +60,7 @@ struct Fft512Params {
   int64_t out_stride;
   int32_t num_cuts, uniform_bpc, tiles_per_block;
   int32_t N, shift, npad_left, M, flags;
-  float preemph, mel_floor;
+  float preemph, mel_floor, log_offset;
   int32_t xs_floats;     // LDS floats reserved for the sample span
   int32_t const_floats;  // LDS floats of the constant block
   // MFCC stage (kernel b only): DCT as a second MFMA GEMM over the log-mel tile

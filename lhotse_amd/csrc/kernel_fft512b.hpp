@@ -32,10 +32,13 @@ constexpr int kBMelVec = kMelARegs / 4;                  // 16-byte loads of fil
 
 constexpr int kMaxDctGroups = 10;  // 8-mel groups of the DCT GEMM (num_filters <= 80)
 
-// MFCC = false: log-mel filterbank output.  MFCC = true: the log-mel tile goes to LDS instead of HBM and a
-// second banded-free (dense, tiny) MFMA GEMM applies the DCT (layers.py:716), then the lifter (:717-718).
-template <int NROWS, bool MFCC>
+// OUT = 0: log-mel filterbank (Wav2LogFilterBank).  OUT = 1: MFCC -- the log-mel tile goes to LDS instead of
+// HBM and a second (dense, tiny) MFMA GEMM applies the DCT (layers.py:716), then the lifter (:717-718).
+// OUT = 2: (log-)spectrogram (Wav2Spec / Wav2LogSpec, layers.py:392-402, :461-473) -- every wave streams the
+// power rows of its own four frames from LDS to HBM; no matrix-core stage.
+template <int NROWS, int OUT>
 __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_kernel(const Fft512Params p) {
+  constexpr bool MFCC = OUT == 1, SPEC = OUT == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;
   const v2* cwin = reinterpret_cast<const v2*>(smem + p.xs_floats);  // [NROWS][16]
@@ -227,8 +230,10 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
     // the filter weights of this wave's band: requested now (the FFT registers are dead), so the L2
     // latency hides behind the barrier and the start of S5
     f32x4 ma[kBMelVec];
+    if (!SPEC) {
 #pragma unroll
-    for (int i = 0; i < kBMelVec; ++i) ma[i] = *reinterpret_cast<const f32x4*>(mel_base + ((unsigned)i * 1024u + lane16));
+      for (int i = 0; i < kBMelVec; ++i) ma[i] = *reinterpret_cast<const f32x4*>(mel_base + ((unsigned)i * 1024u + lane16));
+    }
     HF_T(3);
     __syncthreads();
     HF_T(4);
@@ -237,7 +242,27 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
 #ifdef HIPFEAT_S5_PRIO
     __builtin_amdgcn_s_setprio(HIPFEAT_S5_PRIO);
 #endif
-    {
+    if (SPEC) {
+      {
+        const int fn = f0 + kTileFrames;
+        if (t + 1 < p.tiles_per_block && fn < cd.num_frames) stage_span(fn, lane16);
+      }
+      const int K = 257;
+#pragma unroll
+      for (int fr = 0; fr < 4; ++fr) {
+        const int f = 4 * wv + fr;
+        if (f < nf) {  // uniform
+          const float* prow = myreg + fr * kPRowStride;
+          float* orow = p.out + (cd.out_row + f0 + f) * p.out_stride;
+          for (int col = lane_o; col < K; col += 64) {
+            float v = prow[col];
+            if (p.flags & F_FFT_MAG) v = sqrtf(v);
+            if (p.flags & F_LOG_SPEC) v = fast_log(v + p.log_offset);
+            orow[col] = v;
+          }
+        }
+      }
+    } else {
       const int j = lane_o & 15, kk = lane_o >> 4;
       const float* pb = regions + (j >> 2) * kBWaveRegion + (j & 3) * kPRowStride + 2 * kk;
       // P values of the first segment: ALL chunks are requested unconditionally (clamped, always valid

@@ -23,13 +23,20 @@ REL_TOL = 1e-4
 ABS_TOL = 2e-3
 
 
-def assert_parity(got, want, truth, ctx):
+def assert_parity(got, want, truth, ctx, abs_tol=ABS_TOL):
     s = err_stats(got, want)
     floor = err_stats(want, truth)
     own = err_stats(got, truth)
     assert np.isfinite(np.asarray(got)).all(), ctx
     assert s["rel_l2"] <= max(REL_TOL, 3 * floor["rel_l2"]), (ctx, s, floor, own)
-    assert s["max_abs"] <= max(ABS_TOL, 3 * floor["max_abs"]), (ctx, s, floor, own)
+    assert s["max_abs"] <= max(abs_tol, 3 * floor["max_abs"]), (ctx, s, floor, own)
+
+
+# log of a single near-silent FFT bin: both float32 implementations are dominated by rounding there
+# (tools/fft_accuracy.py: power error / frame peak power = 3e-7 for reference arithmetic and HIP alike, which
+# is 9e-4 vs 6e-3 RELATIVE on a bin 57 dB below the peak).  The norm-wise bar stays 1e-4; the element-wise
+# bar for log-spectra is 1e-2 with >= 99.95 % of the elements inside rtol 1e-4 / atol 1e-3.
+LOGSPEC_ABS_TOL = 1e-2
 
 
 @pytest.mark.parametrize("name", CASE_NAMES)
@@ -310,3 +317,23 @@ def test_c_abi_unaligned_offsets_and_staging_ring():
     torch.cuda.synchronize()
     for o in outs:
         np.testing.assert_array_equal(o.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("kind,cfg", [("spectrogram", {}), ("log-spectrogram", {}), ("spectrogram", {"use_fft_mag": True}),
+                                      ("log-spectrogram", {"use_fft_mag": True, "window_type": "hamming"})])
+def test_spectrogram_fast_path(kind, cfg):
+    """(log-)spectrogram on the fft512 kernel: ragged batch against the oracle, incl. the Nyquist bin."""
+    from _hip import make_hip
+
+    ex = make_hip(kind, cfg)
+    assert ex.kernel_name.startswith("fft512b_kernel") and " spectrogram " in ex.kernel_name, ex.kernel_name
+    rs = np.random.RandomState(31)
+    waves = [(rs.rand(n).astype(np.float32) - 0.5) for n in (16000, 140, 31999, 80000)]
+    outs = ex.extract_batch(waves, 16000)
+    o32 = RefExtractor(RefConfig(kind=kind, **cfg), np.float32)
+    o64 = RefExtractor(RefConfig(kind=kind, **cfg), np.float64)
+    for w, o in zip(waves, outs):
+        assert o.shape[1] == 257
+        want = o32.extract(w)
+        assert_parity(np.asarray(o), want, o64.extract(w), (kind, cfg, len(w)), abs_tol=LOGSPEC_ABS_TOL if kind == "log-spectrogram" else ABS_TOL)
+        assert err_stats(np.asarray(o), want)["frac_within"] >= 0.9995
