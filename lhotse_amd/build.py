@@ -8,6 +8,7 @@ working tree.  No torch, no pybind: the library is a plain C-ABI shared object.
 """
 from __future__ import annotations
 
+import fcntl
 import os
 import shutil
 import subprocess
@@ -48,31 +49,40 @@ def build(force: bool = False, verbose: bool = False, extra_flags: List[str] = (
     if output is None and not force and not needs_build():
         return LIB_PATH
     LIB_DIR.mkdir(exist_ok=True)
-    cmd = [
-        hipcc_path(),
-        f"--offload-arch={ARCH}",
-        "-O3",
-        "-std=c++17",
-        "-fPIC",
-        "-shared",
-        "-fvisibility=hidden",
-        "-Wall",
-        "-Wno-unused-function",
-        "-DHIPFEAT_BUILD",
-        *list(extra_flags),
-        *[str(s) for s in SOURCES],
-        "-o",
-        str(out_path) + ".tmp",
-    ]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd), file=sys.stderr)
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
-    if verbose:
-        print(res.stderr, file=sys.stderr)
-    os.replace(str(out_path) + ".tmp", out_path)
+    # one builder at a time: several ranks of a multi-GPU job may import the package simultaneously
+    with open(LIB_DIR / ".build.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if output is None and not force and not needs_build():
+                return LIB_PATH  # another process built it while we waited
+            tmp = f"{out_path}.{os.getpid()}.tmp"
+            cmd = [
+                hipcc_path(),
+                f"--offload-arch={ARCH}",
+                "-O3",
+                "-std=c++17",
+                "-fPIC",
+                "-shared",
+                "-fvisibility=hidden",
+                "-Wall",
+                "-Wno-unused-function",
+                "-DHIPFEAT_BUILD",
+                *list(extra_flags),
+                *[str(s) for s in SOURCES],
+                "-o",
+                tmp,
+            ]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+                print(" ".join(cmd), file=sys.stderr)
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+            if verbose:
+                print(res.stderr, file=sys.stderr)
+            os.replace(tmp, out_path)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return out_path
 
 

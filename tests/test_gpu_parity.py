@@ -264,12 +264,12 @@ def test_generic_and_fast_kernels_agree(monkeypatch):
         assert err_stats(a, b)["rel_l2"] < 2e-6
 
 
-@pytest.mark.parametrize("cfg,fast", [({}, False), ({"num_filters": 40, "num_ceps": 40}, True),
+@pytest.mark.parametrize("cfg,fast", [({}, True), ({"num_filters": 40, "num_ceps": 40}, True),
                                       ({"num_filters": 80, "num_ceps": 20, "cepstral_lifter": 0}, True),
                                       ({"num_filters": 40, "num_ceps": 13, "frame_length": 0.02}, True)])
 def test_mfcc_fast_path(cfg, fast):
-    """MFCC on the fft512 kernel (DCT as a second MFMA GEMM) against the oracle.  The 23-filter default
-    has 16-mel tiles whose bands exceed the kernel's static MFMA schedule and stays on the generic kernel."""
+    """MFCC on the fft512 kernel (DCT as a second MFMA GEMM) against the oracle, including the 23-filter /
+    13-cepstra Kaldi default whose 16-mel tiles have 112- and 144-bin bands."""
     from _hip import make_hip
 
     ex = make_hip("mfcc", cfg)
@@ -337,3 +337,19 @@ def test_spectrogram_fast_path(kind, cfg):
         want = o32.extract(w)
         assert_parity(np.asarray(o), want, o64.extract(w), (kind, cfg, len(w)), abs_tol=LOGSPEC_ABS_TOL if kind == "log-spectrogram" else ABS_TOL)
         assert err_stats(np.asarray(o), want)["frac_within"] >= 0.9995
+
+
+@pytest.mark.parametrize("cfg", [{"num_filters": 23}, {"num_filters": 128}, {"num_filters": 64, "low_freq": 0.0, "high_freq": 0.0},
+                                 {"num_filters": 24, "frame_length": 0.032, "frame_shift": 0.016}])
+def test_fbank_fast_path_other_filterbanks(cfg):
+    from _hip import make_hip
+
+    ex = make_hip("fbank", cfg)
+    assert ex.kernel_name.startswith("fft512b_kernel"), ex.kernel_name
+    rs = np.random.RandomState(41)
+    waves = [(rs.rand(n).astype(np.float32) - 0.5) for n in (16000, 600, 31999)]
+    outs = ex.extract_batch(waves, 16000)
+    o32 = RefExtractor(RefConfig(kind="fbank", **cfg), np.float32)
+    o64 = RefExtractor(RefConfig(kind="fbank", **cfg), np.float64)
+    for w, o in zip(waves, outs):
+        assert_parity(o, o32.extract(w), o64.extract(w), ("fbank-fast", cfg, len(w)))
