@@ -165,6 +165,25 @@ HIPFEAT_API hipfeat_status hipfeat_extract_host(const hipfeat_plan* plan, const 
                                     int64_t out_elems, const int64_t* h_out_rows, int64_t out_row_stride,
                                     void* stream);
 
+
+/* ---- "next" row: speed perturbation = polyphase sinc resampling --------------- */
+/*
+ * Replaces ResampleTensor (lhotse/augmentation/resample.py:42-142, :284-315) as used by
+ * Speed.__call__ (lhotse/augmentation/torchaudio.py:37-42).  `orig_freq` / `new_freq` are the
+ * gcd-reduced rates; h_kernel is the float32 filter bank [new_freq][2*width + orig_freq] computed by
+ * the caller with the reference's formula (resample.py:184-281), so its values are the caller's.
+ */
+typedef struct hipfeat_resampler hipfeat_resampler;
+HIPFEAT_API hipfeat_status hipfeat_resampler_create(int32_t orig_freq, int32_t new_freq, int32_t width, const float* h_kernel,
+                                        int32_t device, hipfeat_resampler** resampler);
+HIPFEAT_API hipfeat_status hipfeat_resampler_destroy(hipfeat_resampler* resampler);
+/* ceil(new * num_samples / orig), evaluated like the reference (in float32, resample.py:309). */
+HIPFEAT_API int64_t hipfeat_resampled_length(int64_t num_samples, int32_t orig_freq, int32_t new_freq);
+/* Batch of cuts: cut b = d_in[h_in_offsets[b] .. + h_num_samples[b]) -> d_out[h_out_offsets[b] .. + resampled_length). */
+HIPFEAT_API hipfeat_status hipfeat_resample(const hipfeat_resampler* resampler, const float* d_in, const int64_t* h_in_offsets,
+                                const int64_t* h_num_samples, int64_t batch, float* d_out, const int64_t* h_out_offsets,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

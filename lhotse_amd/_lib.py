@@ -48,6 +48,13 @@ _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
         "int",
         ["const hipfeat_plan*", "const float*", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "const int64_t*", "int64_t", "void*"],
     ),
+    "hipfeat_resampler_create": ("int", ["int32_t", "int32_t", "int32_t", "const float*", "int32_t", "hipfeat_resampler**"]),
+    "hipfeat_resampler_destroy": ("int", ["hipfeat_resampler*"]),
+    "hipfeat_resampled_length": ("int64_t", ["int64_t", "int32_t", "int32_t"]),
+    "hipfeat_resample": (
+        "int",
+        ["const hipfeat_resampler*", "const float*", "const int64_t*", "const int64_t*", "int64_t", "float*", "const int64_t*", "void*"],
+    ),
     "hipfeat_extract_host": (
         "int",
         ["const hipfeat_plan*", "const float*", "int64_t", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "int64_t", "const int64_t*", "int64_t", "void*"],
@@ -80,6 +87,8 @@ CONFIG_DTYPE = np.dtype(
 )
 
 STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "HIP", 3: "UNSUPPORTED", 4: "TOO_SHORT"}
+ERR_INVALID = 1
+ERR_HIP = 2
 ERR_TOO_SHORT = 4
 ERR_UNSUPPORTED = 3
 

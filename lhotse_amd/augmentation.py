@@ -1,0 +1,219 @@
+"""
+GPU speed perturbation / sinc resampling behind lhotse's ``AudioTransform`` interface
+("next" row 1).
+
+Mirrors lhotse/augmentation/torchaudio.py:26-140 (``Speed``, ``Resample``, ``get_or_create_resampler``) and
+lhotse/augmentation/resample.py:42-142 (``Resample`` module, here ``HipResampleTensor``): same names, arguments,
+output lengths and dict round trip; the arithmetic -- zero pad, strided polyphase FIR, trim -- runs in
+``resample_kernel`` (lhotse_amd/csrc/kernel_resample.hpp) through the C ABI (``hipfeat_resample``).
+
+    fn = HipSpeed(factor=1.1)                      # AudioTransform: numpy (C, T) -> numpy (C, T')
+    wave = fn(samples, 16000)
+    OnTheFlyFeatures(HipFbank(), wave_transforms=[...])      # unchanged; or, staying on the device:
+    ys = get_or_create_resampler(17600, 16000)(x_cuda)       # torch (..., T) -> (..., T') on the same device
+
+There is no CPU fallback: without a HIP device the call raises ``HipFeatError``.
+"""
+from __future__ import annotations
+
+import threading
+from dataclasses import asdict, dataclass
+from decimal import ROUND_HALF_DOWN, ROUND_HALF_UP, Decimal
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib, constants
+from .compat import HAVE_LHOTSE, Seconds
+
+if HAVE_LHOTSE:  # pragma: no cover - authoring container only
+    from lhotse.augmentation.transform import AudioTransform  # type: ignore
+else:
+
+    class AudioTransform:  # stand-in with the same surface (lhotse/augmentation/transform.py:9-76)
+        KNOWN_TRANSFORMS: Dict[str, type] = {}
+
+        def __init_subclass__(cls, **kwargs):
+            AudioTransform.KNOWN_TRANSFORMS.setdefault(cls.__name__, cls)
+            super().__init_subclass__(**kwargs)
+
+        def to_dict(self) -> dict:
+            return {"name": type(self).__name__, "kwargs": asdict(self)}
+
+        @staticmethod
+        def from_dict(data: dict) -> "AudioTransform":
+            assert data["name"] in AudioTransform.KNOWN_TRANSFORMS, f"Unknown transform type: {data['name']}"
+            return AudioTransform.KNOWN_TRANSFORMS[data["name"]](**data["kwargs"])
+
+
+def perturb_num_samples(num_samples: int, factor: float) -> int:
+    """Number of samples after speed perturbation (lhotse/utils.py:649-654)."""
+    rounding = ROUND_HALF_UP if factor >= 1.0 else ROUND_HALF_DOWN
+    return int(Decimal(round(num_samples / factor, ndigits=8)).quantize(0, rounding=rounding))
+
+
+def _compute_num_samples(duration: Seconds, sampling_rate: int) -> int:
+    """lhotse/utils.py:657-673"""
+    return int(Decimal(round(duration * sampling_rate, ndigits=8)).quantize(0, rounding=ROUND_HALF_UP))
+
+
+class HipResampleTensor:
+    """Device counterpart of the ``Resample`` nn.Module (lhotse/augmentation/resample.py:42-142): the filter
+    bank lives in HBM; calling it resamples every row of a ``(..., T)`` float32 tensor."""
+
+    def __init__(self, orig_freq: int = 16000, new_freq: int = 16000, lowpass_filter_width: int = 6, rolloff: float = 0.99,
+                 device: Union[str, torch.device, None] = None):
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+        self.lowpass_filter_width, self.rolloff = lowpass_filter_width, rolloff
+        self.kernel, self.width, self.orig, self.new = constants.sinc_resample_kernel(orig_freq, new_freq, lowpass_filter_width, rolloff)
+        self.lib = _lib.load()
+        self.handle = 0
+        dev = torch.device("cuda" if device is None else device)
+        if dev.type != "cuda":
+            raise _lib.HipFeatError(1, f"HipResampleTensor runs on an AMD GPU ('cuda[:i]' device), got device={dev}")
+        if not torch.cuda.is_available():
+            raise _lib.HipFeatError(2, "no HIP device is visible (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if dev.index is None else dev.index)
+        out = np.zeros(1, dtype=np.uint64)
+        self.lib.check("hipfeat_resampler_create", self.orig, self.new, self.width, _lib.addr(self.kernel), int(self.device.index), _lib.addr(out))
+        self.handle = int(out[0])
+
+    # ---- lengths -------------------------------------------------------------------------------------------
+    def output_length(self, num_samples: int) -> int:
+        if self.orig == self.new:
+            return int(num_samples)
+        return int(self.lib.raw("hipfeat_resampled_length", int(num_samples), self.orig, self.new))
+
+    # ---- packed ragged batch, device resident ---------------------------------------------------------------
+    def run(self, wave: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray) -> Tuple[torch.Tensor, np.ndarray, np.ndarray]:
+        """wave: contiguous float32 on self.device holding every cut; -> (packed output, out_offsets, out_lengths)."""
+        assert wave.dtype == torch.float32 and wave.is_contiguous() and wave.device == self.device
+        offsets, lengths = _lib.i64(offsets), _lib.i64(lengths)
+        out_lens = np.array([self.output_length(int(n)) for n in lengths], dtype=np.int64)
+        out_offs = np.zeros(len(lengths), dtype=np.int64)
+        np.cumsum(out_lens[:-1], out=out_offs[1:])
+        with torch.cuda.device(self.device):
+            out = torch.empty(int(out_lens.sum()), dtype=torch.float32, device=self.device)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.lib.check("hipfeat_resample", self.handle, wave.data_ptr(), _lib.addr(offsets), _lib.addr(lengths), int(len(lengths)),
+                           out.data_ptr(), _lib.addr(out_offs), int(stream))
+        return out, out_offs, out_lens
+
+    def resample_batch(self, waves: Sequence[Union[np.ndarray, torch.Tensor]]) -> List[torch.Tensor]:
+        """Ragged batch of 1-D waveforms (host or device) -> list of resampled device tensors (one launch)."""
+        ts = [torch.as_tensor(w).reshape(-1) for w in waves]
+        for t in ts:
+            if t.dtype != torch.float32:
+                raise TypeError(f"expected float32 samples, got {t.dtype}")
+        lengths = np.array([t.numel() for t in ts], dtype=np.int64)
+        offsets = np.zeros(len(ts), dtype=np.int64)
+        np.cumsum(lengths[:-1], out=offsets[1:])
+        if not ts:
+            return []
+        wave = torch.cat([t.to(self.device, non_blocking=True) for t in ts]) if len(ts) > 1 else ts[0].to(self.device).contiguous()
+        if self.orig == self.new:
+            return list(wave.split(lengths.tolist()))
+        out, _, out_lens = self.run(wave, offsets, lengths)
+        return list(out.split(out_lens.tolist()))
+
+    def __call__(self, waveform: torch.Tensor) -> torch.Tensor:
+        """(..., T) -> (..., T'), result on the input's device (resample.py:126-142)."""
+        if not isinstance(waveform, torch.Tensor):
+            raise TypeError("expected a torch.Tensor")
+        if self.orig_freq == self.new_freq:
+            return waveform
+        if waveform.dtype != torch.float32:
+            raise TypeError(f"expected float32 samples, got {waveform.dtype}")
+        shape = waveform.shape
+        T = int(shape[-1])
+        rows = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
+        x = waveform.reshape(rows, T).to(self.device).contiguous()
+        out, _, out_lens = self.run(x.view(-1), np.arange(rows, dtype=np.int64) * T, np.full(rows, T, dtype=np.int64))
+        y = out.view(shape[:-1] + (int(out_lens[0]) if rows else 0,))
+        return y if waveform.is_cuda else y.cpu()
+
+    forward = __call__
+
+    def close(self):
+        if self.handle:
+            try:
+                self.lib.raw("hipfeat_resampler_destroy", self.handle)
+            finally:
+                self.handle = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_precompiled_resamplers: Dict[Tuple[int, int, int], HipResampleTensor] = {}
+_cache_lock = threading.Lock()
+
+
+def get_or_create_resampler(source_sampling_rate: int, target_sampling_rate: int, device: Union[str, torch.device, None] = None) -> HipResampleTensor:
+    """lhotse/augmentation/torchaudio.py:72-83, keyed per device as well."""
+    dev = torch.device("cuda" if device is None else device)
+    index = dev.index if dev.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    key = (int(source_sampling_rate), int(target_sampling_rate), int(index))
+    with _cache_lock:
+        r = _precompiled_resamplers.get(key)
+        if r is None:
+            r = _precompiled_resamplers[key] = HipResampleTensor(key[0], key[1], device=torch.device(dev.type, index))
+        return r
+
+
+@dataclass
+class HipSpeed(AudioTransform):
+    """Speed perturbation (``sox speed``): resample from round(sr * factor) back to sr on the GPU.
+    Drop-in for ``lhotse.augmentation.Speed`` (torchaudio.py:26-68)."""
+
+    factor: float
+    device: str = "cuda"
+
+    def __call__(self, samples: Union[np.ndarray, torch.Tensor], sampling_rate: int) -> Union[np.ndarray, torch.Tensor]:
+        resampler = get_or_create_resampler(round(sampling_rate * self.factor), sampling_rate, self.device)
+        if isinstance(samples, torch.Tensor):  # device-resident use: stays a tensor on its device
+            return resampler(samples)
+        return resampler(torch.from_numpy(np.ascontiguousarray(samples))).numpy()
+
+    def reverse_timestamps(self, offset: Seconds, duration: Optional[Seconds], sampling_rate: int) -> Tuple[Seconds, Optional[Seconds]]:
+        """Offset/duration of the original audio that yields the requested perturbed span (torchaudio.py:44-68)."""
+        start_sample = perturb_num_samples(_compute_num_samples(offset, sampling_rate), 1 / self.factor)
+        num_samples = None if duration is None else perturb_num_samples(_compute_num_samples(duration, sampling_rate), 1 / self.factor)
+        return start_sample / sampling_rate, None if num_samples is None else num_samples / sampling_rate
+
+
+@dataclass
+class HipResample(AudioTransform):
+    """Sampling-rate conversion (``sox rate``) on the GPU; drop-in for ``lhotse.augmentation.Resample``
+    (torchaudio.py:86-164) with the sinc backend."""
+
+    source_sampling_rate: int
+    target_sampling_rate: int
+    device: str = "cuda"
+
+    def __post_init__(self):
+        self.source_sampling_rate = int(self.source_sampling_rate)
+        self.target_sampling_rate = int(self.target_sampling_rate)
+
+    @property
+    def resampler(self) -> HipResampleTensor:
+        return get_or_create_resampler(self.source_sampling_rate, self.target_sampling_rate, self.device)
+
+    def __call__(self, samples: Union[np.ndarray, torch.Tensor], *args, **kwargs) -> Union[np.ndarray, torch.Tensor]:
+        if self.source_sampling_rate == self.target_sampling_rate:
+            return samples
+        if isinstance(samples, torch.Tensor):
+            return self.resampler(samples)
+        return self.resampler(torch.from_numpy(np.ascontiguousarray(samples))).numpy()
+
+    def reverse_timestamps(self, offset: Seconds, duration: Optional[Seconds], sampling_rate: int) -> Tuple[Seconds, Optional[Seconds]]:
+        """Timestamps do not change with the sampling rate (torchaudio.py:142-164): whole-sample snapping only."""
+        if self.source_sampling_rate == self.target_sampling_rate:
+            return offset, duration
+        old_offset = _compute_num_samples(offset, self.source_sampling_rate) / self.source_sampling_rate
+        old_duration = None if duration is None else _compute_num_samples(duration, self.source_sampling_rate) / self.source_sampling_rate
+        return old_offset, old_duration

@@ -121,3 +121,29 @@ def make_lifter(num_ceps: int, q: int) -> np.ndarray:
         return np.ones(num_ceps, dtype=np.float32)
     v = 1 + 0.5 * q * torch.sin(math.pi * torch.arange(num_ceps, dtype=torch.float32) / q)
     return np.ascontiguousarray(v.numpy(), dtype=np.float32)
+
+
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> Tuple[np.ndarray, int, int, int]:
+    """Filter bank of the polyphase sinc resampler: (kernel[new][2*width + orig] float32, width, orig, new)
+    with orig/new divided by their gcd -- lhotse/augmentation/resample.py:184-281 (hann-windowed sinc,
+    evaluated in float64 and stored as float32 like the reference's cached buffer).  Evaluated with torch so
+    the transcendental kernels (and therefore the bits) are the reference's."""
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq <= 0 or new_freq <= 0:
+        raise ValueError("Frequencies must be positive integers")
+    if lowpass_filter_width <= 0:
+        raise ValueError("Low pass filter width should be positive.")
+    g = math.gcd(orig_freq, new_freq)
+    orig, new = orig_freq // g, new_freq // g
+    base_freq = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base_freq)
+    taps = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    # the phase offsets are float32 in the reference (arange without dtype, :249-253) and promoted by the sum
+    t = torch.arange(0, -new, -1)[:, None, None] / new + taps
+    t = (t * base_freq).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    scale = base_freq / orig
+    k = torch.where(t == 0, torch.tensor(1.0).to(t), t.sin() / t)
+    k = k * window * scale
+    return np.ascontiguousarray(k.to(torch.float32).reshape(new, 2 * width + orig).numpy()), width, orig, new

@@ -17,6 +17,7 @@
 #include "kernel_generic.hpp"
 #include "kernel_fft512.hpp"
 #include "kernel_fft512b.hpp"
+#include "kernel_resample.hpp"
 
 using namespace hipfeat;
 
@@ -813,6 +814,136 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_extract_host(const hipfeat_plan* p
   if (st != HIPFEAT_OK) return st;
   if (out_elems) HIP_TRY(hipMemcpyAsync(h_out, dout, (size_t)out_elems * sizeof(float), hipMemcpyDeviceToHost, st_));
   HIP_TRY(hipStreamSynchronize(st_));
+  return HIPFEAT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// resampler (speed perturbation)
+// --------------------------------------------------------------------------------------
+struct hipfeat_resampler {
+  int device = 0, orig = 0, nw = 0, kw = 0, width = 0;
+  float* d_kernel = nullptr;
+  int outs_per_block = 2048, span_floats = 0, kernel_in_lds = 0;
+  size_t lds_bytes = 0;
+  mutable std::mutex mu;
+  mutable StagingSlot slots[4];
+  mutable int next_slot = 0;
+};
+
+extern "C" HIPFEAT_API int64_t hipfeat_resampled_length(int64_t num_samples, int32_t orig_freq, int32_t new_freq) {
+  if (orig_freq <= 0 || new_freq <= 0 || num_samples < 0) return 0;
+  // torch.ceil(torch.as_tensor(new * length / orig)): the quotient is a Python float stored as float32
+  const float q = (float)((double)new_freq * (double)num_samples / (double)orig_freq);
+  return (int64_t)std::ceil(q);
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_resampler_create(int32_t orig_freq, int32_t new_freq, int32_t width,
+                                                               const float* h_kernel, int32_t device, hipfeat_resampler** out) {
+  if (!out || !h_kernel) return fail(HIPFEAT_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (orig_freq <= 0 || new_freq <= 0 || width <= 0) return fail(HIPFEAT_ERR_INVALID, "bad resampler geometry");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return fail(HIPFEAT_ERR_HIP, "device %d not available (%d HIP devices visible)", device, ndev);
+  hipfeat_resampler* r = new (std::nothrow) hipfeat_resampler();
+  if (!r) return fail(HIPFEAT_ERR_INVALID, "out of host memory");
+  r->device = device;
+  r->orig = orig_freq;
+  r->nw = new_freq;
+  r->width = width;
+  r->kw = 2 * width + orig_freq;
+  DeviceGuard g(device);
+  hipfeat_status st = upload(&r->d_kernel, h_kernel, (size_t)r->nw * r->kw);
+  if (st != HIPFEAT_OK) {
+    delete r;
+    return st;
+  }
+  r->kernel_in_lds = ((size_t)r->nw * r->kw <= 8192) ? 1 : 0;
+  for (r->outs_per_block = 2048; r->outs_per_block >= 64; r->outs_per_block >>= 1) {
+    r->span_floats = (((r->outs_per_block + r->nw - 1) / r->nw + 1) * r->orig + r->kw + 3) & ~3;
+    r->lds_bytes = ((size_t)r->span_floats + (r->kernel_in_lds ? (size_t)r->nw * r->kw : 0)) * sizeof(float);
+    if (r->lds_bytes <= 64 * 1024) break;
+  }
+  if (r->outs_per_block < 64) {
+    (void)hipFree(r->d_kernel);
+    delete r;
+    return fail(HIPFEAT_ERR_UNSUPPORTED, "resampling ratio %d/%d needs too much LDS", orig_freq, new_freq);
+  }
+  *out = r;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_resampler_destroy(hipfeat_resampler* r) {
+  if (!r) return HIPFEAT_OK;
+  DeviceGuard g(r->device);
+  (void)hipFree(r->d_kernel);
+  for (auto& s : r->slots) {
+    if (s.h) (void)hipHostFree(s.h);
+    if (s.d) (void)hipFree(s.d);
+    if (s.ev) (void)hipEventDestroy(s.ev);
+  }
+  delete r;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_resample(const hipfeat_resampler* r, const float* d_in, const int64_t* h_in_offsets,
+                                                       const int64_t* h_num_samples, int64_t batch, float* d_out,
+                                                       const int64_t* h_out_offsets, void* stream) {
+  if (!r) return fail(HIPFEAT_ERR_INVALID, "resampler is NULL");
+  if (batch < 0 || (batch > 0 && (!h_in_offsets || !h_num_samples || !h_out_offsets || !d_in || !d_out)))
+    return fail(HIPFEAT_ERR_INVALID, "bad batch arguments");
+  std::vector<ResCut> cuts((size_t)batch);
+  int64_t blocks = 0;
+  for (int64_t b = 0; b < batch; ++b) {
+    const int64_t L = h_num_samples[b];
+    if (L < 0 || L > INT32_MAX / 2) return fail(HIPFEAT_ERR_INVALID, "cut %lld: %lld samples out of range", (long long)b, (long long)L);
+    const int64_t ol = hipfeat_resampled_length(L, r->orig, r->nw);
+    if (ol > INT32_MAX) return fail(HIPFEAT_ERR_INVALID, "cut %lld: output too long", (long long)b);
+    cuts[(size_t)b] = ResCut{h_in_offsets[b], h_out_offsets[b], (int32_t)L, (int32_t)ol, (int32_t)blocks, 0};
+    blocks += (ol + r->outs_per_block - 1) / r->outs_per_block;
+    if (blocks > INT32_MAX - (1 << 24)) return fail(HIPFEAT_ERR_INVALID, "batch too large for one launch");
+  }
+  if (blocks == 0) return HIPFEAT_OK;
+  DeviceGuard g(r->device);
+  const size_t bytes = cuts.size() * sizeof(ResCut);
+  std::lock_guard<std::mutex> lk(r->mu);
+  StagingSlot& s = r->slots[r->next_slot];
+  r->next_slot = (r->next_slot + 1) % 4;
+  if (s.busy) {
+    HIP_TRY(hipEventSynchronize(s.ev));
+    s.busy = false;
+  }
+  if (!s.ev) HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  if (s.cap < bytes) {
+    if (s.h) (void)hipHostFree(s.h);
+    if (s.d) (void)hipFree(s.d);
+    s.h = s.d = nullptr;
+    s.cap = 0;
+    const size_t cap = std::max<size_t>(bytes * 2, 1 << 16);
+    HIP_TRY(hipHostMalloc(&s.h, cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&s.d, cap));
+    s.cap = cap;
+  }
+  std::memcpy(s.h, cuts.data(), bytes);
+  HIP_TRY(hipMemcpyAsync(s.d, s.h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  ResampleParams rp{};
+  rp.in = d_in;
+  rp.out = d_out;
+  rp.cuts = static_cast<const ResCut*>(s.d);
+  rp.kernel = r->d_kernel;
+  rp.num_cuts = (int32_t)batch;
+  rp.orig = r->orig;
+  rp.nw = r->nw;
+  rp.kw = r->kw;
+  rp.width = r->width;
+  rp.outs_per_block = r->outs_per_block;
+  rp.span_floats = r->span_floats;
+  rp.kernel_in_lds = r->kernel_in_lds;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), r->lds_bytes, (hipStream_t)stream, rp);
+  hipError_t e1 = hipGetLastError();
+  hipError_t e2 = hipEventRecord(s.ev, (hipStream_t)stream);
+  s.busy = (e2 == hipSuccess);
+  if (e1 != hipSuccess) return fail(HIPFEAT_ERR_HIP, "resample launch failed: %s", hipGetErrorName(e1));
   return HIPFEAT_OK;
 }
 

@@ -1,0 +1,72 @@
+// Polyphase sinc resampler (speed perturbation), SURVEY.md section 8f row 1.
+//
+// Reference: ResampleTensor = _get_sinc_resample_kernel + _apply_sinc_resample_kernel
+// (lhotse/augmentation/resample.py:184-315), reached from Speed.__call__ (lhotse/augmentation/torchaudio.py:37-42).
+// The reference zero-pads the waveform by (width, width + orig) and runs conv1d(stride = orig) with `new` filters
+// of 2*width + orig taps:  y[j*new + ph] = sum_i xpad[j*orig + i] * K[ph][i].
+//
+// Here: one workgroup = `outs_per_block` consecutive output samples of one cut.  The input span those outputs
+// touch is staged in LDS once (coalesced, zero outside the cut), the filter bank too when it is small (speed
+// factors 0.9 / 1.1 give 10 x 23 / 10 x 25 taps); each lane then accumulates one output at a time as an
+// ascending-tap fmaf chain and stores it coalesced.
+#pragma once
+#include "common.hpp"
+
+namespace hipfeat {
+
+struct ResCut {
+  int64_t in_off, out_off;
+  int32_t in_len, out_len;
+  int32_t first_block, pad;
+};
+
+struct ResampleParams {
+  const float* in;
+  float* out;
+  const ResCut* cuts;
+  const float* kernel;  // [nw][kw]
+  int32_t num_cuts, orig, nw, kw, width, outs_per_block, span_floats, kernel_in_lds;
+};
+
+__device__ __forceinline__ int find_res_cut(const ResCut* __restrict__ cuts, int num_cuts, int blk) {
+  int lo = 0, hi = num_cuts - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (cuts[mid].first_block <= blk) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void resample_kernel(const ResampleParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                  // [span_floats]
+  float* kl = smem + p.span_floats;  // [nw * kw] when kernel_in_lds
+  const int tid = threadIdx.x;
+  const int cut = find_res_cut(p.cuts, p.num_cuts, blockIdx.x);
+  const ResCut cd = p.cuts[cut];
+  const int o0 = (blockIdx.x - cd.first_block) * p.outs_per_block;
+  const int o1 = min(o0 + p.outs_per_block, cd.out_len);
+  const int j0 = o0 / p.nw, j1 = (o1 - 1) / p.nw;
+  const int span = (j1 - j0) * p.orig + p.kw;
+  const int64_t x0 = (int64_t)j0 * p.orig - p.width;  // input index of xs[0]
+  const float* __restrict__ x = p.in + cd.in_off;
+  for (int i = tid; i < span; i += 256) {
+    const int64_t s = x0 + i;
+    xs[i] = (s >= 0 && s < cd.in_len) ? x[s] : 0.0f;
+  }
+  if (p.kernel_in_lds)
+    for (int i = tid; i < p.nw * p.kw; i += 256) kl[i] = p.kernel[i];
+  __syncthreads();
+  const float* __restrict__ kt = p.kernel_in_lds ? kl : p.kernel;
+  float* __restrict__ y = p.out + cd.out_off;
+  for (int o = o0 + tid; o < o1; o += 256) {
+    const int j = o / p.nw, ph = o - j * p.nw;
+    const float* xr = xs + (j - j0) * p.orig;
+    const float* kr = kt + ph * p.kw;
+    float acc = 0.f;
+    for (int i = 0; i < p.kw; ++i) acc = fmaf(xr[i], kr[i], acc);
+    y[o] = acc;
+  }
+}
+
+}  // namespace hipfeat
