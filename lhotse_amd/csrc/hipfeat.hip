@@ -825,10 +825,28 @@ struct hipfeat_resampler {
   float* d_kernel = nullptr;
   int outs_per_block = 2048, span_floats = 0, kernel_in_lds = 0;
   size_t lds_bytes = 0;
+  // fast path (compile-time ratio): transposed bank [kw][newp] + launcher
+  float* d_kernel_t = nullptr;
+  void (*fast)(const float*, float*, const ResCut*, const float*, int, unsigned, hipStream_t) = nullptr;
+  int fast_outs = 0;
   mutable std::mutex mu;
   mutable StagingSlot slots[4];
   mutable int next_slot = 0;
 };
+
+template <int ORIG, int NEW, int WIDTH>
+static void launch_resample_fast(const float* in, float* out, const ResCut* cuts, const float* kt, int num_cuts, unsigned blocks,
+                                 hipStream_t stream) {
+  hipLaunchKernelGGL((resample_fast_kernel<ORIG, NEW, WIDTH>), dim3(blocks), dim3(256), 0, stream, in, out, cuts, kt, num_cuts);
+}
+
+template <int ORIG, int NEW, int WIDTH>
+static bool pick_resample_fast(hipfeat_resampler* r) {
+  if (r->orig != ORIG || r->nw != NEW || r->width != WIDTH) return false;
+  r->fast = &launch_resample_fast<ORIG, NEW, WIDTH>;
+  r->fast_outs = ResampleFast<ORIG, NEW, WIDTH>::OUTS;
+  return true;
+}
 
 extern "C" HIPFEAT_API int64_t hipfeat_resampled_length(int64_t num_samples, int32_t orig_freq, int32_t new_freq) {
   if (orig_freq <= 0 || new_freq <= 0 || num_samples < 0) return 0;
@@ -858,6 +876,23 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_resampler_create(int32_t orig_freq
     delete r;
     return st;
   }
+  // speed 0.9 / 1.1 / 0.95 / 1.05 at any rate, and the 1:2, 2:1, 3:1 rate conversions
+  const bool fast = !getenv("HIPFEAT_RESAMPLE_GENERIC") &&
+                    (pick_resample_fast<9, 10, 7>(r) || pick_resample_fast<11, 10, 7>(r) || pick_resample_fast<19, 20, 7>(r) ||
+                     pick_resample_fast<21, 20, 7>(r) || pick_resample_fast<1, 2, 7>(r) || pick_resample_fast<2, 1, 13>(r) ||
+                     pick_resample_fast<3, 1, 19>(r));
+  if (fast) {
+    const int newp = (r->nw + 3) & ~3;
+    std::vector<float> kt((size_t)r->kw * newp, 0.f);
+    for (int ph = 0; ph < r->nw; ++ph)
+      for (int i = 0; i < r->kw; ++i) kt[(size_t)i * newp + ph] = h_kernel[(size_t)ph * r->kw + i];
+    st = upload(&r->d_kernel_t, kt.data(), kt.size());
+    if (st != HIPFEAT_OK) {
+      (void)hipFree(r->d_kernel);
+      delete r;
+      return st;
+    }
+  }
   r->kernel_in_lds = ((size_t)r->nw * r->kw <= 8192) ? 1 : 0;
   for (r->outs_per_block = 2048; r->outs_per_block >= 64; r->outs_per_block >>= 1) {
     r->span_floats = (((r->outs_per_block + r->nw - 1) / r->nw + 1) * r->orig + r->kw + 3) & ~3;
@@ -877,6 +912,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_resampler_destroy(hipfeat_resample
   if (!r) return HIPFEAT_OK;
   DeviceGuard g(r->device);
   (void)hipFree(r->d_kernel);
+  if (r->d_kernel_t) (void)hipFree(r->d_kernel_t);
   for (auto& s : r->slots) {
     if (s.h) (void)hipHostFree(s.h);
     if (s.d) (void)hipFree(s.d);
@@ -894,13 +930,14 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_resample(const hipfeat_resampler* 
     return fail(HIPFEAT_ERR_INVALID, "bad batch arguments");
   std::vector<ResCut> cuts((size_t)batch);
   int64_t blocks = 0;
+  const int64_t opb = r->fast ? r->fast_outs : r->outs_per_block;
   for (int64_t b = 0; b < batch; ++b) {
     const int64_t L = h_num_samples[b];
     if (L < 0 || L > INT32_MAX / 2) return fail(HIPFEAT_ERR_INVALID, "cut %lld: %lld samples out of range", (long long)b, (long long)L);
     const int64_t ol = hipfeat_resampled_length(L, r->orig, r->nw);
     if (ol > INT32_MAX) return fail(HIPFEAT_ERR_INVALID, "cut %lld: output too long", (long long)b);
     cuts[(size_t)b] = ResCut{h_in_offsets[b], h_out_offsets[b], (int32_t)L, (int32_t)ol, (int32_t)blocks, 0};
-    blocks += (ol + r->outs_per_block - 1) / r->outs_per_block;
+    blocks += (ol + opb - 1) / opb;
     if (blocks > INT32_MAX - (1 << 24)) return fail(HIPFEAT_ERR_INVALID, "batch too large for one launch");
   }
   if (blocks == 0) return HIPFEAT_OK;
@@ -926,6 +963,14 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_resample(const hipfeat_resampler* 
   }
   std::memcpy(s.h, cuts.data(), bytes);
   HIP_TRY(hipMemcpyAsync(s.d, s.h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  if (r->fast) {
+    r->fast(d_in, d_out, static_cast<const ResCut*>(s.d), r->d_kernel_t, (int)batch, (unsigned)blocks, (hipStream_t)stream);
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipEventRecord(s.ev, (hipStream_t)stream);
+    s.busy = (e2 == hipSuccess);
+    if (e1 != hipSuccess) return fail(HIPFEAT_ERR_HIP, "resample launch failed: %s", hipGetErrorName(e1));
+    return HIPFEAT_OK;
+  }
   ResampleParams rp{};
   rp.in = d_in;
   rp.out = d_out;

@@ -69,4 +69,64 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleParams p) {
   }
 }
 
+// --------------------------------------------------------------------------------------
+// Fast path for the ratios speed perturbation actually uses (compile-time ORIG / NEW / WIDTH).
+//
+// One lane = one input hop j (ORIG input samples -> NEW output samples): it reads its KW = 2*WIDTH + ORIG taps of
+// x from LDS once and feeds NEW independent accumulators, so one LDS read serves NEW FMAs.  The filter bank is
+// wave-uniform: it is read through the scalar cache (`kt` = transposed bank [KW][NEWP], one row per tap) and the
+// FMAs take it as an SGPR operand -- no LDS or VGPR traffic for coefficients.  Per accumulator the order is the
+// same ascending-tap fmaf chain as the generic kernel (results are bit-identical between the two).
+// The NEW results per lane are transposed through LDS (re-using the input span) so the stores are coalesced.
+// --------------------------------------------------------------------------------------
+template <int ORIG, int NEW, int WIDTH>
+struct ResampleFast {
+  static constexpr int KW = 2 * WIDTH + ORIG;
+  static constexpr int NEWP = (NEW + 3) & ~3;       // row pitch of the transposed bank
+  static constexpr int HOPS = 256;                  // hops per block (one per lane)
+  static constexpr int SPAN = HOPS * ORIG + KW - ORIG;  // input samples the block touches
+  static constexpr int OUTS = HOPS * NEW;
+  static constexpr int LDS_FLOATS = SPAN > OUTS ? SPAN : OUTS;
+};
+
+template <int ORIG, int NEW, int WIDTH>
+__global__ __launch_bounds__(256) void resample_fast_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            const ResCut* __restrict__ cuts, const float* __restrict__ kt,
+                                                            int num_cuts) {
+  using G = ResampleFast<ORIG, NEW, WIDTH>;
+  __shared__ float xs[G::LDS_FLOATS];
+  const int tid = threadIdx.x;
+  const int cut = find_res_cut(cuts, num_cuts, blockIdx.x);
+  const ResCut cd = cuts[cut];
+  const int j0 = (blockIdx.x - cd.first_block) * G::HOPS;
+  const int64_t x0 = (int64_t)j0 * ORIG - WIDTH;
+  const float* __restrict__ x = in + cd.in_off;
+#pragma unroll
+  for (int i = tid; i < G::SPAN; i += 256) {
+    const int64_t s = x0 + i;
+    xs[i] = (s >= 0 && s < cd.in_len) ? x[s] : 0.0f;
+  }
+  __syncthreads();
+  float acc[NEW];
+#pragma unroll
+  for (int ph = 0; ph < NEW; ++ph) acc[ph] = 0.f;
+  const float* xr = xs + tid * ORIG;
+#pragma unroll
+  for (int i = 0; i < G::KW; ++i) {
+    const float xv = xr[i];
+#pragma unroll
+    for (int ph = 0; ph < NEW; ++ph) acc[ph] = fmaf(xv, kt[i * G::NEWP + ph], acc[ph]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ph = 0; ph < NEW; ++ph) xs[tid * NEW + ph] = acc[ph];
+  __syncthreads();
+  const int o0 = j0 * NEW;
+  const int n = min(G::OUTS, cd.out_len - o0);
+  float* __restrict__ y = out + cd.out_off + o0;
+#pragma unroll
+  for (int i = tid; i < G::OUTS; i += 256)
+    if (i < n) y[i] = xs[i];
+}
+
 }  // namespace hipfeat

@@ -129,3 +129,15 @@ def test_c_abi_errors_and_empty_batch():
     assert lib.raw("hipfeat_resample", r.handle, x.data_ptr(), _lib.addr(offs), _lib.addr(lens), 1, x.data_ptr(), _lib.addr(offs), None) == _lib.ERR_INVALID
     assert lib.raw("hipfeat_resampler_destroy", 0) == 0
     assert r.resample_batch([]) == []
+
+
+@pytest.mark.parametrize("orig,new", [(14400, 16000), (17600, 16000), (15200, 16000), (16800, 16000), (8000, 16000), (32000, 16000), (48000, 16000)])
+def test_fast_and_generic_kernels_are_bit_identical(orig, new, monkeypatch):
+    rng = np.random.RandomState(3)
+    xs = [(rng.rand(n).astype(np.float32) - 0.5) for n in (1, 5, 255, 256, 257, 2559, 2560, 2561, 100003, 0, 7)]
+    fast = A.HipResampleTensor(orig, new)
+    monkeypatch.setenv("HIPFEAT_RESAMPLE_GENERIC", "1")
+    generic = A.HipResampleTensor(orig, new)
+    monkeypatch.delenv("HIPFEAT_RESAMPLE_GENERIC")
+    for a, b in zip(fast.resample_batch(xs), generic.resample_batch(xs)):
+        assert a.shape == b.shape and torch.equal(a, b)
