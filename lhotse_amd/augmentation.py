@@ -85,12 +85,19 @@ class HipResampleTensor:
             return int(num_samples)
         return int(self.lib.raw("hipfeat_resampled_length", int(num_samples), self.orig, self.new))
 
+    def output_lengths(self, num_samples: np.ndarray) -> np.ndarray:
+        """Vectorised ``output_length`` (same float32 rounding, resample.py:309)."""
+        n = _lib.i64(num_samples)
+        if self.orig == self.new:
+            return n
+        return np.ceil((self.new * n / self.orig).astype(np.float32)).astype(np.int64)
+
     # ---- packed ragged batch, device resident ---------------------------------------------------------------
     def run(self, wave: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray) -> Tuple[torch.Tensor, np.ndarray, np.ndarray]:
         """wave: contiguous float32 on self.device holding every cut; -> (packed output, out_offsets, out_lengths)."""
         assert wave.dtype == torch.float32 and wave.is_contiguous() and wave.device == self.device
         offsets, lengths = _lib.i64(offsets), _lib.i64(lengths)
-        out_lens = np.array([self.output_length(int(n)) for n in lengths], dtype=np.int64)
+        out_lens = self.output_lengths(lengths)
         out_offs = np.zeros(len(lengths), dtype=np.int64)
         np.cumsum(out_lens[:-1], out=out_offs[1:])
         with torch.cuda.device(self.device):

@@ -99,12 +99,19 @@ __global__ __launch_bounds__(256) void resample_fast_kernel(const float* __restr
   const int cut = find_res_cut(cuts, num_cuts, blockIdx.x);
   const ResCut cd = cuts[cut];
   const int j0 = (blockIdx.x - cd.first_block) * G::HOPS;
-  const int64_t x0 = (int64_t)j0 * ORIG - WIDTH;
+  const int x0 = j0 * ORIG - WIDTH;  // j0 * ORIG <= in_len + ORIG < 2^31
   const float* __restrict__ x = in + cd.in_off;
+  {
+    constexpr int N = (G::SPAN + 255) / 256;
+    float v[N];
 #pragma unroll
-  for (int i = tid; i < G::SPAN; i += 256) {
-    const int64_t s = x0 + i;
-    xs[i] = (s >= 0 && s < cd.in_len) ? x[s] : 0.0f;
+    for (int k = 0; k < N; ++k) {  // all loads in flight before the first LDS write
+      const int s = x0 + tid + 256 * k;
+      v[k] = ((unsigned)s < (unsigned)cd.in_len) ? x[s] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (tid + 256 * k < G::SPAN) xs[tid + 256 * k] = v[k];
   }
   __syncthreads();
   float acc[NEW];
@@ -125,8 +132,8 @@ __global__ __launch_bounds__(256) void resample_fast_kernel(const float* __restr
   const int n = min(G::OUTS, cd.out_len - o0);
   float* __restrict__ y = out + cd.out_off + o0;
 #pragma unroll
-  for (int i = tid; i < G::OUTS; i += 256)
-    if (i < n) y[i] = xs[i];
+  for (int k = 0; k < NEW; ++k)
+    if (tid + 256 * k < n) y[tid + 256 * k] = xs[tid + 256 * k];
 }
 
 }  // namespace hipfeat

@@ -51,7 +51,7 @@ def test_ragged_device_batch_against_oracle_float64(orig, new):
 
 def test_tensor_call_shapes_devices_and_channels():
     r = A.get_or_create_resampler(17600, 16000)
-    x = torch.from_numpy(np.stack([make_signal("noise", 30000, s) for s in range(3)]))
+    x = torch.from_numpy(np.stack([make_signal("gauss", 30000, s) for s in range(3)]))
     y = r(x)  # cpu in -> cpu out, (C, T) -> (C, T')
     assert not y.is_cuda and y.shape == (3, R.resampled_length(30000, 11, 10))
     for c in range(3):

@@ -38,6 +38,18 @@ def test_resampled_length_in_the_library_follows_the_reference_float32_rounding(
     assert lib.raw("hipfeat_resampled_length", 100, 0, 5) == 0
 
 
+def test_vectorised_output_lengths_equal_the_library(monkeypatch):
+    rng = np.random.RandomState(1)
+    lens = np.concatenate([np.arange(0, 300), rng.randint(1, 1 << 25, size=3000)]).astype(np.int64)
+    lib = _lib.load()
+    for orig, new in [(9, 10), (11, 10), (441, 160), (1, 2)]:
+        r = A.HipResampleTensor.__new__(A.HipResampleTensor)  # lengths need no device
+        r.orig, r.new, r.lib, r.handle = orig, new, lib, 0
+        want = np.array([lib.raw("hipfeat_resampled_length", int(n), orig, new) for n in lens])
+        assert np.array_equal(r.output_lengths(lens), want)
+        assert r.output_length(12345) == lib.raw("hipfeat_resampled_length", 12345, orig, new)
+
+
 def test_transform_dict_round_trip_and_registry():
     sp = A.HipSpeed(factor=1.1)
     d = sp.to_dict()
