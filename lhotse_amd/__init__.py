@@ -15,7 +15,13 @@ from .extractors import (  # noqa: F401
     HipSpectrogramConfig,
 )
 
+from .augmentation import HipResample, HipResampleTensor, HipSpeed, get_or_create_resampler  # noqa: F401,E402
+
 __all__ = [
+    "HipSpeed",
+    "HipResample",
+    "HipResampleTensor",
+    "get_or_create_resampler",
     "HipFbank",
     "HipFbankConfig",
     "HipMfcc",

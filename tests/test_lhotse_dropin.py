@@ -34,8 +34,11 @@ def lhotse_mod():
         import lhotse_amd
         import lhotse_amd.extractors as ex
 
+        import lhotse_amd.augmentation as aug
+
         importlib.reload(compat)
         importlib.reload(ex)
+        importlib.reload(aug)
         importlib.reload(lhotse_amd)
     return lhotse
 
@@ -194,3 +197,40 @@ def test_per_cut_driver_and_on_the_fly(tmp_path, cutset, cpu_device):
         np.testing.assert_allclose(feats[i, :t].numpy(), per_cut[c.id], atol=1e-5)  # per-item reflect == extract()
         if t < feats.shape[1]:
             assert torch.all(feats[i, t:] == LOG_EPSILON)
+
+
+def test_speed_perturbation_through_recording_transforms(cutset, lhotse_mod, monkeypatch):
+    """Recording.load_audio applies AudioTransforms lazily (lhotse/audio/recording.py:431-475): HipSpeed must be
+    accepted there (registry, reverse_timestamps, output length bookkeeping) and reproduce Speed's samples.
+    The device object (HipResampleTensor) is replaced by an oracle-backed stand-in; GPU numerics are covered by
+    tests/test_gpu_resample.py."""
+    import lhotse_amd.augmentation as A
+    from lhotse.augmentation import AudioTransform, Speed
+    from lhotse.utils import fastcopy
+    from oracle import resample_ref as R
+
+    assert issubclass(A.HipSpeed, AudioTransform) and AudioTransform.KNOWN_TRANSFORMS["HipSpeed"] is A.HipSpeed
+
+    class CpuResampler:
+        def __init__(self, orig_freq, new_freq, device=None):
+            self.o, self.n = orig_freq, new_freq
+
+        def __call__(self, t):
+            return torch.from_numpy(np.stack([R.resample(row, self.o, self.n) for row in t.numpy().reshape(-1, t.shape[-1])]))
+
+    monkeypatch.setattr(A, "HipResampleTensor", CpuResampler)
+    monkeypatch.setattr(A, "_precompiled_resamplers", {})
+    for factor in (0.9, 1.1):
+        for cut in cutset:
+            sp = cut.perturb_speed(factor)
+            want = sp.load_audio()
+            assert isinstance(sp.recording.transforms[0], (Speed, dict))
+            hip_rec = fastcopy(sp.recording, transforms=[A.HipSpeed(factor).to_dict()])  # as read back from a manifest
+            hip = fastcopy(sp, recording=hip_rec)
+            got = hip.load_audio()
+            assert got.shape == want.shape == (1, sp.num_samples)
+            assert np.abs(got - want).max() <= 5e-6
+            # a sub-span of the perturbed cut goes through reverse_timestamps
+            part_w = sp.truncate(offset=0.25, duration=0.5).load_audio()
+            part_g = hip.truncate(offset=0.25, duration=0.5).load_audio()
+            assert part_g.shape == part_w.shape and np.abs(part_g - part_w).max() <= 5e-6
