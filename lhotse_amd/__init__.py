@@ -17,7 +17,22 @@ from .extractors import (  # noqa: F401
 
 from .augmentation import HipResample, HipResampleTensor, HipSpeed, get_or_create_resampler  # noqa: F401,E402
 
+from .kaldifeat import (  # noqa: F401,E402
+    HipKaldifeatFbank,
+    HipKaldifeatFbankConfig,
+    HipKaldifeatFrameOptions,
+    HipKaldifeatMelOptions,
+    HipKaldifeatMfcc,
+    HipKaldifeatMfccConfig,
+)
+
 __all__ = [
+    "HipKaldifeatFbank",
+    "HipKaldifeatFbankConfig",
+    "HipKaldifeatMfcc",
+    "HipKaldifeatMfccConfig",
+    "HipKaldifeatFrameOptions",
+    "HipKaldifeatMelOptions",
     "HipSpeed",
     "HipResample",
     "HipResampleTensor",

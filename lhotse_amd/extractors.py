@@ -186,7 +186,7 @@ class _Plan:
         self.device = torch.device("cuda", torch.cuda.current_device() if device.index is None else device.index)
         n, shift, fft = constants.frame_sizes(cfg.sampling_rate, cfg.frame_length, cfg.frame_shift, cfg.round_to_power_of_two)
         self.n, self.shift, self.fft = n, shift, fft
-        window = constants.make_window(n, cfg.window_type)
+        window = constants.make_window(n, cfg.window_type, getattr(cfg, "blackman_coeff", 0.42))
         mel = dct = lifter = None
         num_filters = num_ceps = 0
         apply_lifter = 0

@@ -39,6 +39,9 @@ def lhotse_mod():
         importlib.reload(compat)
         importlib.reload(ex)
         importlib.reload(aug)
+        import lhotse_amd.kaldifeat as kf
+
+        importlib.reload(kf)
         importlib.reload(lhotse_amd)
     return lhotse
 
@@ -234,3 +237,25 @@ def test_speed_perturbation_through_recording_transforms(cutset, lhotse_mod, mon
             part_w = sp.truncate(offset=0.25, duration=0.5).load_audio()
             part_g = hip.truncate(offset=0.25, duration=0.5).load_audio()
             assert part_g.shape == part_w.shape and np.abs(part_g - part_w).max() <= 5e-6
+
+
+def test_kaldifeat_shaped_configs_equal_the_reference_dict_layout(lhotse_mod):
+    """HipKaldifeat*Config must (de)serialise exactly like lhotse/features/kaldifeat.py:148-246 (device aside)."""
+    import lhotse_amd as LA
+    from lhotse.features.kaldifeat import KaldifeatFbankConfig, KaldifeatFrameOptions, KaldifeatMelOptions, KaldifeatMfccConfig
+
+    for ours, theirs in [(LA.HipKaldifeatFbankConfig(), KaldifeatFbankConfig()), (LA.HipKaldifeatMfccConfig(), KaldifeatMfccConfig())]:
+        a, b = ours.to_dict(), theirs.to_dict()
+        assert a.pop("device") == "cuda" and b.pop("device") == "cpu"
+        assert a == b
+        # a manifest written by the reference loads into ours and back
+        d = theirs.to_dict()
+        assert type(ours).from_dict(d).to_dict() == theirs.to_dict()
+    fo = KaldifeatFrameOptions(sampling_rate=8000, frame_shift=0.0125, snip_edges=True)
+    assert LA.HipKaldifeatFrameOptions.from_dict(fo.to_dict()).to_dict() == fo.to_dict()
+    mo = KaldifeatMelOptions(num_bins=64, high_freq=0.0)
+    assert LA.HipKaldifeatMelOptions.from_dict(mo.to_dict()).to_dict() == mo.to_dict()
+    from lhotse.features import FeatureExtractor
+
+    ex = FeatureExtractor.from_dict({**LA.HipKaldifeatFbankConfig().to_dict(), "feature_type": "hip-kaldifeat-fbank"})
+    assert isinstance(ex, LA.HipKaldifeatFbank)
