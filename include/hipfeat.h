@@ -166,6 +166,22 @@ HIPFEAT_API hipfeat_status hipfeat_extract_host(const hipfeat_plan* plan, const 
                                     void* stream);
 
 
+/* ---- "next" row: fused collation of the output, int16 PCM input ------------------- */
+/*
+ * hipfeat_extract + collate_matrices(features, padding_value) in one call
+ * (lhotse/dataset/input_strategies.py:458-462, lhotse/dataset/collation.py:506-535): d_out is a dense
+ * (batch, rows_per_cut, feature_dim) float32 tensor; cut b's frames go to d_out[b, :T_b] and the rows
+ * [T_b, rows_per_cut) are filled with pad_value (LOG_EPSILON in lhotse).  T_b is returned in h_num_frames
+ * (may be NULL).  Fails if some T_b > rows_per_cut.
+ */
+HIPFEAT_API hipfeat_status hipfeat_extract_collated(const hipfeat_plan* plan, const float* d_wave, const int64_t* h_wave_offsets,
+                                        const int64_t* h_num_samples, const int64_t* h_padded_len, int64_t batch,
+                                        float* d_out, int64_t rows_per_cut, float pad_value, int64_t* h_num_frames,
+                                        void* stream);
+/* int16 PCM -> float32 in [-1, 1): x / 32768, exactly what the audio backends hand to the reference
+ * (so features are bit-identical to the float32 path); lets the host send half the bytes over PCIe. */
+HIPFEAT_API hipfeat_status hipfeat_pcm16_to_float(const int16_t* d_pcm, float* d_wave, int64_t num_samples, void* stream);
+
 /* ---- "next" row: speed perturbation = polyphase sinc resampling --------------- */
 /*
  * Replaces ResampleTensor (lhotse/augmentation/resample.py:42-142, :284-315) as used by

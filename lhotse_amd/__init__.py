@@ -26,7 +26,10 @@ from .kaldifeat import (  # noqa: F401,E402
     HipKaldifeatMfccConfig,
 )
 
+from .input_strategies import HipOnTheFlyFeatures  # noqa: F401,E402
+
 __all__ = [
+    "HipOnTheFlyFeatures",
     "HipKaldifeatFbank",
     "HipKaldifeatFbankConfig",
     "HipKaldifeatMfcc",

@@ -48,6 +48,12 @@ _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
         "int",
         ["const hipfeat_plan*", "const float*", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "const int64_t*", "int64_t", "void*"],
     ),
+    "hipfeat_extract_collated": (
+        "int",
+        ["const hipfeat_plan*", "const float*", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "int64_t", "float",
+         "int64_t*", "void*"],
+    ),
+    "hipfeat_pcm16_to_float": ("int", ["const int16_t*", "float*", "int64_t", "void*"]),
     "hipfeat_resampler_create": ("int", ["int32_t", "int32_t", "int32_t", "const float*", "int32_t", "hipfeat_resampler**"]),
     "hipfeat_resampler_destroy": ("int", ["hipfeat_resampler*"]),
     "hipfeat_resampled_length": ("int64_t", ["int64_t", "int32_t", "int32_t"]),
@@ -105,7 +111,7 @@ def _is_ptr(ctype: str) -> bool:
 
 class _CtypesBackend:
     name = "ctypes"
-    _SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64}
+    _SCALARS = {"int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float}
 
     def __init__(self, path: str):
         self.dll = ctypes.CDLL(path)

@@ -23,6 +23,7 @@ import numpy as np
 
 Seconds = float
 EPSILON = 1e-10  # lhotse/utils.py:49
+LOG_EPSILON = -23.025850929940457  # math.log(EPSILON), lhotse/utils.py:50-51
 
 try:  # pragma: no cover - exercised in the authoring container only
     from lhotse.features.base import (  # type: ignore

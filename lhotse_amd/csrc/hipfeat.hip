@@ -722,18 +722,75 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_extract_layout(const hipfeat_plan*
   return launch(plan, layout, d_wave, d_out, (hipStream_t)stream);
 }
 
-extern "C" HIPFEAT_API hipfeat_status hipfeat_extract(const hipfeat_plan* plan, const float* d_wave, const int64_t* h_wave_offsets,
-                                          const int64_t* h_num_samples, const int64_t* h_padded_len, int64_t batch,
-                                          float* d_out, const int64_t* h_out_rows, int64_t out_row_stride, void* stream) {
+// fills rows [num_frames, rows_per_cut) of every cut's slot in a collated (B, rows_per_cut, F) output
+__global__ __launch_bounds__(256) void fill_padding_kernel(const CutDesc* __restrict__ cuts, float* __restrict__ out, int64_t row_stride,
+                                                           int32_t rows_per_cut, int32_t feature_dim, float value) {
+  const CutDesc cd = cuts[blockIdx.y];
+  const int64_t n = (int64_t)(rows_per_cut - cd.num_frames) * feature_dim;
+  float* __restrict__ base = out + (cd.out_row + cd.num_frames) * row_stride;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / feature_dim;
+    base[r * row_stride + (i - r * feature_dim)] = value;
+  }
+}
+
+__global__ __launch_bounds__(256) void pcm16_to_float_kernel(const int16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+  // 8 samples per lane per step: one 16-byte load, two 16-byte stores
+  const int64_t n8 = n >> 3;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  constexpr float k = 1.0f / 32768.0f;
+  if (aligned) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+      const int4 v = reinterpret_cast<const int4*>(in)[i];
+      const int w[4] = {v.x, v.y, v.z, v.w};
+      float4 a, b;
+      a.x = (float)(int16_t)(w[0] & 0xffff) * k; a.y = (float)(w[0] >> 16) * k;
+      a.z = (float)(int16_t)(w[1] & 0xffff) * k; a.w = (float)(w[1] >> 16) * k;
+      b.x = (float)(int16_t)(w[2] & 0xffff) * k; b.y = (float)(w[2] >> 16) * k;
+      b.z = (float)(int16_t)(w[3] & 0xffff) * k; b.w = (float)(w[3] >> 16) * k;
+      reinterpret_cast<float4*>(out)[2 * i] = a;
+      reinterpret_cast<float4*>(out)[2 * i + 1] = b;
+    }
+    for (int64_t i = (n8 << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)in[i] * k;
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (float)in[i] * k;
+  }
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_pcm16_to_float(const int16_t* d_pcm, float* d_wave, int64_t num_samples, void* stream) {
+  if (num_samples < 0 || (num_samples > 0 && (!d_pcm || !d_wave))) return fail(HIPFEAT_ERR_INVALID, "bad pcm16 arguments");
+  if (num_samples == 0) return HIPFEAT_OK;
+  const int64_t blocks = std::min<int64_t>((num_samples / 8 + 255) / 256 + 1, 256 * 32);
+  hipLaunchKernelGGL(pcm16_to_float_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_pcm, d_wave, num_samples);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "pcm16 launch failed: %s", hipGetErrorName(e));
+  return HIPFEAT_OK;
+}
+
+// transient layout: descriptors staged through a pinned ring slot so the call stays asynchronous
+static hipfeat_status extract_transient(const hipfeat_plan* plan, const float* d_wave, const int64_t* h_wave_offsets,
+                                        const int64_t* h_num_samples, const int64_t* h_padded_len, int64_t batch, float* d_out,
+                                        const int64_t* h_out_rows, int64_t out_row_stride, void* stream, int64_t rows_per_cut,
+                                        float pad_value, int64_t* h_num_frames) {
   if (!plan) return fail(HIPFEAT_ERR_INVALID, "plan is NULL");
   hipfeat_layout lay;
   lay.owns = false;
   std::vector<CutDesc> descs;
   hipfeat_status st = build_descs(plan, batch, h_wave_offsets, h_num_samples, h_padded_len, h_out_rows, out_row_stride, descs, &lay);
   if (st != HIPFEAT_OK) return st;
-  if (lay.total_blocks == 0) return HIPFEAT_OK;
+  int64_t max_pad = 0;
+  if (rows_per_cut >= 0) {
+    for (int64_t b = 0; b < batch; ++b) {
+      if (lay.num_frames[(size_t)b] > rows_per_cut)
+        return fail(HIPFEAT_ERR_INVALID, "cut %lld has %lld frames but the collated output holds %lld rows per cut", (long long)b,
+                    (long long)lay.num_frames[(size_t)b], (long long)rows_per_cut);
+      max_pad = std::max(max_pad, rows_per_cut - lay.num_frames[(size_t)b]);
+    }
+  }
+  if (h_num_frames)
+    for (int64_t b = 0; b < batch; ++b) h_num_frames[b] = lay.num_frames[(size_t)b];
+  if (lay.total_blocks == 0 && max_pad == 0) return HIPFEAT_OK;
   DeviceGuard g(plan->device);
-  // stage the descriptor table through a pinned ring slot so the call stays asynchronous
   const size_t bytes = descs.size() * sizeof(CutDesc);
   std::lock_guard<std::mutex> lk(plan->mu);
   StagingSlot& s = plan->slots[plan->next_slot];
@@ -756,10 +813,38 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_extract(const hipfeat_plan* plan, 
   std::memcpy(s.h, descs.data(), bytes);
   HIP_TRY(hipMemcpyAsync(s.d, s.h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
   lay.d_cuts = static_cast<CutDesc*>(s.d);
-  st = launch(plan, &lay, d_wave, d_out, (hipStream_t)stream);
+  st = HIPFEAT_OK;
+  if (lay.total_blocks > 0) st = launch(plan, &lay, d_wave, d_out, (hipStream_t)stream);
+  if (st == HIPFEAT_OK && max_pad > 0) {
+    const int64_t per_cut = max_pad * plan->feature_dim;
+    const unsigned gx = (unsigned)std::min<int64_t>((per_cut + 1023) / 1024, 64);
+    hipLaunchKernelGGL(fill_padding_kernel, dim3(gx, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, lay.d_cuts, d_out,
+                       out_row_stride, (int32_t)rows_per_cut, (int32_t)plan->feature_dim, pad_value);
+    hipError_t e1 = hipGetLastError();
+    if (e1 != hipSuccess) st = fail(HIPFEAT_ERR_HIP, "padding fill launch failed: %s", hipGetErrorName(e1));
+  }
   hipError_t e = hipEventRecord(s.ev, (hipStream_t)stream);
   s.busy = (e == hipSuccess);
   return st;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_extract(const hipfeat_plan* plan, const float* d_wave, const int64_t* h_wave_offsets,
+                                          const int64_t* h_num_samples, const int64_t* h_padded_len, int64_t batch,
+                                          float* d_out, const int64_t* h_out_rows, int64_t out_row_stride, void* stream) {
+  return extract_transient(plan, d_wave, h_wave_offsets, h_num_samples, h_padded_len, batch, d_out, h_out_rows, out_row_stride, stream, -1,
+                           0.f, nullptr);
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_extract_collated(const hipfeat_plan* plan, const float* d_wave, const int64_t* h_wave_offsets,
+                                                   const int64_t* h_num_samples, const int64_t* h_padded_len, int64_t batch,
+                                                   float* d_out, int64_t rows_per_cut, float pad_value, int64_t* h_num_frames,
+                                                   void* stream) {
+  if (!plan) return fail(HIPFEAT_ERR_INVALID, "plan is NULL");
+  if (rows_per_cut < 0 || batch < 0 || batch > 65535) return fail(HIPFEAT_ERR_INVALID, "collated output: bad rows_per_cut / batch (max 65535 cuts)");
+  std::vector<int64_t> rows((size_t)batch);
+  for (int64_t b = 0; b < batch; ++b) rows[(size_t)b] = b * rows_per_cut;
+  return extract_transient(plan, d_wave, h_wave_offsets, h_num_samples, h_padded_len, batch, d_out, rows.data(), plan->feature_dim, stream,
+                           rows_per_cut, pad_value, h_num_frames);
 }
 
 extern "C" HIPFEAT_API hipfeat_status hipfeat_extract_host(const hipfeat_plan* plan, const float* h_wave, int64_t wave_elems,

@@ -36,7 +36,7 @@ import numpy as np
 import torch
 
 from . import _lib, constants
-from .compat import EPSILON, FeatureExtractor, Seconds, asdict_nonull, compute_num_frames_from_samples, register_extractor
+from .compat import EPSILON, LOG_EPSILON, FeatureExtractor, Seconds, asdict_nonull, compute_num_frames_from_samples, register_extractor
 
 KIND_SPECTROGRAM, KIND_LOG_SPECTROGRAM, KIND_FBANK, KIND_MFCC = 0, 1, 2, 3
 EDGE_RULES = ("reflect", "batch_zero_pad")
@@ -270,6 +270,27 @@ class _Plan:
             )
         return out, frames
 
+    def run_collated(self, wave: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray, padded: Optional[np.ndarray],
+                     pad_value: float) -> Tuple[torch.Tensor, np.ndarray]:
+        """As ``run`` but into a dense (B, Tmax, F) tensor whose padding rows hold ``pad_value``."""
+        assert wave.dtype == torch.float32 and wave.is_contiguous() and wave.device == self.device
+        lengths, offsets = _lib.i64(lengths), _lib.i64(offsets)
+        n, shift, snip = self.n, self.shift, self.snip_edges
+        frames = np.array([self.lib.raw("hipfeat_num_frames", int(s), n, shift, snip) for s in lengths], dtype=np.int64)
+        if padded is not None:
+            padded = _lib.i64(padded)
+            row = np.array([self.lib.raw("hipfeat_num_frames", int(p), n, shift, snip) for p in padded], dtype=np.int64)
+            frames = np.minimum((lengths + shift // 2) // shift, row)
+        tmax = int(frames.max(initial=0))
+        got = np.zeros(len(lengths), dtype=np.int64)
+        with torch.cuda.device(self.device):
+            out = torch.empty((len(lengths), tmax, self.feature_dim), dtype=torch.float32, device=self.device)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.lib.check("hipfeat_extract_collated", self.handle, wave.data_ptr(), _lib.addr(offsets), _lib.addr(lengths), _lib.addr(padded),
+                           int(len(lengths)), out.data_ptr(), tmax, float(pad_value), _lib.addr(got), int(stream))
+        assert np.array_equal(got, frames)
+        return out, frames
+
     def close(self):
         if self.handle:
             try:
@@ -361,15 +382,21 @@ class _HostStaging:
 # --------------------------------------------------------------------------------------
 def _as_1d_float(x: ArrayLike, what: str) -> ArrayLike:
     """(T,), (1,T) or (C,T) -> (T,) of channel 0, as Fbank.extract does with ``[0]``
-    (extractors.py:107-110).  Only float32 is accepted, as in the reference."""
+    (extractors.py:107-110).  float32 in [-1, 1] as in the reference, or -- an extension,
+    SURVEY 8f row 2 -- int16 PCM, which the device converts as x / 32768 (what the audio backends do on the
+    host), so that only half the bytes cross PCIe."""
     if isinstance(x, torch.Tensor):
-        if x.dtype != torch.float32:
-            raise TypeError(f"{what}: expected float32 samples, got {x.dtype}")
+        if x.dtype not in (torch.float32, torch.int16):
+            raise TypeError(f"{what}: expected float32 (or int16 PCM) samples, got {x.dtype}")
         return x[0] if x.ndim == 2 else x.reshape(-1)
     x = np.asarray(x)
-    if x.dtype != np.float32:
-        raise TypeError(f"{what}: expected float32 samples, got {x.dtype}")
+    if x.dtype not in (np.float32, np.int16):
+        raise TypeError(f"{what}: expected float32 (or int16 PCM) samples, got {x.dtype}")
     return x[0] if x.ndim == 2 else x.reshape(-1)
+
+
+def _is_pcm16(x: ArrayLike) -> bool:
+    return x.dtype in (torch.int16, np.int16)
 
 
 class _HipExtractor(FeatureExtractor):
@@ -439,6 +466,11 @@ class _HipExtractor(FeatureExtractor):
         cut starts on a 16-byte boundary so that the kernels can use their 16-byte load path."""
         dev = self.plan.device
         lens = np.array([int(x.shape[0]) for x in items], dtype=np.int64)
+        pcm = [_is_pcm16(x) for x in items]
+        if any(pcm):
+            if not all(pcm):
+                raise TypeError("a batch must be all float32 or all int16 PCM")
+            return self._pack_pcm16(items, lens)
         if all(isinstance(x, torch.Tensor) and x.device == dev for x in items):
             if len(items) == 1:
                 return items[0].contiguous(), np.zeros(1, dtype=np.int64), lens
@@ -467,6 +499,58 @@ class _HipExtractor(FeatureExtractor):
         wave.copy_(host[:total], non_blocking=True)
         stage.sent(slot, dev)
         return wave, offs, lens
+
+    def _pack_pcm16(self, items: Sequence[ArrayLike], lens: np.ndarray) -> Tuple[torch.Tensor, np.ndarray, np.ndarray]:
+        """int16 PCM items -> one pinned int16 buffer -> H2D (half the bytes) -> float32 on the device."""
+        dev = self.plan.device
+        padded = (lens + 7) & ~7  # 16-byte aligned cut starts in the int16 buffer too
+        offs = np.zeros(len(items), dtype=np.int64)
+        np.cumsum(padded[:-1], out=offs[1:])
+        total = int(offs[-1] + lens[-1]) if len(items) else 0
+        if all(isinstance(x, torch.Tensor) and x.device == dev for x in items):
+            pcm = torch.zeros(total, dtype=torch.int16, device=dev)
+            for x, o, n in zip(items, offs, lens):
+                pcm[o : o + n] = x
+        else:
+            stage = self._stage()
+            host, slot = stage.input((total + 1) // 2)
+            hv = host.numpy().view(np.int16)
+            pieces = []
+            for x, o in zip(items, offs):
+                if isinstance(x, torch.Tensor):
+                    x = x.detach().cpu().contiguous().numpy()
+                pieces.append((int(o), np.ascontiguousarray(x)))
+            _parallel_copy(hv, pieces)
+            pcm = torch.empty(total, dtype=torch.int16, device=dev)
+            pcm.copy_(host.view(torch.int16)[:total], non_blocking=True)
+            stage.sent(slot, dev)
+        with torch.cuda.device(dev):
+            wave = torch.empty(total, dtype=torch.float32, device=dev)
+            self.plan.lib.check("hipfeat_pcm16_to_float", pcm.data_ptr(), wave.data_ptr(), total, int(torch.cuda.current_stream(dev).cuda_stream))
+        return wave, offs, lens
+
+    def extract_collated(
+        self, samples: Sequence[ArrayLike], sampling_rate: int, padding_value: float = LOG_EPSILON
+    ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``extract_batch`` + ``collate_matrices(features, padding_value=LOG_EPSILON)`` in one pass
+        (lhotse/dataset/input_strategies.py:441-462): returns the dense ``(B, Tmax, F)`` float32 tensor on the
+        extractor's device, padded with ``padding_value``, and the int64 frame counts.  The kernels write every
+        cut straight into its slot and a fill kernel writes only the padding rows -- no per-cut copies."""
+        self._check_sr(sampling_rate)
+        items = [_as_1d_float(x.squeeze() if x.ndim > 1 else x, "extract_collated()") for x in samples]
+        if not items:
+            raise ValueError("extract_collated(): empty batch")
+        zero_pad = self.config.edge_rule == "batch_zero_pad"
+        with torch.no_grad():
+            wave, offs, lens = self._pack(items)
+            padded = np.full(len(items), int(lens.max()), dtype=np.int64) if zero_pad else None
+            try:
+                out, frames = self.plan.run_collated(wave, offs, lens, padded, float(padding_value))
+            except _lib.HipFeatError as e:
+                if e.status == _lib.ERR_TOO_SHORT:
+                    raise ValueError(str(e)) from e
+                raise
+        return out, torch.from_numpy(frames)
 
     def _extract_items(self, items: Sequence[ArrayLike], padded_len: Optional[int] = None) -> Tuple[torch.Tensor, np.ndarray]:
         wave, offs, lens = self._pack(items)
@@ -540,7 +624,7 @@ class _HipExtractor(FeatureExtractor):
                     items = [samples.reshape(1, -1)]
                 input_is_torch = any(isinstance(x, torch.Tensor) for x in items)
                 # the reference squeezes every item (extractors.py:519-522)
-                items = [x if (x.ndim == 1 and x.dtype in (torch.float32, np.float32)) else _as_1d_float(x.squeeze() if x.ndim > 1 else x, "extract_batch()") for x in items]
+                items = [x if (x.ndim == 1 and x.dtype in (torch.float32, np.float32, torch.int16, np.int16)) else _as_1d_float(x.squeeze() if x.ndim > 1 else x, "extract_batch()") for x in items]
                 pmax = max(int(x.shape[0]) for x in items) if zero_pad else None
                 packed, frames = self._extract_items(items, pmax)
 

@@ -1,0 +1,64 @@
+"""
+``HipOnTheFlyFeatures`` -- lhotse's ``OnTheFlyFeatures`` input strategy (lhotse/dataset/input_strategies.py:351-476)
+with the extraction + collation step fused on the GPU.
+
+The reference computes a list of per-cut feature matrices and then ``collate_matrices(..., padding_value=LOG_EPSILON)``
+copies each of them into a fresh padded tensor (lhotse/dataset/collation.py:506-535).  Here the kernels write every
+cut straight into its slot of the ``(B, Tmax, F)`` tensor and only the padding rows are filled
+(``hipfeat_extract_collated``); audio reading, wave transforms, ``return_audio`` / ``fault_tolerant`` outputs and the
+supervision helpers are inherited unchanged.
+
+Needs lhotse (it consumes ``CutSet``s); importing this module without lhotse works, constructing the class does not.
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import torch
+
+from .compat import HAVE_LHOTSE, LOG_EPSILON
+
+if HAVE_LHOTSE:  # pragma: no cover - authoring container only
+    from lhotse.dataset.collation import collate_vectors, read_audio_from_cuts  # type: ignore
+    from lhotse.dataset.input_strategies import OnTheFlyFeatures, _get_executor  # type: ignore
+
+    class HipOnTheFlyFeatures(OnTheFlyFeatures):
+        """Same constructor as ``OnTheFlyFeatures`` plus ``return_device``: ``None`` keeps the padded feature
+        tensor on the extractor's GPU (ready for the training step), ``"cpu"`` hands back a host tensor like the
+        reference does."""
+
+        def __init__(self, extractor, *args, return_device: Optional[Union[str, torch.device]] = None, **kwargs) -> None:
+            if not hasattr(extractor, "extract_collated"):
+                raise TypeError("HipOnTheFlyFeatures needs a Hip* extractor (with extract_collated)")
+            super().__init__(extractor, *args, **kwargs)
+            self.return_device = return_device
+
+        def __call__(self, cuts, recording_field: Optional[str] = None):
+            audios, cuts = read_audio_from_cuts(
+                cuts,
+                executor=_get_executor(self.num_workers, executor_type=self._executor_type),
+                suppress_errors=self.fault_tolerant,
+                recording_field=recording_field,
+            )
+            for tfnm in self.wave_transforms:
+                for idx in range(len(audios)):
+                    audios[idx] = tfnm(audios[idx])
+            # one launch for the whole batch: a single sampling rate, as with use_batch_extract=True (:437-443)
+            assert all(c.sampling_rate == cuts[0].sampling_rate for c in cuts)
+            features_batch, feature_lens = self.extractor.extract_collated(audios, sampling_rate=cuts[0].sampling_rate, padding_value=LOG_EPSILON)
+            if self.return_device is not None:
+                features_batch = features_batch.to(self.return_device)
+            out = (features_batch, feature_lens)
+            if self.return_audio:
+                audios = [a.squeeze(0) for a in audios]  # (1, T) -> (T, )
+                audio_lens = torch.tensor([a.shape[0] for a in audios], dtype=torch.int64)
+                out = out + (collate_vectors(audios, padding_value=0), audio_lens)
+            if self.fault_tolerant:
+                out = out + (cuts,)
+            return out
+
+else:
+
+    class HipOnTheFlyFeatures:  # type: ignore[no-redef]
+        def __init__(self, *args, **kwargs):
+            raise ImportError("HipOnTheFlyFeatures consumes lhotse CutSets: install lhotse (lhotse.dataset.input_strategies.OnTheFlyFeatures)")

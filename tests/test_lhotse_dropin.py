@@ -42,6 +42,9 @@ def lhotse_mod():
         import lhotse_amd.kaldifeat as kf
 
         importlib.reload(kf)
+        import lhotse_amd.input_strategies as ins
+
+        importlib.reload(ins)
         importlib.reload(lhotse_amd)
     return lhotse
 
@@ -71,6 +74,13 @@ def cpu_device(monkeypatch, lhotse_mod):
                     f = f[: (int(l) + self.shift // 2) // self.shift]
                 outs.append(torch.from_numpy(np.ascontiguousarray(f)))
             return torch.cat(outs), np.array([len(o) for o in outs], dtype=np.int64)
+
+        def run_collated(self, wave, offsets, lengths, padded, pad_value):
+            packed, frames = self.run(wave, offsets, lengths, padded)
+            out = torch.full((len(frames), int(frames.max()), self.feature_dim), pad_value, dtype=torch.float32)
+            for i, f in enumerate(packed.split(frames.tolist())):
+                out[i, : len(f)] = f
+            return out, frames
 
         def close(self):
             pass
@@ -259,3 +269,32 @@ def test_kaldifeat_shaped_configs_equal_the_reference_dict_layout(lhotse_mod):
 
     ex = FeatureExtractor.from_dict({**LA.HipKaldifeatFbankConfig().to_dict(), "feature_type": "hip-kaldifeat-fbank"})
     assert isinstance(ex, LA.HipKaldifeatFbank)
+
+
+def test_fused_on_the_fly_features_equal_the_reference_strategy(cutset, cpu_device):
+    """HipOnTheFlyFeatures (extract + collate fused) vs lhotse's OnTheFlyFeatures(Fbank()): same padded tensor
+    (LOG_EPSILON padding), same lengths, same optional outputs."""
+    import lhotse_amd as LA
+    from lhotse import Fbank
+    from lhotse.dataset.input_strategies import OnTheFlyFeatures
+    from lhotse.utils import LOG_EPSILON
+
+    assert LA.compat.LOG_EPSILON == LOG_EPSILON
+    assert issubclass(LA.HipOnTheFlyFeatures, OnTheFlyFeatures)
+    ref_f, ref_l = OnTheFlyFeatures(Fbank())(cutset)
+    ours = LA.HipOnTheFlyFeatures(LA.HipFbank(), num_workers=2)
+    f, l = ours(cutset)
+    assert f.shape == ref_f.shape and f.dtype == torch.float32 and torch.equal(l, ref_l) and l.dtype == ref_l.dtype
+    for i, n in enumerate(l.tolist()):
+        assert torch.all(f[i, n:] == LOG_EPSILON) and torch.equal(f[i, n:], ref_f[i, n:])
+        # valid rows: the reference zero-pads the batch before framing (SURVEY Q1), we reflect per cut -> last rows differ
+        assert torch.allclose(f[i, : n - 2], ref_f[i, : n - 2], atol=2e-3)
+    # with the reference's edge rule the whole tensor agrees
+    f2, _ = LA.HipOnTheFlyFeatures(LA.HipFbank(LA.HipFbankConfig(edge_rule="batch_zero_pad")))(cutset)
+    assert torch.allclose(f2, ref_f, atol=2e-3)
+    # optional outputs
+    f3, l3, a3, al3, c3 = LA.HipOnTheFlyFeatures(LA.HipFbank(), return_audio=True, fault_tolerant=True, return_device="cpu")(cutset)
+    assert torch.equal(f3, f) and a3.shape == (5, 32000) and al3.tolist() == [16000, 24000, 12345, 32000, 8000] and len(c3) == 5
+    assert ours.supervision_intervals is not None
+    with pytest.raises(TypeError):
+        LA.HipOnTheFlyFeatures(Fbank())

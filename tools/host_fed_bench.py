@@ -21,3 +21,17 @@ for B in (60, 1024):
             n += B
         torch.cuda.synchronize()
         print(f"B={B:5d} {name:42s} {n / (time.perf_counter() - t0):10.0f} cuts/s (host in, host out)")
+
+# fused collation (features stay on the GPU, padded (B, Tmax, F)) and int16 PCM input
+for B in (60, 1024):
+    lens = np.random.RandomState(0).randint(8 * 16000, 12 * 16000, size=B)
+    xf = [(np.random.RandomState(i).rand(n).astype(np.float32) - 0.5) for i, n in enumerate(lens)]
+    xi = [np.round(a * 32767).astype(np.int16) for a in xf]
+    for name, arg in [("float32 list -> collated on device", xf), ("int16 PCM list -> collated on device", xi)]:
+        ex.extract_collated(arg, 16000); torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 3.0:
+            f, l = ex.extract_collated(arg, 16000)
+            n += B
+        torch.cuda.synchronize()
+        print(f"B={B:5d} {name:42s} {n / (time.perf_counter() - t0):10.0f} cuts/s (host in, device out)")
