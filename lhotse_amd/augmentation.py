@@ -93,15 +93,19 @@ class HipResampleTensor:
         return np.ceil((self.new * n / self.orig).astype(np.float32)).astype(np.int64)
 
     # ---- packed ragged batch, device resident ---------------------------------------------------------------
-    def run(self, wave: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray) -> Tuple[torch.Tensor, np.ndarray, np.ndarray]:
-        """wave: contiguous float32 on self.device holding every cut; -> (packed output, out_offsets, out_lengths)."""
+    def run(self, wave: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray, align: bool = True) -> Tuple[torch.Tensor, np.ndarray, np.ndarray]:
+        """wave: contiguous float32 on self.device holding every cut; -> (output buffer, out_offsets, out_lengths).
+        With ``align`` every output cut starts on a 16-byte boundary (up to 3 floats of slack between cuts), which is
+        what lets the feature kernels take their LDS-DMA load path on the result; otherwise cuts are back to back."""
         assert wave.dtype == torch.float32 and wave.is_contiguous() and wave.device == self.device
         offsets, lengths = _lib.i64(offsets), _lib.i64(lengths)
         out_lens = self.output_lengths(lengths)
         out_offs = np.zeros(len(lengths), dtype=np.int64)
-        np.cumsum(out_lens[:-1], out=out_offs[1:])
+        step = ((out_lens + 3) & ~3) if align else out_lens
+        np.cumsum(step[:-1], out=out_offs[1:])
+        total = int(out_offs[-1] + out_lens[-1]) if len(lengths) else 0
         with torch.cuda.device(self.device):
-            out = torch.empty(int(out_lens.sum()), dtype=torch.float32, device=self.device)
+            out = torch.empty(total, dtype=torch.float32, device=self.device)
             stream = torch.cuda.current_stream(self.device).cuda_stream
             self.lib.check("hipfeat_resample", self.handle, wave.data_ptr(), _lib.addr(offsets), _lib.addr(lengths), int(len(lengths)),
                            out.data_ptr(), _lib.addr(out_offs), int(stream))
@@ -121,8 +125,8 @@ class HipResampleTensor:
         wave = torch.cat([t.to(self.device, non_blocking=True) for t in ts]) if len(ts) > 1 else ts[0].to(self.device).contiguous()
         if self.orig == self.new:
             return list(wave.split(lengths.tolist()))
-        out, _, out_lens = self.run(wave, offsets, lengths)
-        return list(out.split(out_lens.tolist()))
+        out, out_offs, out_lens = self.run(wave, offsets, lengths)
+        return [out[o : o + n] for o, n in zip(out_offs.tolist(), out_lens.tolist())]
 
     def __call__(self, waveform: torch.Tensor) -> torch.Tensor:
         """(..., T) -> (..., T'), result on the input's device (resample.py:126-142)."""
@@ -136,7 +140,7 @@ class HipResampleTensor:
         T = int(shape[-1])
         rows = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
         x = waveform.reshape(rows, T).to(self.device).contiguous()
-        out, _, out_lens = self.run(x.view(-1), np.arange(rows, dtype=np.int64) * T, np.full(rows, T, dtype=np.int64))
+        out, _, out_lens = self.run(x.view(-1), np.arange(rows, dtype=np.int64) * T, np.full(rows, T, dtype=np.int64), align=False)
         y = out.view(shape[:-1] + (int(out_lens[0]) if rows else 0,))
         return y if waveform.is_cuda else y.cpu()
 

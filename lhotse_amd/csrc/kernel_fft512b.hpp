@@ -65,7 +65,6 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
   const int N = p.N, shift = p.shift;
   const int span = (kTileFrames - 1) * shift + N;
   const int nchunks = (p.xs_floats + 255) >> 8;  // 1 KiB LDS-DMA chunks covering the span buffer
-  const bool aligned16 = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && ((shift & 3) == 0) && ((p.npad_left & 3) == 0);
 
   for (int i = tid; i < p.const_floats; i += 256) smem[p.xs_floats + i] = p.lds_consts[i];
   float* lm = regions + 4 * kBWaveRegion;            // [16 frames][lm_stride] log-mel tile (MFCC only)
@@ -81,10 +80,12 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
 
   // Stage the sample span of the tile starting at frame f0 into xs.  Interior tiles: LDS-DMA, each wave
   // moves 1 KiB chunks (lane i supplies the global address of its 16 bytes; the hardware writes
-  // chunk base + 16 i).  Tiles touching a cut edge (reflection / zero padding): scalar loads.
+  // chunk base + 16 i).  The global side only needs dword alignment (measured: cuts packed back to
+  // back at odd sample offsets run at the same rate and give identical results), so any packing works.
+  // Tiles touching a cut edge (reflection / zero padding): scalar loads.
   auto stage_span = [&](int f0, unsigned lane16) {
     const int64_t j0 = (int64_t)f0 * shift - p.npad_left;
-    if (aligned16 && j0 >= 0 && j0 + (int64_t)nchunks * 256 <= cd.num_samples) {
+    if (j0 >= 0 && j0 + (int64_t)nchunks * 256 <= cd.num_samples) {
       const char* src = reinterpret_cast<const char*>(w + j0);  // uniform
       for (int ch = wv; ch < nchunks; ch += 4)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)ch * 1024u + lane16)),

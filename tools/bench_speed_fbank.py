@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cuts", type=int, default=6000)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--unaligned", action="store_true", help="resampled cuts back to back (not 16-byte aligned)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rng = np.random.RandomState(0)
@@ -38,14 +39,14 @@ def main():
     res = {}
     for factor in (0.9, 1.1):
         r = A.get_or_create_resampler(round(16000 * factor), 16000)
-        out, ooffs, olens = r.run(wave, offs, lens)  # warm-up + shapes
+        out, ooffs, olens = r.run(wave, offs, lens, align=not args.unaligned)  # warm-up + shapes
         feats, frames = plan.run(out, ooffs, olens, None)
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         t0 = time.perf_counter()
         for a, b, c in evs:
             a.record()
-            out, ooffs, olens = r.run(wave, offs, lens)
+            out, ooffs, olens = r.run(wave, offs, lens, align=not args.unaligned)
             b.record()
             feats, frames = plan.run(out, ooffs, olens, None)
             c.record()
