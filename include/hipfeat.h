@@ -55,7 +55,13 @@ typedef enum hipfeat_kind {
   HIPFEAT_SPECTROGRAM = 0,     /* Wav2Spec            layers.py:336-402 */
   HIPFEAT_LOG_SPECTROGRAM = 1, /* Wav2LogSpec         layers.py:405-473 */
   HIPFEAT_FBANK = 2,           /* Wav2LogFilterBank   layers.py:476-578 */
-  HIPFEAT_MFCC = 3             /* Wav2MFCC            layers.py:581-724 */
+  HIPFEAT_MFCC = 3,            /* Wav2MFCC            layers.py:581-724 */
+  /* "next" row: Whisper log-mel, log_mel_spectrogram lhotse/features/whisper_fbank.py:17-85.
+   * Implies: centred frames (frame t covers samples [t*shift - N/2, t*shift + N/2), torch.stft(center=True)),
+   * "reflect" edges without repeating the edge sample, fft_length == frame_length (any size, direct DFT),
+   * S / shift computed frames, log10(max(mel, mel_floor)) clamped to (per-cut max - 8), then (x + 4) / 4,
+   * and (S + shift/2) / shift output rows, the extra one (if any) all zeros.  window / mel as for HIPFEAT_FBANK. */
+  HIPFEAT_WHISPER = 4
 } hipfeat_kind;
 
 /*

@@ -28,7 +28,11 @@ from .kaldifeat import (  # noqa: F401,E402
 
 from .input_strategies import HipOnTheFlyFeatures  # noqa: F401,E402
 
+from .whisper import HipWhisperFbank, HipWhisperFbankConfig  # noqa: F401,E402
+
 __all__ = [
+    "HipWhisperFbank",
+    "HipWhisperFbankConfig",
     "HipOnTheFlyFeatures",
     "HipKaldifeatFbank",
     "HipKaldifeatFbankConfig",

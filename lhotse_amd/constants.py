@@ -24,7 +24,7 @@ import torch
 MEL_FLOOR = float(torch.finfo(torch.float32).eps)  # layers.py:536-538
 LOG_SPEC_OFFSET = 1e-15  # layers.py:467
 
-WINDOW_TYPES = ("hamming", "hanning", "povey", "rectangular", "blackman")
+WINDOW_TYPES = ("hamming", "hanning", "povey", "rectangular", "blackman", "hann_periodic")
 
 
 def frame_sizes(sampling_rate: int, frame_length: float, frame_shift: float, round_to_power_of_two: bool) -> Tuple[int, int, int]:
@@ -43,6 +43,8 @@ def make_window(n: int, window_type: str, blackman_coeff: float = 0.42) -> np.nd
         w = torch.hamming_window(n, periodic=False, alpha=0.54, beta=0.46)
     elif window_type == "povey":
         w = torch.hann_window(n, periodic=False).pow(0.85)
+    elif window_type == "hann_periodic":  # torch.hann_window(n), the STFT window of whisper_fbank.py:115,120
+        w = torch.hann_window(n)
     elif window_type == "rectangular":
         w = torch.ones(n, dtype=torch.float32)
     elif window_type == "blackman":
@@ -147,3 +149,29 @@ def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: in
     k = torch.where(t == 0, torch.tensor(1.0).to(t), t.sin() / t)
     k = k * window * scale
     return np.ascontiguousarray(k.to(torch.float32).reshape(new, 2 * width + orig).numpy()), width, orig, new
+
+
+def _slaney_hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    lin = f * (3.0 / 200.0)
+    return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-300) / 1000.0) / (np.log(6.4) / 27.0), lin)
+
+
+def _slaney_mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), m * (200.0 / 3.0))
+
+
+def make_slaney_mel(num_filters: int, fft: int, sampling_rate: int) -> np.ndarray:
+    """(fft/2+1, M) float32 -- the transpose of ``librosa.filters.mel(sr, n_fft, n_mels)`` (slaney mel scale, triangles
+    built from frequency ramps, area ("slaney") normalisation), which the reference loads in
+    lhotse/features/whisper_fbank.py:116-119 and multiplies from the left (:65)."""
+    bins = np.fft.rfftfreq(fft, 1.0 / sampling_rate)
+    edges = _slaney_mel_to_hz(np.linspace(_slaney_hz_to_mel(0.0), _slaney_hz_to_mel(sampling_rate / 2.0), num_filters + 2))
+    width = np.diff(edges)
+    ramps = edges[:, None] - bins[None, :]
+    rising = -ramps[:-2] / width[:-1, None]
+    falling = ramps[2:] / width[1:, None]
+    tri = np.maximum(0.0, np.minimum(rising, falling))
+    tri *= (2.0 / (edges[2:] - edges[:-2]))[:, None]
+    return np.ascontiguousarray(tri.astype(np.float32).T)

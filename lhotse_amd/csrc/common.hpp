@@ -23,6 +23,7 @@ enum : int32_t {
   F_LIFTER = 1 << 4,
   F_POW2 = 1 << 5,
   F_LOG_SPEC = 1 << 6,
+  F_CENTER = 1 << 7,  // torch.stft(center=True, pad_mode="reflect") framing (Whisper)
 };
 
 // Kernel arguments of the generic kernel (passed by value; lives in the kernarg segment).
@@ -51,6 +52,13 @@ __device__ __forceinline__ float load_sample(const float* __restrict__ w, int64_
   // j<0 -> -j-1, j>=P -> 2P-1-j; indices in [S, P) are the zero padding of a batch row.
   if (j < 0) j = -j - 1;
   if (j >= P) j = 2 * (int64_t)P - 1 - j;
+  return (j >= 0 && j < S) ? w[j] : 0.0f;
+}
+
+// torch.stft "reflect" padding: the edge sample is not repeated (j<0 -> -j, j>=S -> 2S-2-j).
+__device__ __forceinline__ float load_sample_center(const float* __restrict__ w, int64_t j, int32_t S) {
+  if (j < 0) j = -j;
+  if (j >= S) j = 2 * (int64_t)S - 2 - j;
   return (j >= 0 && j < S) ? w[j] : 0.0f;
 }
 

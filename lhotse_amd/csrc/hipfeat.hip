@@ -394,7 +394,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
     return fail(HIPFEAT_ERR_INVALID, "hipfeat_config.struct_size %d != %zu (ABI mismatch)", cfg->struct_size,
                 sizeof(hipfeat_config));
   const int N = cfg->frame_length, shift = cfg->frame_shift, fft = cfg->fft_length;
-  if (cfg->kind < 0 || cfg->kind > 3) return fail(HIPFEAT_ERR_INVALID, "unknown kind %d", cfg->kind);
+  if (cfg->kind < 0 || cfg->kind > 4) return fail(HIPFEAT_ERR_INVALID, "unknown kind %d", cfg->kind);
   if (N <= 0 || shift <= 0 || fft < N)
     return fail(HIPFEAT_ERR_INVALID, "need frame_length>0, frame_shift>0, fft_length>=frame_length (got %d, %d, %d)",
                 N, shift, fft);
@@ -403,7 +403,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   if (!h_window) return fail(HIPFEAT_ERR_INVALID, "window is NULL");
   if (cfg->dither != 0.0f)
     return fail(HIPFEAT_ERR_UNSUPPORTED, "dither != 0 is not supported in ABI v%d", HIPFEAT_ABI_VERSION);
-  const bool need_mel = cfg->kind == HIPFEAT_FBANK || cfg->kind == HIPFEAT_MFCC;
+  const bool whisper = cfg->kind == HIPFEAT_WHISPER;
+  if (whisper && (fft != N || cfg->snip_edges || cfg->use_energy || cfg->use_fft_mag || cfg->remove_dc_offset || cfg->preemph_coeff != 0.0f))
+    return fail(HIPFEAT_ERR_INVALID, "whisper: needs fft_length == frame_length and no snip_edges / energy / magnitude / DC removal / pre-emphasis");
+  const bool need_mel = cfg->kind == HIPFEAT_FBANK || cfg->kind == HIPFEAT_MFCC || whisper;
   if (need_mel && (cfg->num_filters <= 0 || !h_mel))
     return fail(HIPFEAT_ERR_INVALID, "fbank/mfcc need num_filters>0 and a mel matrix");
   if (cfg->kind == HIPFEAT_MFCC) {
@@ -424,10 +427,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   p->H = p->pow2 ? fft / 2 : 0;
   p->log2H = 0;
   while (p->pow2 && (1 << p->log2H) < p->H) ++p->log2H;
-  p->npad_left = cfg->snip_edges ? 0 : (N - shift) / 2;
+  p->npad_left = whisper ? N / 2 : (cfg->snip_edges ? 0 : (N - shift) / 2);
   const int M = need_mel ? cfg->num_filters : 0;
   const int C = cfg->kind == HIPFEAT_MFCC ? cfg->num_ceps : 0;
-  p->feature_dim = cfg->kind == HIPFEAT_FBANK ? M + (cfg->use_energy ? 1 : 0) : (cfg->kind == HIPFEAT_MFCC ? C : p->K);
+  p->feature_dim = cfg->kind == HIPFEAT_FBANK ? M + (cfg->use_energy ? 1 : 0) : (cfg->kind == HIPFEAT_MFCC ? C : (whisper ? M : p->K));
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
@@ -527,14 +530,19 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
     if (S < 0 || P < S || P > INT32_MAX)
       return fail(HIPFEAT_ERR_INVALID, "cut %lld: num_samples=%lld padded_len=%lld out of range", (long long)b, (long long)S, (long long)P);
     int64_t T = hipfeat_num_frames(S, c.frame_length, c.frame_shift, c.snip_edges);
-    if (padded) {
+    if (c.kind == HIPFEAT_WHISPER) {
+      if (P != S) return fail(HIPFEAT_ERR_INVALID, "whisper: zero-padded batch rows (padded_len != num_samples) are not defined");
+      if (S <= c.frame_length / 2)  // torch.stft: reflect padding must be shorter than the signal
+        return fail(HIPFEAT_ERR_TOO_SHORT, "cut %lld: %lld samples are not longer than the reflect padding (%d)", (long long)b, (long long)S,
+                    c.frame_length / 2);
+    } else if (padded) {
       // _extract_batch (extractors.py:499-537): the padded row of P samples is framed as a whole and
       // item b keeps the first compute_num_frames_from_samples(S) rows (lhotse/utils.py:424-434) --
       // with snip_edges that is NOT the snip_edges count, and it is capped by what the row yields.
       T = std::min<int64_t>((S + c.frame_shift / 2) / c.frame_shift,
                             hipfeat_num_frames(P, c.frame_length, c.frame_shift, c.snip_edges));
     }
-    if (!c.snip_edges && T > 0) {
+    if (!c.snip_edges && T > 0 && c.kind != HIPFEAT_WHISPER) {
       hipfeat_status st = hipfeat_check_length(P, c.frame_length, c.frame_shift, 0);
       if (st != HIPFEAT_OK) return st;
     }
@@ -695,9 +703,10 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
   gp.K = plan->K;
   gp.M = c.num_filters;
   gp.C = c.num_ceps;
-  gp.kind = c.kind;
+  const bool whisper = c.kind == HIPFEAT_WHISPER;
+  gp.kind = whisper ? (int)HIPFEAT_FBANK : c.kind;  // same epilogue: ln(max(mel, floor)); the post-pass below finishes it
   gp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0) | (c.use_energy ? F_USE_ENERGY : 0) | (c.raw_energy ? F_RAW_ENERGY : 0) |
-             (c.use_fft_mag ? F_FFT_MAG : 0) | (c.apply_lifter ? F_LIFTER : 0) | (plan->pow2 ? F_POW2 : 0);
+             (c.use_fft_mag ? F_FFT_MAG : 0) | (c.apply_lifter ? F_LIFTER : 0) | (plan->pow2 ? F_POW2 : 0) | (whisper ? F_CENTER : 0);
   gp.fpb = plan->fpb;
   gp.npad_left = plan->npad_left;
   gp.preemph = c.preemph_coeff;
@@ -713,6 +722,11 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
   DeviceGuard g(plan->device);
   hipLaunchKernelGGL(generic_kernel, dim3((unsigned)lay->total_blocks), dim3(256), plan->lds_bytes, stream, gp);
   HIP_TRY(hipGetLastError());
+  if (whisper) {
+    hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)lay->batch), dim3(1024), 0, stream, lay->d_cuts, d_out, lay->out_row_stride,
+                       (int32_t)c.num_filters, (int32_t)c.frame_shift);
+    HIP_TRY(hipGetLastError());
+  }
   return HIPFEAT_OK;
 }
 

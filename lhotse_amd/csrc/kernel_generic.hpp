@@ -58,7 +58,11 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericParams p) {
   const int N = p.N, H = p.H, K = p.K, fft = p.fft;
 
   // ---- phase 1: sample span + twiddles into LDS ------------------------------------
-  for (int i = tid; i < p.span; i += T) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
+  if (p.flags & F_CENTER) {
+    for (int i = tid; i < p.span; i += T) xs[i] = load_sample_center(w, j0 + i, cd.num_samples);
+  } else {
+    for (int i = tid; i < p.span; i += T) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
+  }
   if (pow2)
     for (int i = tid; i < H; i += T) tw[i] = p.tw[i];
   __syncthreads();
@@ -225,6 +229,38 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericParams p) {
       if (p.flags & F_LIFTER) acc *= p.lifter[c];
       out[(int64_t)f * p.out_stride + c] = acc;
     }
+  }
+}
+
+// Whisper post-pass (whisper_fbank.py:67-80) over one cut per workgroup: the main kernel left ln(max(mel, 1e-10)) in
+// the cut's rows; here: per-cut maximum over the S / shift computed frames, clamp to (max - 8) in log10 units, the
+// affine map (x + 4) / 4, and zeros in the padding row.
+__global__ __launch_bounds__(1024) void whisper_norm_kernel(const CutDesc* __restrict__ cuts, float* __restrict__ out, int64_t stride,
+                                                            int32_t M, int32_t shift) {
+  __shared__ float red[16];
+  const CutDesc cd = cuts[blockIdx.x];
+  const int valid = min(cd.num_samples / shift, cd.num_frames);
+  float* __restrict__ base = out + cd.out_row * stride;
+  const int64_t n = (int64_t)valid * M;
+  float mx = -INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const int64_t r = i / M;
+    mx = fmaxf(mx, base[r * stride + (i - r * M)]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+  constexpr float kLn10 = 2.302585092994046f, kLog10e = 0.4342944819032518f;
+  const float lo = mx - 8.0f * kLn10;
+  const int64_t nt = (int64_t)cd.num_frames * M;
+  for (int64_t i = threadIdx.x; i < nt; i += 1024) {
+    const int64_t r = i / M;
+    float* q = base + r * stride + (i - r * M);
+    *q = (r < valid) ? (fmaxf(*q, lo) * kLog10e + 4.0f) * 0.25f : 0.0f;
   }
 }
 

@@ -38,7 +38,7 @@ import torch
 from . import _lib, constants
 from .compat import EPSILON, LOG_EPSILON, FeatureExtractor, Seconds, asdict_nonull, compute_num_frames_from_samples, register_extractor
 
-KIND_SPECTROGRAM, KIND_LOG_SPECTROGRAM, KIND_FBANK, KIND_MFCC = 0, 1, 2, 3
+KIND_SPECTROGRAM, KIND_LOG_SPECTROGRAM, KIND_FBANK, KIND_MFCC, KIND_WHISPER = 0, 1, 2, 3, 4
 EDGE_RULES = ("reflect", "batch_zero_pad")
 
 ArrayLike = Union[np.ndarray, torch.Tensor]
@@ -176,7 +176,7 @@ class HipMfccConfig:
 class _Plan:
     """Owns one ``hipfeat_plan`` (constants resident in HBM + kernel selection)."""
 
-    def __init__(self, cfg, kind: int, device: torch.device):
+    def __init__(self, cfg, kind: int, device: torch.device, mel_floor: float = constants.MEL_FLOOR):
         self.lib = _lib.load()
         self.handle = 0
         if device.type != "cuda":
@@ -190,9 +190,11 @@ class _Plan:
         mel = dct = lifter = None
         num_filters = num_ceps = 0
         apply_lifter = 0
-        if kind in (KIND_FBANK, KIND_MFCC):
+        if kind in (KIND_FBANK, KIND_MFCC, KIND_WHISPER):
             num_filters = int(cfg.num_filters)
-            if cfg.torchaudio_compatible_mel_scale:
+            if kind == KIND_WHISPER:
+                mel = constants.make_slaney_mel(num_filters, fft, cfg.sampling_rate)
+            elif cfg.torchaudio_compatible_mel_scale:
                 mel = constants.make_kaldi_mel(num_filters, fft, cfg.sampling_rate, cfg.low_freq, cfg.high_freq)
             else:
                 mel = constants.make_htk_mel(num_filters, fft, cfg.sampling_rate, cfg.low_freq, cfg.high_freq, cfg.norm_filters)
@@ -214,7 +216,7 @@ class _Plan:
         c["apply_lifter"] = apply_lifter
         c["preemph_coeff"] = cfg.preemph_coeff
         c["energy_floor"] = cfg.energy_floor
-        c["mel_floor"] = constants.MEL_FLOOR
+        c["mel_floor"] = mel_floor
         c["log_offset"] = constants.LOG_SPEC_OFFSET
         c["dither"] = cfg.dither
         cbuf = np.ascontiguousarray(c).reshape(1)
@@ -436,8 +438,14 @@ class _HipExtractor(FeatureExtractor):
     @property
     def plan(self) -> _Plan:
         if self._plan is None:
-            self._plan = _Plan(self.config, self.kind, torch.device(self.config.device))
+            self._plan = _Plan(self._plan_config(), self.kind, torch.device(self.config.device), mel_floor=self._plan_mel_floor())
         return self._plan
+
+    def _plan_config(self):
+        return self.config
+
+    def _plan_mel_floor(self) -> float:
+        return constants.MEL_FLOOR
 
     @property
     def kernel_name(self) -> str:
@@ -540,7 +548,7 @@ class _HipExtractor(FeatureExtractor):
         items = [_as_1d_float(x.squeeze() if x.ndim > 1 else x, "extract_collated()") for x in samples]
         if not items:
             raise ValueError("extract_collated(): empty batch")
-        zero_pad = self.config.edge_rule == "batch_zero_pad"
+        zero_pad = getattr(self.config, "edge_rule", "reflect") == "batch_zero_pad"
         with torch.no_grad():
             wave, offs, lens = self._pack(items)
             padded = np.full(len(items), int(lens.max()), dtype=np.int64) if zero_pad else None
@@ -580,7 +588,7 @@ class _HipExtractor(FeatureExtractor):
         lengths: Optional[Union[np.ndarray, torch.Tensor]] = None,
     ) -> Union[np.ndarray, torch.Tensor, List[np.ndarray], List[torch.Tensor]]:
         self._check_sr(sampling_rate)
-        zero_pad = self.config.edge_rule == "batch_zero_pad"
+        zero_pad = getattr(self.config, "edge_rule", "reflect") == "batch_zero_pad"
         input_is_list = False
         input_is_torch = False
         with torch.no_grad():
