@@ -23,6 +23,7 @@ enum : int32_t {
   F_LIFTER = 1 << 4,
   F_POW2 = 1 << 5,
   F_LOG_SPEC = 1 << 6,
+  F_LOG10 = 1 << 8,   // mel epilogue in log10 (Whisper)
   F_CENTER = 1 << 7,  // torch.stft(center=True, pad_mode="reflect") framing (Whisper)
 };
 

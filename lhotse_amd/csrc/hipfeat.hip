@@ -18,6 +18,7 @@
 #include "kernel_fft512.hpp"
 #include "kernel_fft512b.hpp"
 #include "kernel_resample.hpp"
+#include "kernel_whisper.hpp"
 
 using namespace hipfeat;
 
@@ -100,6 +101,12 @@ struct hipfeat_plan {
   float* d_lds_consts = nullptr;
   float* d_mel_a = nullptr;
   WaveWork* d_work = nullptr;
+  // whisper fast path (variant 3)
+  float* d_wh_dft = nullptr;
+  float* d_wh_mel = nullptr;
+  uint32_t wh_mask[kWhBinTiles] = {};
+  int32_t wh_pair_base[kWhBinTiles] = {};
+  int wh_mel_tiles = 0;
   // transient-layout staging ring (hipfeat_extract)
   mutable std::mutex mu;
   mutable StagingSlot slots[4];
@@ -190,6 +197,8 @@ static void plan_free(hipfeat_plan* p) {
   (void)hipFree(p->d_dct_consts);
   (void)hipFree(p->d_mel_a);
   (void)hipFree(p->d_work);
+  (void)hipFree(p->d_wh_dft);
+  (void)hipFree(p->d_wh_mel);
   for (auto& s : p->slots) {
     if (s.h) (void)hipHostFree(s.h);
     if (s.d) (void)hipFree(s.d);
@@ -385,6 +394,79 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   return HIPFEAT_OK;
 }
 
+// --------------------------------------------------------------------------------------
+// whisper fast path: DFT-400 and mel operands in MFMA lane order (kernel_whisper.hpp)
+// --------------------------------------------------------------------------------------
+static hipfeat_status setup_whisper(hipfeat_plan* p, const float* h_mel) {
+  const hipfeat_config& c = p->cfg;
+  if (c.kind != HIPFEAT_WHISPER || c.frame_length != kWhN || c.num_filters > 16 * kWhMaxMelTiles || getenv("HIPFEAT_FORCE_GENERIC"))
+    return HIPFEAT_OK;
+  const int M = c.num_filters;
+  const int nmt = (M + 15) / 16;
+  // DFT operands: tile bt < 7: even bins 2m, m = 16 bt + i; bt >= 7: odd bins 2m + 1, m = 16 (bt - 7) + i
+  std::vector<float> dft((size_t)kWhBinTiles * kWhSteps * 64, 0.f);
+  for (int bt = 0; bt < kWhBinTiles; ++bt) {
+    const bool odd = bt >= 7;
+    for (int s = 0; s < kWhSteps; ++s)
+      for (int l = 0; l < 64; ++l) {
+        const int i = l & 15, g = l >> 4;
+        const int m = 16 * (odd ? bt - 7 : bt) + i;
+        if (m > (odd ? 99 : 100)) continue;
+        const bool sine = s >= kWhCosSteps;
+        const int kk = 4 * (sine ? s - kWhCosSteps : s) + g;
+        const int n = sine ? kk + 1 : kk;
+        double v = 0.0;
+        if (!odd) {
+          const double th = 2.0 * M_PI * (double)((int64_t)m * n % 200) / 200.0;
+          if (!sine && kk <= 100) v = std::cos(th);
+          if (sine && n <= 99) v = -std::sin(th);
+        } else {
+          const double th = 2.0 * M_PI * (double)((int64_t)n * (2 * m + 1) % 400) / 400.0;
+          if (!sine && kk <= 99) v = std::cos(th);
+          if (sine && n <= 100) v = -std::sin(th);
+        }
+        dft[((size_t)bt * kWhSteps + s) * 64 + l] = (float)v;
+      }
+  }
+  // mel operands for the (bin tile, mel tile) pairs with non-zero weights; k-step r covers accumulator rows 4 g + r
+  auto bin_of = [](int bt, int j) { return bt < 7 ? 2 * (16 * bt + j) : 2 * (16 * (bt - 7) + j) + 1; };
+  std::vector<float> mel;
+  int pairs = 0;
+  for (int bt = 0; bt < kWhBinTiles; ++bt) {
+    p->wh_pair_base[bt] = pairs;
+    p->wh_mask[bt] = 0;
+    for (int mt = 0; mt < nmt; ++mt) {
+      bool any = false;
+      for (int j = 0; j < 16 && !any; ++j)
+        for (int i = 0; i < 16 && !any; ++i) {
+          const int bin = bin_of(bt, j), m = 16 * mt + i;
+          any = bin <= 200 && m < M && h_mel[(size_t)bin * M + m] != 0.0f;
+        }
+      if (!any) continue;
+      p->wh_mask[bt] |= 1u << mt;
+      mel.resize((size_t)(pairs + 1) * 256, 0.f);
+      for (int r = 0; r < 4; ++r)
+        for (int l = 0; l < 64; ++l) {
+          const int i = l & 15, g = l >> 4;
+          const int bin = bin_of(bt, 4 * g + r), m = 16 * mt + i;
+          mel[(size_t)pairs * 256 + r * 64 + l] = (bin <= 200 && m < M) ? h_mel[(size_t)bin * M + m] : 0.f;
+        }
+      ++pairs;
+    }
+  }
+  if (mel.empty()) mel.resize(256, 0.f);
+  hipfeat_status st;
+  if ((st = upload(&p->d_wh_dft, dft.data(), dft.size())) != HIPFEAT_OK) return st;
+  if ((st = upload(&p->d_wh_mel, mel.data(), mel.size())) != HIPFEAT_OK) return st;
+  p->wh_mel_tiles = nmt <= 5 ? 5 : 8;
+  p->variant = 3;
+  p->fpb = 16;
+  char buf[160];
+  snprintf(buf, sizeof(buf), "whisper_kernel<%d> dft400-as-mfma-gemm lds=%dB mel_pairs=%d", p->wh_mel_tiles, (int)(16 * kWhRowStride * sizeof(float)), pairs);
+  p->kernel_name = buf;
+  return HIPFEAT_OK;
+}
+
 extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* cfg, const float* h_window,
                                               const float* h_mel, const float* h_dct, const float* h_lifter,
                                               int32_t device, hipfeat_plan** out) {
@@ -495,6 +577,8 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   if (e != hipSuccess) return bail(fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", p->lds_bytes, hipGetErrorName(e)));
 
   st = setup_fft512(p, h_window, h_mel, h_dct, h_lifter);
+  if (st != HIPFEAT_OK) return bail(st);
+  st = setup_whisper(p, h_mel);
   if (st != HIPFEAT_OK) return bail(st);
 
   *out = p;
@@ -631,6 +715,34 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
   if (lay->fpb != plan->fpb || lay->device != plan->device)
     return fail(HIPFEAT_ERR_INVALID, "layout was created for a different plan");
   const hipfeat_config& c = plan->cfg;
+  if (plan->variant == 3) {
+    WhisperParams wp{};
+    wp.wave = d_wave;
+    wp.out = d_out;
+    wp.cuts = lay->d_cuts;
+    wp.window = plan->d_window;
+    wp.dft_a = plan->d_wh_dft;
+    wp.mel_a = plan->d_wh_mel;
+    wp.out_stride = lay->out_row_stride;
+    wp.num_cuts = (int32_t)lay->batch;
+    wp.uniform_bpc = lay->uniform_bpc;
+    wp.shift = c.frame_shift;
+    wp.M = c.num_filters;
+    wp.mel_floor = c.mel_floor;
+    for (int i = 0; i < kWhBinTiles; ++i) {
+      wp.mel_mask[i] = plan->wh_mask[i];
+      wp.pair_base[i] = plan->wh_pair_base[i];
+    }
+    DeviceGuard g(plan->device);
+    const dim3 grid((unsigned)lay->total_blocks), block(64);
+    if (plan->wh_mel_tiles == 5) hipLaunchKernelGGL(whisper_kernel<5>, grid, block, 0, stream, wp);
+    else hipLaunchKernelGGL(whisper_kernel<8>, grid, block, 0, stream, wp);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)lay->batch), dim3(1024), 0, stream, lay->d_cuts, d_out, lay->out_row_stride,
+                       (int32_t)c.num_filters, (int32_t)c.frame_shift);
+    HIP_TRY(hipGetLastError());
+    return HIPFEAT_OK;
+  }
   if (plan->variant == 1 || plan->variant == 2) {
     Fft512Params fp{};
     fp.wave = d_wave;
@@ -704,9 +816,9 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
   gp.M = c.num_filters;
   gp.C = c.num_ceps;
   const bool whisper = c.kind == HIPFEAT_WHISPER;
-  gp.kind = whisper ? (int)HIPFEAT_FBANK : c.kind;  // same epilogue: ln(max(mel, floor)); the post-pass below finishes it
+  gp.kind = whisper ? (int)HIPFEAT_FBANK : c.kind;  // same epilogue with log10; the post-pass below finishes it
   gp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0) | (c.use_energy ? F_USE_ENERGY : 0) | (c.raw_energy ? F_RAW_ENERGY : 0) |
-             (c.use_fft_mag ? F_FFT_MAG : 0) | (c.apply_lifter ? F_LIFTER : 0) | (plan->pow2 ? F_POW2 : 0) | (whisper ? F_CENTER : 0);
+             (c.use_fft_mag ? F_FFT_MAG : 0) | (c.apply_lifter ? F_LIFTER : 0) | (plan->pow2 ? F_POW2 : 0) | (whisper ? (F_CENTER | F_LOG10) : 0);
   gp.fpb = plan->fpb;
   gp.npad_left = plan->npad_left;
   gp.preemph = c.preemph_coeff;

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericParams p) {
     const float* pf = P + f * K;
     float acc = 0.f;
     for (int k = r.x; k < r.y; ++k) acc = fmaf(pf[k], p.mel[(size_t)k * M + j], acc);
-    const float v = logf(fmaxf(acc, p.mel_floor));
+    const float v = (p.flags & F_LOG10) ? log10f(fmaxf(acc, p.mel_floor)) : logf(fmaxf(acc, p.mel_floor));
     if (p.kind == 2) {
       if (f < nf) {
         out[(int64_t)f * p.out_stride + ecol + j] = v;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericParams p) {
   }
 }
 
-// Whisper post-pass (whisper_fbank.py:67-80) over one cut per workgroup: the main kernel left ln(max(mel, 1e-10)) in
+// Whisper post-pass (whisper_fbank.py:67-80) over one cut per workgroup: the main kernel left log10(max(mel, 1e-10)) in
 // the cut's rows; here: per-cut maximum over the S / shift computed frames, clamp to (max - 8) in log10 units, the
 // affine map (x + 4) / 4, and zeros in the padding row.
 __global__ __launch_bounds__(1024) void whisper_norm_kernel(const CutDesc* __restrict__ cuts, float* __restrict__ out, int64_t stride,
@@ -254,13 +254,12 @@ __global__ __launch_bounds__(1024) void whisper_norm_kernel(const CutDesc* __res
   mx = red[0];
 #pragma unroll
   for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
-  constexpr float kLn10 = 2.302585092994046f, kLog10e = 0.4342944819032518f;
-  const float lo = mx - 8.0f * kLn10;
+  const float lo = mx - 8.0f;
   const int64_t nt = (int64_t)cd.num_frames * M;
   for (int64_t i = threadIdx.x; i < nt; i += 1024) {
     const int64_t r = i / M;
     float* q = base + r * stride + (i - r * M);
-    *q = (r < valid) ? (fmaxf(*q, lo) * kLog10e + 4.0f) * 0.25f : 0.0f;
+    *q = (r < valid) ? (fmaxf(*q, lo) + 4.0f) * 0.25f : 0.0f;
   }
 }
 
