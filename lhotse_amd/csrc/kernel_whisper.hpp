@@ -92,6 +92,8 @@ __global__ __launch_bounds__(64) void whisper_kernel(const WhisperParams p) {
   if (lane < 48) {  // zero the k padding of the even-cos vector (entries 101 .. 103)
     const int f = lane / 3, e = lane - 3 * f;
     rows[f * kWhRowStride + kWhOffCosE + 101 + e] = 0.f;
+  } else {  // and the unused last entry of the even-sin vector (its coefficient is 0, but 0 * garbage may be NaN)
+    rows[(lane - 48) * kWhRowStride + kWhOffSinE + 99] = 0.f;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
