@@ -104,8 +104,8 @@ struct hipfeat_plan {
   // whisper fast path (variant 3)
   float* d_wh_dft = nullptr;
   float* d_wh_mel = nullptr;
-  uint32_t wh_mask[kWhBinTiles] = {};
-  int32_t wh_pair_base[kWhBinTiles] = {};
+  int32_t wh_mt_lo[kWhBinTiles] = {};
+  int32_t wh_mt_cnt[kWhBinTiles] = {};
   int wh_mel_tiles = 0;
   // transient-layout staging ring (hipfeat_extract)
   mutable std::mutex mu;
@@ -430,11 +430,10 @@ static hipfeat_status setup_whisper(hipfeat_plan* p, const float* h_mel) {
   }
   // mel operands for the (bin tile, mel tile) pairs with non-zero weights; k-step r covers accumulator rows 4 g + r
   auto bin_of = [](int bt, int j) { return bt < 7 ? 2 * (16 * bt + j) : 2 * (16 * (bt - 7) + j) + 1; };
-  std::vector<float> mel;
+  std::vector<float> mel((size_t)kWhBinTiles * kWhSlots * 256, 0.f);
   int pairs = 0;
   for (int bt = 0; bt < kWhBinTiles; ++bt) {
-    p->wh_pair_base[bt] = pairs;
-    p->wh_mask[bt] = 0;
+    int lo = nmt, hi = -1;
     for (int mt = 0; mt < nmt; ++mt) {
       bool any = false;
       for (int j = 0; j < 16 && !any; ++j)
@@ -442,19 +441,25 @@ static hipfeat_status setup_whisper(hipfeat_plan* p, const float* h_mel) {
           const int bin = bin_of(bt, j), m = 16 * mt + i;
           any = bin <= 200 && m < M && h_mel[(size_t)bin * M + m] != 0.0f;
         }
-      if (!any) continue;
-      p->wh_mask[bt] |= 1u << mt;
-      mel.resize((size_t)(pairs + 1) * 256, 0.f);
+      if (any) {
+        lo = std::min(lo, mt);
+        hi = std::max(hi, mt);
+      }
+    }
+    if (hi < 0) lo = 0;
+    const int cnt = hi < 0 ? 0 : hi - lo + 1;
+    if (cnt > kWhSlots) return HIPFEAT_OK;  // filterbank too dense for the static schedule: generic kernel
+    p->wh_mt_lo[bt] = lo;
+    p->wh_mt_cnt[bt] = cnt;
+    pairs += cnt;
+    for (int sl = 0; sl < cnt; ++sl)
       for (int r = 0; r < 4; ++r)
         for (int l = 0; l < 64; ++l) {
           const int i = l & 15, g = l >> 4;
-          const int bin = bin_of(bt, 4 * g + r), m = 16 * mt + i;
-          mel[(size_t)pairs * 256 + r * 64 + l] = (bin <= 200 && m < M) ? h_mel[(size_t)bin * M + m] : 0.f;
+          const int bin = bin_of(bt, 4 * g + r), m = 16 * (lo + sl) + i;
+          mel[(((size_t)bt * kWhSlots + sl) * 4 + r) * 64 + l] = (bin <= 200 && m < M) ? h_mel[(size_t)bin * M + m] : 0.f;
         }
-      ++pairs;
-    }
   }
-  if (mel.empty()) mel.resize(256, 0.f);
   hipfeat_status st;
   if ((st = upload(&p->d_wh_dft, dft.data(), dft.size())) != HIPFEAT_OK) return st;
   if ((st = upload(&p->d_wh_mel, mel.data(), mel.size())) != HIPFEAT_OK) return st;
@@ -729,12 +734,13 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     wp.shift = c.frame_shift;
     wp.M = c.num_filters;
     wp.mel_floor = c.mel_floor;
+    if (const char* ab = getenv("HIPFEAT_WH_ABLATE")) wp.ablate = atoi(ab);
     for (int i = 0; i < kWhBinTiles; ++i) {
-      wp.mel_mask[i] = plan->wh_mask[i];
-      wp.pair_base[i] = plan->wh_pair_base[i];
+      wp.mt_lo[i] = plan->wh_mt_lo[i];
+      wp.mt_cnt[i] = plan->wh_mt_cnt[i];
     }
     DeviceGuard g(plan->device);
-    const dim3 grid((unsigned)lay->total_blocks), block(64);
+    const dim3 grid((unsigned)lay->total_blocks), block(128);
     if (plan->wh_mel_tiles == 5) hipLaunchKernelGGL(whisper_kernel<5>, grid, block, 0, stream, wp);
     else hipLaunchKernelGGL(whisper_kernel<8>, grid, block, 0, stream, wp);
     HIP_TRY(hipGetLastError());

@@ -241,11 +241,23 @@ __global__ __launch_bounds__(1024) void whisper_norm_kernel(const CutDesc* __res
   const CutDesc cd = cuts[blockIdx.x];
   const int valid = min(cd.num_samples / shift, cd.num_frames);
   float* __restrict__ base = out + cd.out_row * stride;
-  const int64_t n = (int64_t)valid * M;
+  const int64_t n = (int64_t)valid * M, nt = (int64_t)cd.num_frames * M;
+  // dense rows (stride == M) on a 16-byte boundary: one linear float4 sweep per pass
+  const bool dense = stride == M && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
   float mx = -INFINITY;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
-    const int64_t r = i / M;
-    mx = fmaxf(mx, base[r * stride + (i - r * M)]);
+  if (dense) {
+    const float4* b4 = reinterpret_cast<const float4*>(base);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+      const float4 v = b4[i];
+      mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, base[i]);
+  } else {
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+      const int64_t r = i / M;
+      mx = fmaxf(mx, base[r * stride + (i - r * M)]);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -255,11 +267,24 @@ __global__ __launch_bounds__(1024) void whisper_norm_kernel(const CutDesc* __res
 #pragma unroll
   for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
   const float lo = mx - 8.0f;
-  const int64_t nt = (int64_t)cd.num_frames * M;
-  for (int64_t i = threadIdx.x; i < nt; i += 1024) {
-    const int64_t r = i / M;
-    float* q = base + r * stride + (i - r * M);
-    *q = (r < valid) ? (fmaxf(*q, lo) + 4.0f) * 0.25f : 0.0f;
+  if (dense) {
+    float4* b4 = reinterpret_cast<float4*>(base);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+      float4 v = b4[i];
+      v.x = (fmaxf(v.x, lo) + 4.0f) * 0.25f;
+      v.y = (fmaxf(v.y, lo) + 4.0f) * 0.25f;
+      v.z = (fmaxf(v.z, lo) + 4.0f) * 0.25f;
+      v.w = (fmaxf(v.w, lo) + 4.0f) * 0.25f;
+      b4[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < nt; i += 1024) base[i] = (i < n) ? (fmaxf(base[i], lo) + 4.0f) * 0.25f : 0.0f;
+  } else {
+    for (int64_t i = threadIdx.x; i < nt; i += 1024) {
+      const int64_t r = i / M;
+      float* q = base + r * stride + (i - r * M);
+      *q = (r < valid) ? (fmaxf(*q, lo) + 4.0f) * 0.25f : 0.0f;
+    }
   }
 }
 
