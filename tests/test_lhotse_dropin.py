@@ -58,7 +58,7 @@ def cpu_device(monkeypatch, lhotse_mod):
     kinds = {0: "spectrogram", 1: "log-spectrogram", 2: "fbank", 3: "mfcc"}
 
     class CpuPlan:
-        def __init__(self, cfg, kind, device):
+        def __init__(self, cfg, kind, device, mel_floor=None):
             fields = {k: getattr(cfg, k) for k in RefConfig.__dataclass_fields__ if hasattr(cfg, k)}
             self.ref = RefExtractor(RefConfig(kind=kinds[kind], **fields), np.float32)
             self.device = torch.device("cpu")
