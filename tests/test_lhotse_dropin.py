@@ -43,8 +43,10 @@ def lhotse_mod():
 
         importlib.reload(kf)
         import lhotse_amd.input_strategies as ins
+        import lhotse_amd.whisper as wh
 
         importlib.reload(ins)
+        importlib.reload(wh)
         importlib.reload(lhotse_amd)
     return lhotse
 
