@@ -399,12 +399,13 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
 // --------------------------------------------------------------------------------------
 static hipfeat_status setup_whisper(hipfeat_plan* p, const float* h_mel) {
   const hipfeat_config& c = p->cfg;
-  if (c.kind != HIPFEAT_WHISPER || c.frame_length != kWhN || c.num_filters > 16 * kWhMaxMelTiles || getenv("HIPFEAT_FORCE_GENERIC"))
+  if (c.kind != HIPFEAT_WHISPER || c.frame_length != kWhN || c.frame_shift != kWhShift || c.num_filters > 16 * kWhMaxMelTiles ||
+      getenv("HIPFEAT_FORCE_GENERIC"))
     return HIPFEAT_OK;
   const int M = c.num_filters;
   const int nmt = (M + 15) / 16;
   // DFT operands: tile bt < 7: even bins 2m, m = 16 bt + i; bt >= 7: odd bins 2m + 1, m = 16 (bt - 7) + i
-  std::vector<float> dft((size_t)kWhBinTiles * kWhSteps * 64, 0.f);
+  std::vector<float> dft((size_t)kWhBinTiles * kWhChunks * 256, 0.f);  // [bt][chunk][lane][step & 3]
   for (int bt = 0; bt < kWhBinTiles; ++bt) {
     const bool odd = bt >= 7;
     for (int s = 0; s < kWhSteps; ++s)
@@ -425,7 +426,7 @@ static hipfeat_status setup_whisper(hipfeat_plan* p, const float* h_mel) {
           if (!sine && kk <= 99) v = std::cos(th);
           if (sine && n <= 100) v = -std::sin(th);
         }
-        dft[((size_t)bt * kWhSteps + s) * 64 + l] = (float)v;
+        dft[(((size_t)bt * kWhChunks + (s >> 2)) * 64 + l) * 4 + (s & 3)] = (float)v;
       }
   }
   // mel operands for the (bin tile, mel tile) pairs with non-zero weights; k-step r covers accumulator rows 4 g + r
@@ -457,7 +458,7 @@ static hipfeat_status setup_whisper(hipfeat_plan* p, const float* h_mel) {
         for (int l = 0; l < 64; ++l) {
           const int i = l & 15, g = l >> 4;
           const int bin = bin_of(bt, 4 * g + r), m = 16 * (lo + sl) + i;
-          mel[(((size_t)bt * kWhSlots + sl) * 4 + r) * 64 + l] = (bin <= 200 && m < M) ? h_mel[(size_t)bin * M + m] : 0.f;
+          mel[(((size_t)bt * kWhSlots + sl) * 64 + l) * 4 + r] = (bin <= 200 && m < M) ? h_mel[(size_t)bin * M + m] : 0.f;
         }
   }
   hipfeat_status st;
@@ -465,9 +466,10 @@ static hipfeat_status setup_whisper(hipfeat_plan* p, const float* h_mel) {
   if ((st = upload(&p->d_wh_mel, mel.data(), mel.size())) != HIPFEAT_OK) return st;
   p->wh_mel_tiles = nmt <= 5 ? 5 : 8;
   p->variant = 3;
-  p->fpb = 16;
+  p->fpb = 16 * kWhTilesPerBlock;
   char buf[160];
-  snprintf(buf, sizeof(buf), "whisper_kernel<%d> dft400-as-mfma-gemm lds=%dB mel_pairs=%d", p->wh_mel_tiles, (int)(16 * kWhRowStride * sizeof(float)), pairs);
+  snprintf(buf, sizeof(buf), "whisper_kernel<%d> dft400-as-mfma-gemm lds=%dB mel_pairs=%d", p->wh_mel_tiles,
+           (int)((16 * kWhRowStride + kWhSpanChunks * 256) * sizeof(float)), pairs);
   p->kernel_name = buf;
   return HIPFEAT_OK;
 }
