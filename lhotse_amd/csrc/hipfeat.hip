@@ -19,6 +19,7 @@
 #include "kernel_fft512b.hpp"
 #include "kernel_resample.hpp"
 #include "kernel_whisper.hpp"
+#include "kernel_fft256.hpp"
 
 using namespace hipfeat;
 
@@ -219,6 +220,83 @@ static const void* fft512b_entry() {
   return reinterpret_cast<const void*>(&fft512b_kernel<NROWS, OUT>);
 }
 
+// Mel work split of the fast kernels: band of every 16-mel tile in 8-bin groups, assigned to the 4 waves, and the MFMA
+// A operands in lane order.  Returns false when the filterbank does not fit the static schedule (-> generic kernel).
+static bool build_mel_schedule(const float* h_mel, int M, int K, int prow_stride, int ntiles, WaveWork (&work)[4], std::vector<float>& mel_a) {
+  struct Seg { int tile, bin, ng; };
+  std::vector<Seg> segs;
+  for (int t = 0; t < ntiles; ++t) {
+    int lo = K, hi = 0;
+    for (int k = 0; k < K; ++k)
+      for (int j = 16 * t; j < std::min(M, 16 * t + 16); ++j)
+        if (h_mel[(size_t)k * M + j] != 0.0f) {
+          lo = std::min(lo, k);
+          hi = std::max(hi, k + 1);
+        }
+    if (hi == 0) lo = 0, hi = 1;
+    int lo2 = lo & ~1;
+    int ng = (hi - lo2 + 7) / 8;
+    if (lo2 + 8 * ng > prow_stride) lo2 = (prow_stride - 8 * ng) & ~1;  // keep reads inside the padded row
+    if (lo2 < 0 || ng > kMaxGroups0) return false;
+    segs.push_back({t, lo2, ng});
+  }
+  // the four widest tiles become the waves' first segment, the rest go to the least loaded waves
+  std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.ng > b.ng; });
+  std::memset(work, 0, sizeof(work));
+  int load[4] = {0, 0, 0, 0};
+  bool has1[4] = {false, false, false, false};
+  for (size_t i = 0; i < segs.size(); ++i) {
+    const Seg& sg = segs[i];
+    if (i < 4) {
+      work[i].tile0 = sg.tile; work[i].bin0 = sg.bin; work[i].ngroups0 = sg.ng;
+      load[i] = sg.ng;
+      continue;
+    }
+    if (sg.ng > kMaxGroups1) return false;
+    int best = -1;
+    for (int w = 0; w < 4; ++w)
+      if (!has1[w] && (best < 0 || load[w] < load[best])) best = w;
+    if (best < 0) return false;
+    work[best].tile1 = sg.tile; work[best].bin1 = sg.bin; work[best].ngroups1 = sg.ng;
+    has1[best] = true;
+    load[best] += sg.ng;
+  }
+  // MFMA A operands: lane (i = lane & 15, kk = lane >> 4) of step (2*gi + r) holds
+  // W[bin + 8*gi + 2*kk + r][16*tile + i]; the second segment's steps start at 2*kMaxGroups0
+  mel_a.assign((size_t)4 * kMelARegs * 64, 0.0f);
+  for (int w = 0; w < 4; ++w)
+    for (int sgm = 0; sgm < 2; ++sgm) {
+      const int tile = sgm ? work[w].tile1 : work[w].tile0, bin = sgm ? work[w].bin1 : work[w].bin0;
+      const int ng = sgm ? work[w].ngroups1 : work[w].ngroups0;
+      for (int g2 = 0; g2 < ng; ++g2)
+        for (int r = 0; r < 2; ++r)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int i = lane & 15, kk = lane >> 4;
+            const int b = bin + 8 * g2 + 2 * kk + r, m = 16 * tile + i;
+            const int step = 2 * ((sgm ? kMaxGroups0 : 0) + g2) + r;
+            if (b < K && m < M) mel_a[((size_t)w * kMelARegs + step) * 64 + lane] = h_mel[(size_t)b * M + m];
+          }
+    }
+  return true;
+}
+
+// DCT^T as MFMA A operands + lifter (MFCC stage of the fast kernels): lane (i = lane & 15, kk = lane >> 4) of group g,
+// half r holds dct[mel = 8 g + 2 kk + r][ceps = 16 ct + i]  (Wav2MFCC._dct, layers.py:697-706)
+static std::vector<float> build_dct_operands(const hipfeat_config& c, const float* h_dct, const float* h_lifter, int dct_groups) {
+  const int M = c.num_filters, C = c.num_ceps, nct = (C + 15) / 16;
+  std::vector<float> da((size_t)nct * dct_groups * 64 * 2, 0.0f);
+  for (int ct = 0; ct < nct; ++ct)
+    for (int g2 = 0; g2 < dct_groups; ++g2)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 2; ++r) {
+          const int i = lane & 15, kk = lane >> 4, m = 8 * g2 + 2 * kk + r, cc = 16 * ct + i;
+          if (m < M && cc < C) da[(((size_t)ct * dct_groups + g2) * 64 + lane) * 2 + r] = h_dct[(size_t)m * C + cc];
+        }
+  for (int cc = 0; cc < 64; ++cc)  // lifter (layers.py:681-695), ones when cepstral_lifter == 0
+    da.push_back((c.apply_lifter && h_lifter && cc < C) ? h_lifter[cc] : 1.0f);
+  return da;
+}
+
 static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const float* h_mel, const float* h_dct,
                                    const float* h_lifter) {
   const hipfeat_config& c = p->cfg;
@@ -234,62 +312,9 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   const int ntiles = spec ? 0 : (M + 15) / 16;
   if (ntiles > 8) return HIPFEAT_OK;
 
-  // band of every 16-mel tile, in 8-bin groups starting at an even bin
-  struct Seg { int tile, bin, ng; };
-  std::vector<Seg> segs;
-  for (int t = 0; t < ntiles; ++t) {
-    int lo = p->K, hi = 0;
-    for (int k = 0; k < p->K; ++k)
-      for (int j = 16 * t; j < std::min(M, 16 * t + 16); ++j)
-        if (h_mel[(size_t)k * M + j] != 0.0f) {
-          lo = std::min(lo, k);
-          hi = std::max(hi, k + 1);
-        }
-    if (hi == 0) lo = 0, hi = 1;
-    int lo2 = lo & ~1;
-    int ng = (hi - lo2 + 7) / 8;
-    if (lo2 + 8 * ng > kPRowStride) lo2 = (kPRowStride - 8 * ng) & ~1;  // keep reads inside the padded row
-    if (lo2 < 0 || ng > kMaxGroups0) return HIPFEAT_OK;
-    segs.push_back({t, lo2, ng});
-  }
-  // the four widest tiles become the waves' first segment, the rest go to the least loaded waves
-  std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.ng > b.ng; });
   WaveWork work[4];
-  std::memset(work, 0, sizeof(work));
-  int load[4] = {0, 0, 0, 0};
-  bool has1[4] = {false, false, false, false};
-  for (size_t i = 0; i < segs.size(); ++i) {
-    const Seg& sg = segs[i];
-    if (i < 4) {
-      work[i].tile0 = sg.tile; work[i].bin0 = sg.bin; work[i].ngroups0 = sg.ng;
-      load[i] = sg.ng;
-      continue;
-    }
-    if (sg.ng > kMaxGroups1) return HIPFEAT_OK;  // does not fit the static schedule -> generic kernel
-    int best = -1;
-    for (int w = 0; w < 4; ++w)
-      if (!has1[w] && (best < 0 || load[w] < load[best])) best = w;
-    if (best < 0) return HIPFEAT_OK;
-    work[best].tile1 = sg.tile; work[best].bin1 = sg.bin; work[best].ngroups1 = sg.ng;
-    has1[best] = true;
-    load[best] += sg.ng;
-  }
-  // MFMA A operands: lane (i = lane & 15, kk = lane >> 4) of step (2*gi + r) holds
-  // W[bin + 8*gi + 2*kk + r][16*tile + i]; the second segment's steps start at 2*kMaxGroups0
-  std::vector<float> mel_a((size_t)4 * kMelARegs * 64, 0.0f);
-  for (int w = 0; w < 4; ++w)
-    for (int sgm = 0; sgm < 2; ++sgm) {
-      const int tile = sgm ? work[w].tile1 : work[w].tile0, bin = sgm ? work[w].bin1 : work[w].bin0;
-      const int ng = sgm ? work[w].ngroups1 : work[w].ngroups0;
-      for (int g2 = 0; g2 < ng; ++g2)
-        for (int r = 0; r < 2; ++r)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int i = lane & 15, kk = lane >> 4;
-            const int b = bin + 8 * g2 + 2 * kk + r, m = 16 * tile + i;
-            const int step = 2 * ((sgm ? kMaxGroups0 : 0) + g2) + r;
-            if (b < p->K && m < M) mel_a[((size_t)w * kMelARegs + step) * 64 + lane] = h_mel[(size_t)b * M + m];
-          }
-    }
+  std::vector<float> mel_a;
+  if (!build_mel_schedule(h_mel, M, p->K, kPRowStride, ntiles, work, mel_a)) return HIPFEAT_OK;  // -> generic kernel
   // LDS constant block: window/2 as (even, odd) sample pairs per (row n1, lane q); pass twiddles
   // W_256^(q k1) per (row k1, lane q); split-step twiddles -i W_512^(q + 16 k2) per (row k2, lane q)
   std::vector<float> wh(512, 0.0f);
@@ -343,21 +368,9 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
     p->xs_floats = (15 * shift + 32 * nrows + 255) & ~255;  // whole 1 KiB LDS-DMA chunks
     size_t lds_floats = (size_t)p->xs_floats + const_floats + 4 * kBWaveRegion;
     if (mfcc) {
-      // DCT^T as MFMA A operands: lane (i = lane & 15, kk = lane >> 4) of group g, half r holds
-      // dct[mel = 8 g + 2 kk + r][ceps = 16 ct + i]  (Wav2MFCC._dct, layers.py:697-706)
-      const int C = c.num_ceps, nct = (C + 15) / 16;
       p->dct_groups = (M + 7) / 8;
       p->lm_stride = ntiles <= 4 ? 68 : 132;  // == 4 mod 64: conflict-free 8-byte reads of the log-mel tile
-      std::vector<float> da((size_t)nct * p->dct_groups * 64 * 2, 0.0f);
-      for (int ct = 0; ct < nct; ++ct)
-        for (int g2 = 0; g2 < p->dct_groups; ++g2)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int r = 0; r < 2; ++r) {
-              const int i = lane & 15, kk = lane >> 4, m = 8 * g2 + 2 * kk + r, cc = 16 * ct + i;
-              if (m < M && cc < C) da[(((size_t)ct * p->dct_groups + g2) * 64 + lane) * 2 + r] = h_dct[(size_t)m * C + cc];
-            }
-      for (int cc = 0; cc < 64; ++cc)  // lifter (layers.py:681-695), ones when cepstral_lifter == 0
-        da.push_back((c.apply_lifter && h_lifter && cc < C) ? h_lifter[cc] : 1.0f);
+      std::vector<float> da = build_dct_operands(c, h_dct, h_lifter, p->dct_groups);
       p->dct_floats = (int)da.size();
       if ((st = upload(&p->d_dct_consts, da.data(), da.size())) != HIPFEAT_OK) return st;
       lds_floats += (size_t)kTileFrames * p->lm_stride + da.size();
@@ -391,6 +404,104 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   p->kernel_name = nm;
   p->variant = use_b ? 2 : 1;
   p->fpb = kTileFrames * p->tiles_per_block;
+  return HIPFEAT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// fft256 fast path (kernel_fft256.hpp): 8 kHz 25/10 ms frames, or <= 16 ms frames at 16 kHz
+// --------------------------------------------------------------------------------------
+template <int NROWS, int OUT>
+static const void* fft256_entry() {
+  return reinterpret_cast<const void*>(&fft256_kernel<NROWS, OUT>);
+}
+
+static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const float* h_mel, const float* h_dct, const float* h_lifter) {
+  const hipfeat_config& c = p->cfg;
+  const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
+  const bool mfcc = c.kind == HIPFEAT_MFCC;
+  const bool spec = c.kind == HIPFEAT_SPECTROGRAM || c.kind == HIPFEAT_LOG_SPECTROGRAM;
+  if (c.kind > HIPFEAT_MFCC || c.fft_length != 256 || (shift & 1) || N < 16 || c.use_energy || (!spec && c.use_fft_mag) ||
+      getenv("HIPFEAT_FORCE_GENERIC"))
+    return HIPFEAT_OK;
+  if (mfcc && (M > 8 * kMaxDctGroups || c.num_ceps > 64)) return HIPFEAT_OK;
+  const int need = (N + 15) / 16;
+  const int nrows = need <= 13 ? 13 : 16;
+  const int ntiles = spec ? 0 : (M + 15) / 16;
+  if (ntiles > 8) return HIPFEAT_OK;
+  WaveWork work[4];
+  std::vector<float> mel_a((size_t)4 * kMelARegs * 64, 0.0f);
+  std::memset(work, 0, sizeof(work));
+  if (!spec && !build_mel_schedule(h_mel, M, p->K, k256PRowStride, ntiles, work, mel_a)) return HIPFEAT_OK;
+  // LDS constants: window/2 pairs per (row n1, lane q) | W_128^(q k1) per (row k1, lane q) | split-step twiddles
+  // w = -i W_256^(q + 8 j) per (row j < 8, lane q) | (-w.y, w.x)
+  std::vector<float> wh(256, 0.0f);
+  for (int i = 0; i < N; ++i) wh[i] = 0.5f * h_window[i];
+  const int const_floats = (nrows * 8 + 128 + 64 + 64) * 2;
+  std::vector<float> lc((size_t)const_floats, 0.0f);
+  for (int n1 = 0; n1 < nrows; ++n1)
+    for (int q = 0; q < 8; ++q) {
+      lc[2 * (n1 * 8 + q)] = wh[16 * n1 + 2 * q];
+      lc[2 * (n1 * 8 + q) + 1] = wh[16 * n1 + 2 * q + 1];
+    }
+  float* twp = lc.data() + 2 * nrows * 8;
+  float* tws = twp + 256;
+  float* twsp = tws + 128;
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int q = 0; q < 8; ++q) {
+      const double a = -2.0 * M_PI * (double)(q * k1) / 128.0;
+      twp[2 * (k1 * 8 + q)] = (float)std::cos(a);
+      twp[2 * (k1 * 8 + q) + 1] = (float)std::sin(a);
+    }
+  for (int j = 0; j < 8; ++j)
+    for (int q = 0; q < 8; ++q) {  // w = -i * W_256^k = (sin(a), -cos(a)) with a = -2 pi k / 256
+      const double a = -2.0 * M_PI * (double)(q + 8 * j) / 256.0;
+      const float wx = (float)std::sin(a), wy = (float)(-std::cos(a));
+      tws[2 * (j * 8 + q)] = wx;
+      tws[2 * (j * 8 + q) + 1] = wy;
+      twsp[2 * (j * 8 + q)] = -wy;
+      twsp[2 * (j * 8 + q) + 1] = wx;
+    }
+  hipfeat_status st;
+  if ((st = upload(&p->d_lds_consts, lc.data(), lc.size())) != HIPFEAT_OK) return st;
+  if ((st = upload(&p->d_work, work, 4)) != HIPFEAT_OK) return st;
+  std::vector<float> mel_a4(mel_a.size());  // weights as 16-byte vectors: [wave][step / 4][lane][step % 4]
+  for (int w = 0; w < 4; ++w)
+    for (int s4 = 0; s4 < kMelARegs; ++s4)
+      for (int lane = 0; lane < 64; ++lane)
+        mel_a4[(((size_t)w * kBMelVec + s4 / 4) * 64 + lane) * 4 + (s4 & 3)] = mel_a[((size_t)w * kMelARegs + s4) * 64 + lane];
+  if ((st = upload(&p->d_mel_a4, mel_a4.data(), mel_a4.size())) != HIPFEAT_OK) return st;
+  p->nrows = nrows;
+  p->tiles_per_block = 8;  // 256 frames per workgroup, as the 512 kernel
+  if (const char* tpb = getenv("HIPFEAT_TILES_PER_BLOCK")) p->tiles_per_block = std::max(1, atoi(tpb));
+  p->const_floats = const_floats;
+  p->xs_floats = ((k256TileFrames - 1) * shift + 16 * nrows + 255) & ~255;  // whole 1 KiB LDS-DMA chunks
+  size_t lds_floats = (size_t)p->xs_floats + const_floats + 4 * k256WaveRegion;
+  if (mfcc) {
+    p->dct_groups = (M + 7) / 8;
+    p->lm_stride = ntiles <= 4 ? 68 : 132;
+    std::vector<float> da = build_dct_operands(c, h_dct, h_lifter, p->dct_groups);
+    p->dct_floats = (int)da.size();
+    if ((st = upload(&p->d_dct_consts, da.data(), da.size())) != HIPFEAT_OK) return st;
+    lds_floats += (size_t)k256TileFrames * p->lm_stride + da.size();
+    p->fast_mfcc = true;
+  }
+  p->fast_lds_bytes = lds_floats * sizeof(float);
+  p->fast_out = mfcc ? 1 : (spec ? 2 : 0);
+  if (p->fast_lds_bytes > 64 * 1024) return HIPFEAT_OK;  // keep at least two workgroups per CU; otherwise the generic kernel
+  const void* fn;
+  if (mfcc) fn = nrows == 13 ? fft256_entry<13, 1>() : fft256_entry<16, 1>();
+  else if (spec) fn = nrows == 13 ? fft256_entry<13, 2>() : fft256_entry<16, 2>();
+  else fn = nrows == 13 ? fft256_entry<13, 0>() : fft256_entry<16, 0>();
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->fast_lds_bytes);
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft256) failed: %s", hipGetErrorName(e));
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, p->fast_lds_bytes) == hipSuccess) p->blocks_per_cu = nb;
+  char nm[112];
+  snprintf(nm, sizeof(nm), "fft256_kernel<%d,%d> %s lds=%zuB blocks/CU=%d", nrows, p->fast_out, mfcc ? "mfcc" : (spec ? "spectrogram" : "fbank"),
+           p->fast_lds_bytes, p->blocks_per_cu);
+  p->kernel_name = nm;
+  p->variant = 4;
+  p->fpb = k256TileFrames * p->tiles_per_block;
   return HIPFEAT_OK;
 }
 
@@ -587,6 +698,8 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   if (st != HIPFEAT_OK) return bail(st);
   st = setup_whisper(p, h_mel);
   if (st != HIPFEAT_OK) return bail(st);
+  st = setup_fft256(p, h_window, h_mel, h_dct, h_lifter);
+  if (st != HIPFEAT_OK) return bail(st);
 
   *out = p;
   return HIPFEAT_OK;
@@ -751,13 +864,13 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }
-  if (plan->variant == 1 || plan->variant == 2) {
+  if (plan->variant == 1 || plan->variant == 2 || plan->variant == 4) {
     Fft512Params fp{};
     fp.wave = d_wave;
     fp.out = d_out;
     fp.cuts = lay->d_cuts;
     fp.lds_consts = plan->d_lds_consts;
-    fp.mel_a = plan->variant == 2 ? plan->d_mel_a4 : plan->d_mel_a;
+    fp.mel_a = plan->variant == 1 ? plan->d_mel_a : plan->d_mel_a4;
     fp.work = plan->d_work;
     fp.out_stride = lay->out_row_stride;
     fp.num_cuts = (int32_t)lay->batch;
@@ -780,7 +893,19 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.dct_floats = plan->dct_floats;
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(256);
-    if (plan->variant == 2) {
+    if (plan->variant == 4) {
+#define HF_LAUNCH_256(NR, OUT) hipLaunchKernelGGL((fft256_kernel<NR, OUT>), grid, block, plan->fast_lds_bytes, stream, fp)
+      if (plan->nrows == 13) {
+        if (plan->fast_out == 1) HF_LAUNCH_256(13, 1);
+        else if (plan->fast_out == 2) HF_LAUNCH_256(13, 2);
+        else HF_LAUNCH_256(13, 0);
+      } else {
+        if (plan->fast_out == 1) HF_LAUNCH_256(16, 1);
+        else if (plan->fast_out == 2) HF_LAUNCH_256(16, 2);
+        else HF_LAUNCH_256(16, 0);
+      }
+#undef HF_LAUNCH_256
+    } else if (plan->variant == 2) {
 #define HF_LAUNCH_B(NR, OUT) hipLaunchKernelGGL((fft512b_kernel<NR, OUT>), grid, block, plan->fast_lds_bytes, stream, fp)
 #define HF_LAUNCH_NR(OUT)                      \
   do {                                         \
