@@ -239,6 +239,13 @@ class _Plan:
     def num_frames(self, num_samples: int) -> int:
         return int(self.lib.raw("hipfeat_num_frames", int(num_samples), self.n, self.shift, self.snip_edges))
 
+    def num_frames_many(self, num_samples: np.ndarray) -> np.ndarray:
+        """Vectorised ``hipfeat_num_frames`` (same integer formula; tests/test_abi.py compares the two)."""
+        s = _lib.i64(num_samples)
+        if self.snip_edges:
+            return np.where(s < self.n, 0, 1 + (s - self.n) // self.shift).astype(np.int64)
+        return (s + self.shift // 2) // self.shift
+
     def run(self, wave: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray, padded: Optional[np.ndarray]) -> Tuple[torch.Tensor, np.ndarray]:
         """wave: float32 tensor on self.device holding every cut; returns the packed
         (sum T_b, F) feature matrix (same device, same stream) and the per-cut frame counts."""
@@ -247,12 +254,11 @@ class _Plan:
         offsets = _lib.i64(offsets)
         n, shift, snip = self.n, self.shift, self.snip_edges
         if padded is None:
-            frames = np.array([self.lib.raw("hipfeat_num_frames", int(s), n, shift, snip) for s in lengths], dtype=np.int64)
+            frames = self.num_frames_many(lengths)
         else:
             padded = _lib.i64(padded)
             own = (lengths + shift // 2) // shift
-            row = np.array([self.lib.raw("hipfeat_num_frames", int(p), n, shift, snip) for p in padded], dtype=np.int64)
-            frames = np.minimum(own, row)
+            frames = np.minimum(own, self.num_frames_many(padded))
         total = int(frames.sum())
         with torch.cuda.device(self.device):
             out = torch.empty((total, self.feature_dim), dtype=torch.float32, device=self.device)
@@ -278,11 +284,10 @@ class _Plan:
         assert wave.dtype == torch.float32 and wave.is_contiguous() and wave.device == self.device
         lengths, offsets = _lib.i64(lengths), _lib.i64(offsets)
         n, shift, snip = self.n, self.shift, self.snip_edges
-        frames = np.array([self.lib.raw("hipfeat_num_frames", int(s), n, shift, snip) for s in lengths], dtype=np.int64)
+        frames = self.num_frames_many(lengths)
         if padded is not None:
             padded = _lib.i64(padded)
-            row = np.array([self.lib.raw("hipfeat_num_frames", int(p), n, shift, snip) for p in padded], dtype=np.int64)
-            frames = np.minimum((lengths + shift // 2) // shift, row)
+            frames = np.minimum((lengths + shift // 2) // shift, self.num_frames_many(padded))
         tmax = int(frames.max(initial=0))
         got = np.zeros(len(lengths), dtype=np.int64)
         with torch.cuda.device(self.device):

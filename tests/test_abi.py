@@ -60,6 +60,15 @@ def test_loader_and_pure_helpers():
         for s in list(range(0, 1300)) + [160000, 100050, 256640]:
             for snip in (0, 1):
                 assert lib.raw("hipfeat_num_frames", s, n, shift, snip) == K.num_frames(s, n, shift, bool(snip))
+    # the vectorised host formula used on the hot path equals the library function
+    from lhotse_amd.extractors import _Plan
+
+    for n, shift in [(400, 160), (200, 80), (551, 220)]:
+        for snip in (0, 1):
+            pl = _Plan.__new__(_Plan)
+            pl.n, pl.shift, pl.snip_edges = n, shift, snip
+            s = np.concatenate([np.arange(0, 1300), np.array([160000, 100050, 256640, 57600000])])
+            assert np.array_equal(pl.num_frames_many(s), [lib.raw("hipfeat_num_frames", int(v), n, shift, snip) for v in s])
     # first valid length for 25/10 ms @ 16 kHz is 140 samples
     assert lib.raw("hipfeat_check_length", 139, 400, 160, 0) == _lib.ERR_TOO_SHORT
     assert "shorter than the reflect padding" in lib.last_error()
