@@ -319,8 +319,8 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   // W_256^(q k1) per (row k1, lane q); split-step twiddles -i W_512^(q + 16 k2) per (row k2, lane q)
   std::vector<float> wh(512, 0.0f);
   for (int i = 0; i < N; ++i) wh[i] = 0.5f * h_window[i];
-  const int const_floats = (nrows * 16 + 512) * 2;
-  std::vector<float> lc((size_t)const_floats, 0.0f);
+  const int const_floats_full = (nrows * 16 + 512) * 2;
+  std::vector<float> lc((size_t)const_floats_full, 0.0f);
   for (int n1 = 0; n1 < nrows; ++n1)
     for (int q = 0; q < 16; ++q) {
       lc[2 * (n1 * 16 + q)] = wh[32 * n1 + 2 * q];
@@ -353,9 +353,11 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   // fetch are paid once per workgroup (measured on MI355X: 4 -> 1.98 M, 8 -> 2.11 M, 16 -> 2.16 M cuts/s)
   p->tiles_per_block = 16;
   if (const char* tpb = getenv("HIPFEAT_TILES_PER_BLOCK")) p->tiles_per_block = std::max(1, atoi(tpb));
-  p->const_floats = const_floats;
   const char* var = getenv("HIPFEAT_FFT512_VARIANT");
   const bool use_b = mfcc || spec || !(var && var[0] == 'a');
+  // the twsp table (last 256 floats) is only copied to LDS by the kernels that read it
+  const int const_floats = const_floats_full - (use_b ? 256 - kBTwspFloats : 0);
+  p->const_floats = const_floats;
   const void* fn;
   if (use_b) {
     // weights as 16-byte vectors: [wave][step / 4][lane][step % 4]

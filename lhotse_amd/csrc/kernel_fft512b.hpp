@@ -18,9 +18,21 @@
 
 namespace hipfeat {
 
+#ifndef HIPFEAT_B5
+#define HIPFEAT_B5 0  // experiment: 32.6 KB / <= 96 VGPRs -> FIVE workgroups per CU (exchange in quarters, no twsp table)
+#endif
 constexpr int kBExRowStride = 34;                        // dwords per exchange row (16 complex + 2 pad)
+#if HIPFEAT_B5
+constexpr int kBExParts = 4;                             // the exchange runs in quarters (4 rows at a time)
+constexpr int kBExFrameStride = 4 * kBExRowStride + 8;   // 144 (== 16 mod 64)
+constexpr int kBWaveRegion = 4 * kPRowStride;            // 1040 dwords per wave: the power rows; 4 x 144 exchange fits inside
+constexpr int kBTwspFloats = 0;                          // (-w.y, w.x) is derived from w with one packed multiply
+#else
+constexpr int kBExParts = 2;
 constexpr int kBExFrameStride = 8 * kBExRowStride + 16;  // 288 (== 32 mod 64): 8 rows per half
 constexpr int kBWaveRegion = 4 * kBExFrameStride + 16;   // 1168 dwords per wave (== 16 mod 64)
+constexpr int kBTwspFloats = 256;
+#endif
 constexpr int kBMelVec = kMelARegs / 4;                  // 16-byte loads of filter weights per lane per tile
 
 #ifndef HIPFEAT_S5_PRIO
@@ -143,6 +155,16 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
       for (int n1 = 0; n1 < NROWS; ++n1) sum2 += z[n1];
       float mu = 0.f;
       if (dc) mu = row16_sum(sum2.x + sum2.y) * inv_n;
+#if HIPFEAT_B5
+      // previous sample of the first element of each pair, read from the span (the very first sample of the frame
+      // replicates itself, layers.py:166): no cross-lane chain, fewer live registers
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        const float pvs = n1 == 0 ? x[q == 0 ? 0 : -1] : x[32 * n1 - 1];
+        const v2 d = z[n1] - v2{mu, mu};
+        z[n1] = (d - v2{c, c} * v2{pvs - mu, d.x}) * win[n1];
+      }
+#else
       // previous sample of the first element of each pair: lane q-1's second element; for lane 0 it is
       // lane 15's second element of the previous row (fetched one row earlier with row_ror:1), and the
       // very first sample of the frame replicates itself (layers.py:166)
@@ -154,6 +176,7 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         if (n1 + 1 < NROWS) wrap = dpp_mov<DPP_ROW_ROR1>(d.y);
         z[n1] = (d - v2{c, c} * v2{dp, d.x}) * win[n1];
       }
+#endif
 #pragma unroll
       for (int n1 = NROWS; n1 < 16; ++n1) z[n1] = v2{0.f, 0.f};
       v2 a[16];
@@ -172,16 +195,17 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
       // (q >> 3) == h then read "their" row (all n2) back
       float* exf = myreg + g * kBExFrameStride;
       v2 b[16];
+      constexpr int RPP = 16 / kBExParts;  // rows per part
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < kBExParts; ++h) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) *reinterpret_cast<v2*>(exf + r * kBExRowStride + 2 * q) = a[8 * h + r];
+        for (int r = 0; r < RPP; ++r) *reinterpret_cast<v2*>(exf + r * kBExRowStride + 2 * q) = a[RPP * h + r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if ((q >> 3) == h) {
+        if (q / RPP == h) {
 #pragma unroll
-          for (int n2 = 0; n2 < 16; ++n2) b[n2] = *reinterpret_cast<const v2*>(exf + (q & 7) * kBExRowStride + 2 * n2);
+          for (int n2 = 0; n2 < 16; ++n2) b[n2] = *reinterpret_cast<const v2*>(exf + (q % RPP) * kBExRowStride + 2 * n2);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -193,6 +217,7 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
       float* pown = prow + q;
       float* ppar = prow + ((16 - q) & 15) + (q == 0 ? 16 : 0);
       if (q < 3) prow[257 + q] = 0.f;
+#if !HIPFEAT_B5
       float t1[16];
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
@@ -206,18 +231,28 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         t1[2 * k2] = dpp_shr1_keep(Z[(16 - k2) & 15].x, t1[2 * k2]);
         t1[2 * k2 + 1] = dpp_shr1_keep(Z[(16 - k2) & 15].y, t1[2 * k2 + 1]);
       }
+#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         v2 tw[4], twq[4];  // split-step twiddles of 4 bin pairs per burst
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           tw[r] = ctws[(4 * h + r) * 16 + q];
+#if HIPFEAT_B5
+          twq[r] = swap2(tw[r] * HF_CJ);  // (-w.y, w.x)
+#else
           twq[r] = ctwsp[(4 * h + r) * 16 + q];
+#endif
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k2 = 4 * h + r;
+#if HIPFEAT_B5
+          const v2 m = v2{dpp_shr1_keep(Z[(16 - k2) & 15].x, dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].x)),
+                          dpp_shr1_keep(Z[(16 - k2) & 15].y, dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].y))};
+#else
           const v2 m = v2{t1[2 * k2], t1[2 * k2 + 1]};
+#endif
           const v2 sp = m * HF_CJ + Z[k2];
           const v2 dm = m * HF_NCJ + Z[k2];
           const v2 tt = cmulc(dm, tw[r], twq[r]);
