@@ -218,7 +218,10 @@ class _Plan:
         c["energy_floor"] = cfg.energy_floor
         c["mel_floor"] = mel_floor
         c["log_offset"] = constants.LOG_SPEC_OFFSET
-        c["dither"] = cfg.dither
+        # dither is applied by the host mirror to the packed waveform with the device RNG (torch.randn, exactly what the
+        # reference does, layers.py:189-193); the library itself takes the (dithered) samples
+        self.dither = float(cfg.dither)
+        c["dither"] = 0.0
         cbuf = np.ascontiguousarray(c).reshape(1)
         out = np.zeros(1, dtype=np.uint64)
         self.lib.check(
@@ -236,6 +239,14 @@ class _Plan:
         self.kernel_name = self.lib.string("hipfeat_plan_kernel_name", self.handle)
         self.snip_edges = int(cfg.snip_edges)
 
+    def _dithered(self, wave: torch.Tensor) -> torch.Tensor:
+        """x + dither * N(0, 1) per sample, drawn on the device (Wav2Win.forward, layers.py:189-193).  Never in place:
+        the buffer may be the caller's."""
+        if self.dither == 0.0:
+            return wave
+        with torch.cuda.device(self.device):
+            return torch.randn(wave.shape, device=self.device).mul_(self.dither).add_(wave)
+
     def num_frames(self, num_samples: int) -> int:
         return int(self.lib.raw("hipfeat_num_frames", int(num_samples), self.n, self.shift, self.snip_edges))
 
@@ -250,6 +261,7 @@ class _Plan:
         """wave: float32 tensor on self.device holding every cut; returns the packed
         (sum T_b, F) feature matrix (same device, same stream) and the per-cut frame counts."""
         assert wave.dtype == torch.float32 and wave.is_contiguous() and wave.device == self.device
+        wave = self._dithered(wave)
         lengths = _lib.i64(lengths)
         offsets = _lib.i64(offsets)
         n, shift, snip = self.n, self.shift, self.snip_edges
@@ -282,6 +294,7 @@ class _Plan:
                      pad_value: float) -> Tuple[torch.Tensor, np.ndarray]:
         """As ``run`` but into a dense (B, Tmax, F) tensor whose padding rows hold ``pad_value``."""
         assert wave.dtype == torch.float32 and wave.is_contiguous() and wave.device == self.device
+        wave = self._dithered(wave)
         lengths, offsets = _lib.i64(lengths), _lib.i64(offsets)
         n, shift, snip = self.n, self.shift, self.snip_edges
         frames = self.num_frames_many(lengths)

@@ -128,8 +128,38 @@ def test_too_short_and_errors():
 
     with pytest.raises(HipFeatError):
         make_hip("mfcc", {"use_energy": True}).extract(np.zeros(1600, dtype=np.float32), 16000)
-    with pytest.raises(HipFeatError):
-        make_hip("fbank", {"dither": 1.0}).extract(np.zeros(1600, dtype=np.float32), 16000)
+
+
+def test_dither_is_gaussian_noise_on_the_waveform():
+    """dither draws torch.randn on the device (layers.py:189-193) -- not bit-reproducible across
+    implementations, so the check is statistical: on digital silence the features equal those of unit-variance Gaussian
+    noise scaled by `dither`; the caller's buffer is not modified; torch.manual_seed makes it repeatable."""
+    from _hip import make_hip
+    from oracle.kaldi_ref import RefConfig, RefExtractor
+
+    x = torch.zeros(160000, device="cuda")
+    ex = make_hip("fbank", {"dither": 0.01})
+    assert ex.kernel_name.startswith("fft512b_kernel")
+    torch.manual_seed(3)
+    a = ex.extract(x, 16000)
+    torch.manual_seed(3)
+    b = ex.extract(x, 16000)
+    assert torch.equal(a, b) and float(x.abs().max()) == 0.0  # repeatable, input untouched
+    c = ex.extract(x, 16000)
+    assert not torch.equal(a, c)
+    noise = (np.random.RandomState(0).randn(160000) * 0.01).astype(np.float32)
+    want = RefExtractor(RefConfig(kind="fbank"), np.float64).extract(noise)
+    # per-mel means over 1000 overlapping frames of log-energies: standard error ~ 0.05 for the narrowest filters
+    got = a.cpu().numpy()
+    assert np.abs(got.mean(axis=0) - want.mean(axis=0)).max() < 0.3
+    assert abs(float(got.mean()) - float(want.mean())) < 0.05
+    assert abs(float(got.std()) - float(want.std())) < 0.1
+    # dither 0 on the same extractor type stays exact
+    z = make_hip("fbank", {}).extract(x, 16000)
+    assert torch.all(z == z[0, 0])
+    # host input, batch API
+    outs = ex.extract_batch([np.zeros(16000, dtype=np.float32), np.zeros(8000, dtype=np.float32)], 16000)
+    assert outs[0].shape == (100, 80) and np.isfinite(outs[0]).all() and outs[0].std() > 0.1
 
 
 def test_return_conventions():
