@@ -81,7 +81,8 @@ typedef struct hipfeat_config {
   int32_t num_ceps;         /* C (MFCC only);  0 otherwise                                      */
   int32_t snip_edges;       /* layers.py:747-753                                                */
   int32_t remove_dc_offset; /* layers.py:155-157                                                */
-  int32_t use_energy;       /* layers.py:575-576 (fbank: prepended column), :399-400, :470-471  */
+  int32_t use_energy;       /* layers.py:575-576 (fbank: prepended column), :399-400, :470-471;
+                               MFCC: log-energy replaces C0 (Kaldi; the intent of :721-722)     */
   int32_t raw_energy;       /* layers.py:161 vs :183                                            */
   int32_t use_fft_mag;      /* |X| instead of |X|^2                          layers.py:387-390 */
   int32_t apply_lifter;     /* cepstral_lifter > 0                           layers.py:717     */

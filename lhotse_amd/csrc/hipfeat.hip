@@ -614,9 +614,6 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   if (cfg->kind == HIPFEAT_MFCC) {
     if (cfg->num_ceps <= 0 || !h_dct) return fail(HIPFEAT_ERR_INVALID, "mfcc needs num_ceps>0 and a dct matrix");
     if (cfg->apply_lifter && !h_lifter) return fail(HIPFEAT_ERR_INVALID, "apply_lifter set but lifter is NULL");
-    if (cfg->use_energy)
-      return fail(HIPFEAT_ERR_UNSUPPORTED,
-                  "MFCC with use_energy=True raises in the reference (layers.py:721-722) and is not defined here");
   }
   if (fft > 8192) return fail(HIPFEAT_ERR_UNSUPPORTED, "fft_length %d > 8192 is not supported", fft);
 

@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericParams p) {
       float acc = 0.f;
       for (int m = 0; m < M; ++m) acc = fmaf(mf[m], p.dct[(size_t)m * C + c], acc);
       if (p.flags & F_LIFTER) acc *= p.lifter[c];
+      if (use_e && c == 0) acc = stat[2 * f + 1];  // the log-energy replaces C0 (Kaldi; the intent of layers.py:721-722)
       out[(int64_t)f * p.out_stride + c] = acc;
     }
   }

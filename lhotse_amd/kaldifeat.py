@@ -15,6 +15,7 @@ as Kaldi does), i.e. ``edge_rule="reflect"``.
 
 Options that have no counterpart in the kernels raise ``NotImplementedError`` at construction:
 ``htk_compat=True``, ``use_log_fbank=False``, ``mel_opts.htk_mode=True``, ``mel_opts.debug_mel=True``.
+MFCC ``use_energy=True`` follows Kaldi (the log-energy replaces C0); lhotse's own torch-native layer crashes on it.
 ``vtln_low`` / ``vtln_high`` only act through a VTLN warp factor, which the lhotse wrapper never sets.
 ``chunk_size`` is accepted and ignored (one launch handles any batch).
 """
@@ -282,10 +283,8 @@ class HipKaldifeatMfcc(_HipKaldifeatExtractor):
         c = self.config
         if c.htk_compat:
             raise NotImplementedError("hip-kaldifeat-mfcc: htk_compat=True is not supported by the HIP kernels")
-        if c.use_energy:
-            raise NotImplementedError("hip-kaldifeat-mfcc: use_energy=True is not supported (undefined in lhotse's own Kaldi layers, layers.py:721-722)")
         kw = _frame_kwargs(c.frame_opts, c.mel_opts, self.name)
-        inner = HipMfcc(HipMfccConfig(energy_floor=c.energy_floor, raw_energy=c.raw_energy, num_ceps=c.num_ceps,
+        inner = HipMfcc(HipMfccConfig(use_energy=c.use_energy, energy_floor=c.energy_floor, raw_energy=c.raw_energy, num_ceps=c.num_ceps,
                                        cepstral_lifter=c.cepstral_lifter, device=_device_str(c.device), **kw))
         inner.config.blackman_coeff = c.frame_opts.blackman_coeff
         return inner

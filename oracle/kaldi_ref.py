@@ -305,9 +305,9 @@ class RefExtractor:
         c = self.cfg
         dt = self.dtype.type
         want_e = c.use_energy
-        if c.kind == "mfcc" and want_e:
-            # layers.py:721-722 raises a shape error upstream
-            raise ValueError("Wav2MFCC(use_energy=True) is broken in the reference")
+        # NB Wav2MFCC(use_energy=True) raises a shape error upstream (layers.py:721-722 assigns a (B, T) tensor to
+        # mfcc[:, 0]).  Its evident intent -- and Kaldi's definition (feature-mfcc.cc: the log-energy
+        # replaces C0 after liftering) -- is restated below; this one option has no reference output to pin against.
         y, log_e = preprocess_frames(frames.astype(self.dtype), c, self.window, self.fft, want_e)
         p = self._spec(y)
         if c.kind == "spectrogram":  # layers.py:392-402
@@ -328,6 +328,9 @@ class RefExtractor:
         out = mel @ self.dct  # layers.py:716
         if c.cepstral_lifter > 0:
             out = out * self.lifter
+        if want_e:
+            out = out.copy()
+            out[..., 0] = log_e  # layers.py:721-722 as intended
         return out
 
     def extract(self, x: np.ndarray, padded_len: Optional[int] = None) -> np.ndarray:

@@ -124,10 +124,28 @@ def test_too_short_and_errors():
         ex.extract(np.zeros(1600, dtype=np.float32), 8000)
     with pytest.raises(TypeError):
         ex.extract(np.zeros(1600, dtype=np.float64), 16000)
-    from lhotse_amd._lib import HipFeatError
 
-    with pytest.raises(HipFeatError):
-        make_hip("mfcc", {"use_energy": True}).extract(np.zeros(1600, dtype=np.float32), 16000)
+
+@pytest.mark.parametrize("raw", [True, False])
+def test_mfcc_use_energy_replaces_c0(raw):
+    """MFCC use_energy=True crashes in the reference (layers.py:721-722); defined here as Kaldi does and as
+    that line intends: the log-energy replaces C0, everything else is unchanged."""
+    from _hip import make_hip
+    from oracle.kaldi_ref import RefConfig, RefExtractor
+
+    rng = np.random.RandomState(11)
+    x = rng.rand(24000).astype(np.float32) - 0.5
+    cfg = {"use_energy": True, "raw_energy": raw, "energy_floor": 1e-3}
+    ex = make_hip("mfcc", cfg)
+    assert "generic" in ex.kernel_name
+    got = ex.extract(x, 16000)
+    plain = make_hip("mfcc", {}).extract(x, 16000)
+    want = RefExtractor(RefConfig(kind="mfcc", num_filters=23, **cfg), np.float64).extract(x)
+    assert got.shape == plain.shape == want.shape == (150, 13)
+    assert np.abs(got - want).max() <= 2e-3
+    assert np.abs(got[:, 1:] - plain[:, 1:]).max() <= 2e-3 and np.abs(got[:, 0] - plain[:, 0]).max() > 1.0
+    fb = make_hip("fbank", {"use_energy": True, "raw_energy": raw, "energy_floor": 1e-3, "num_filters": 23}).extract(x, 16000)
+    assert np.abs(got[:, 0] - fb[:, 0]).max() <= 1e-5  # the same log-energy Fbank prepends
 
 
 def test_dither_is_gaussian_noise_on_the_waveform():
