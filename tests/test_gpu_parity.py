@@ -401,3 +401,40 @@ def test_fbank_fast_path_other_filterbanks(cfg):
     o64 = RefExtractor(RefConfig(kind="fbank", **cfg), np.float64)
     for w, o in zip(waves, outs):
         assert_parity(o, o32.extract(w), o64.extract(w), ("fbank-fast", cfg, len(w)))
+
+
+def test_layout_launch_is_hip_graph_capturable():
+    """hipfeat_extract_layout is a pure kernel launch (descriptors already resident, no allocation, no sync), so a
+    fixed-shape batch can be captured into a HIP graph on the caller's stream and replayed on new audio."""
+    from _hip import make_hip
+    from lhotse_amd import _lib
+
+    ex = make_hip("fbank", {})
+    plan = ex.plan
+    L = plan.lib
+    B, S = 64, 48000
+    offs = np.arange(B, dtype=np.int64) * S
+    lens = np.full(B, S, dtype=np.int64)
+    wave = torch.empty(B * S, device="cuda").uniform_(-0.5, 0.5)
+    out = torch.zeros(B * 300, 80, device="cuda")
+    h = np.zeros(1, dtype=np.uint64)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        L.check("hipfeat_layout_create", plan.handle, B, _lib.addr(offs), _lib.addr(lens), None, None, 80, side.cuda_stream, _lib.addr(h))
+        layout = int(h[0])
+        L.check("hipfeat_extract_layout", plan.handle, layout, wave.data_ptr(), out.data_ptr(), side.cuda_stream)  # warm-up
+    side.synchronize()
+    want1 = out.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        L.check("hipfeat_extract_layout", plan.handle, layout, wave.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want1)
+    wave.uniform_(-0.25, 0.25)  # new audio in the same buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    ref, _ = plan.run(wave, offs, lens, None)
+    assert torch.equal(out, ref) and not torch.equal(out, want1)
+    L.check("hipfeat_layout_destroy", layout)
