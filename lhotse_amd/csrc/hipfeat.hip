@@ -675,18 +675,31 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
     if (cfg->apply_lifter && (st = upload(&p->d_lifter, h_lifter, (size_t)C)) != HIPFEAT_OK) return bail(st);
   }
 
-  // LDS carve-up of the generic kernel; shrink frames-per-block until it fits 160 KiB
-  for (p->fpb = 8; p->fpb >= 1; p->fpb >>= 1) {
+  // LDS carve-up of the generic kernel.  Frames per workgroup: the largest of 8/4/2 whose footprint stays <= 21 KB
+  // (7-8 workgroups = full wave occupancy per CU); large FFTs that cannot get there take 2 frames if that fits 64 KB,
+  // else 1.  Measured on MI355X (cuts/s of 10 s cuts): fft 512: 8 -> 4 frames 373 k -> 458 k; fft 1024: 8 -> 2 frames
+  // 117 k -> 209 k; fft 2048: 8 -> 2 frames 30 k -> 67 k (1 frame: 59 k).
+  auto carve = [&](int fpb) {
     auto al = [](int v) { return (v + 3) & ~3; };
-    p->span = (p->fpb - 1) * shift + N;
+    p->fpb = fpb;
+    p->span = (fpb - 1) * shift + N;
     p->off_z = al(p->span);
-    p->off_p = p->off_z + al(p->fpb * fft);
-    p->off_tw = p->off_p + al(p->fpb * p->K);
+    p->off_p = p->off_z + al(fpb * fft);
+    p->off_tw = p->off_p + al(fpb * p->K);
     p->off_stat = p->off_tw + (p->pow2 ? al(2 * std::max(p->H, 1)) : 0);
-    p->off_mel = p->off_stat + al(2 * p->fpb);
-    const int end = p->off_mel + al(p->fpb * std::max(M, 1));
+    p->off_mel = p->off_stat + al(2 * fpb);
+    const int end = p->off_mel + al(fpb * std::max(M, 1));
     p->lds_bytes = (size_t)end * sizeof(float);
-    if (p->lds_bytes <= 160 * 1024) break;
+    return p->lds_bytes;
+  };
+  {
+    size_t cap = 21 * 1024;
+    if (const char* kb = getenv("HIPFEAT_GENERIC_LDS_KB")) cap = (size_t)std::max(8, atoi(kb)) * 1024;  // experiments
+    int pick = 0;
+    for (int fpb = 8; fpb >= 2 && !pick; fpb >>= 1)
+      if (carve(fpb) <= cap) pick = fpb;
+    if (!pick) pick = carve(2) <= 64 * 1024 ? 2 : 1;
+    if (carve(pick) > 160 * 1024) p->fpb = 0;
   }
   if (p->fpb < 1) return bail(fail(HIPFEAT_ERR_UNSUPPORTED, "configuration does not fit in LDS"));
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_kernel),
