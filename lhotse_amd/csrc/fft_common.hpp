@@ -85,6 +85,28 @@ __device__ __forceinline__ void fft16(const v2 (&x)[16], v2 (&X)[16]) {
   }
 }
 
+// 8-point complex FFT in registers (radix-4 x radix-2, natural order in and out)
+__device__ __forceinline__ void fft8(const v2* x, v2* X) {
+  constexpr float R2 = 0.70710678118654752f;
+  v2 e[4], o[4];
+  {
+    const v2 s0 = x[0] + x[4], s1 = x[0] - x[4], s2 = x[2] + x[6], u3 = swap2(x[2] - x[6]);
+    e[0] = s0 + s2, e[2] = s0 - s2, e[1] = u3 * HF_CJ + s1, e[3] = u3 * HF_NCJ + s1;
+  }
+  {
+    const v2 s0 = x[1] + x[5], s1 = x[1] - x[5], s2 = x[3] + x[7], u3 = swap2(x[3] - x[7]);
+    o[0] = s0 + s2, o[2] = s0 - s2, o[1] = u3 * HF_CJ + s1, o[3] = u3 * HF_NCJ + s1;
+  }
+  o[1] = cmulc(o[1], v2{R2, -R2}, v2{R2, R2});    // W8^1
+  o[2] = rot_mi(o[2]);                            // W8^2 = -i
+  o[3] = cmulc(o[3], v2{-R2, -R2}, v2{R2, -R2});  // W8^3
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    X[k] = e[k] + o[k];
+    X[k + 4] = e[k] - o[k];
+  }
+}
+
 // natural log of a normal positive float: v_log_f32 (log2, 1 ulp) times ln 2.  The argument is
 // >= mel_floor (1.19e-7), so the denormal path of the library logf is never needed.
 __device__ __forceinline__ float fast_log(float x) {

@@ -20,6 +20,7 @@
 #include "kernel_resample.hpp"
 #include "kernel_whisper.hpp"
 #include "kernel_fft256.hpp"
+#include "kernel_wave.hpp"
 
 using namespace hipfeat;
 
@@ -102,6 +103,10 @@ struct hipfeat_plan {
   float* d_lds_consts = nullptr;
   float* d_mel_a = nullptr;
   WaveWork* d_work = nullptr;
+  // wave-per-frame kernel (variant 5)
+  float* d_mel_t = nullptr;
+  int mel_maxband = 0;
+  size_t wave_lds_bytes = 0;
   // whisper fast path (variant 3)
   float* d_wh_dft = nullptr;
   float* d_wh_mel = nullptr;
@@ -198,6 +203,7 @@ static void plan_free(hipfeat_plan* p) {
   (void)hipFree(p->d_dct_consts);
   (void)hipFree(p->d_mel_a);
   (void)hipFree(p->d_work);
+  (void)hipFree(p->d_mel_t);
   (void)hipFree(p->d_wh_dft);
   (void)hipFree(p->d_wh_mel);
   for (auto& s : p->slots) {
@@ -508,6 +514,56 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
 }
 
 // --------------------------------------------------------------------------------------
+// wave-per-frame kernel (kernel_wave.hpp): power-of-two fft 256 .. 2048 without a specialised kernel
+// --------------------------------------------------------------------------------------
+template <int N1>
+static const void* wave_entry() {
+  return reinterpret_cast<const void*>(&wave_kernel<N1>);
+}
+
+static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
+  const hipfeat_config& c = p->cfg;
+  if (p->variant != 0 || !p->pow2 || c.kind > HIPFEAT_MFCC || getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_KERNEL")) return HIPFEAT_OK;
+  const int H = p->H;
+  if (!(H == 128 || H == 256 || H == 512 || H == 1024) || c.frame_length > 64 * kWaveMaxRegs || c.num_filters > 128) return HIPFEAT_OK;
+  const bool need_mel = c.kind == HIPFEAT_FBANK || c.kind == HIPFEAT_MFCC;
+  const int M = need_mel ? c.num_filters : 0;
+  hipfeat_status st;
+  if (need_mel) {
+    int maxband = 1;
+    std::vector<int2> rng(M);
+    for (int j = 0; j < M; ++j) {
+      int lo = p->K, hi = 0;
+      for (int k = 0; k < p->K; ++k)
+        if (h_mel[(size_t)k * M + j] != 0.0f) {
+          lo = std::min(lo, k);
+          hi = std::max(hi, k + 1);
+        }
+      if (hi == 0) lo = 0;
+      rng[j] = make_int2(lo, hi);
+      maxband = std::max(maxband, hi - lo);
+    }
+    std::vector<float> mt((size_t)maxband * M, 0.0f);  // mel_t[t][j] = W[lo_j + t][j]
+    for (int j = 0; j < M; ++j)
+      for (int k = rng[j].x; k < rng[j].y; ++k) mt[(size_t)(k - rng[j].x) * M + j] = h_mel[(size_t)k * M + j];
+    if ((st = upload(&p->d_mel_t, mt.data(), mt.size())) != HIPFEAT_OK) return st;
+    p->mel_maxband = maxband;
+  }
+  p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)2 * H + 8)) * sizeof(float);
+  const void* fn = H == 128 ? wave_entry<2>() : (H == 256 ? wave_entry<4>() : (H == 512 ? wave_entry<8>() : wave_entry<16>()));
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->wave_lds_bytes);
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(wave) failed: %s", hipGetErrorName(e));
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, p->wave_lds_bytes) == hipSuccess) p->blocks_per_cu = nb;
+  char nm[96];
+  snprintf(nm, sizeof(nm), "wave_kernel<%d> fft=%d lds=%zuB blocks/CU=%d", H / 64, c.fft_length, p->wave_lds_bytes, p->blocks_per_cu);
+  p->kernel_name = nm;
+  p->variant = 5;
+  p->fpb = 16;  // 4 waves x 4 frames
+  return HIPFEAT_OK;
+}
+
+// --------------------------------------------------------------------------------------
 // whisper fast path: DFT-400 and mel operands in MFMA lane order (kernel_whisper.hpp)
 // --------------------------------------------------------------------------------------
 static hipfeat_status setup_whisper(hipfeat_plan* p, const float* h_mel) {
@@ -712,6 +768,8 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   if (st != HIPFEAT_OK) return bail(st);
   st = setup_fft256(p, h_window, h_mel, h_dct, h_lifter);
   if (st != HIPFEAT_OK) return bail(st);
+  st = setup_wave(p, h_mel);
+  if (st != HIPFEAT_OK) return bail(st);
 
   *out = p;
   return HIPFEAT_OK;
@@ -847,6 +905,47 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
   if (lay->fpb != plan->fpb || lay->device != plan->device)
     return fail(HIPFEAT_ERR_INVALID, "layout was created for a different plan");
   const hipfeat_config& c = plan->cfg;
+  if (plan->variant == 5) {
+    WaveParams wp{};
+    wp.wave = d_wave;
+    wp.out = d_out;
+    wp.cuts = lay->d_cuts;
+    wp.window = plan->d_window;
+    wp.tw = plan->d_tw;
+    wp.mel_t = plan->d_mel_t;
+    wp.mel_range = plan->d_mel_range;
+    wp.dct = plan->d_dct;
+    wp.lifter = plan->d_lifter;
+    wp.out_stride = lay->out_row_stride;
+    wp.num_cuts = (int32_t)lay->batch;
+    wp.uniform_bpc = lay->uniform_bpc;
+    wp.frames_per_wave = plan->fpb / 4;
+    wp.N = c.frame_length;
+    wp.shift = c.frame_shift;
+    wp.H = plan->H;
+    wp.K = plan->K;
+    wp.M = c.num_filters;
+    wp.C = c.num_ceps;
+    wp.maxband = plan->mel_maxband;
+    wp.kind = c.kind;
+    wp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0) | (c.use_energy ? F_USE_ENERGY : 0) | (c.raw_energy ? F_RAW_ENERGY : 0) |
+               (c.use_fft_mag ? F_FFT_MAG : 0) | (c.apply_lifter ? F_LIFTER : 0);
+    wp.npad_left = plan->npad_left;
+    wp.preemph = c.preemph_coeff;
+    wp.log_energy_floor = c.energy_floor > 0.0f ? logf(c.energy_floor) : -INFINITY;
+    wp.mel_floor = c.mel_floor;
+    wp.log_offset = c.log_offset;
+    DeviceGuard g(plan->device);
+    const dim3 grid((unsigned)lay->total_blocks), block(256);
+    switch (plan->H >> 6) {
+      case 2: hipLaunchKernelGGL(wave_kernel<2>, grid, block, plan->wave_lds_bytes, stream, wp); break;
+      case 4: hipLaunchKernelGGL(wave_kernel<4>, grid, block, plan->wave_lds_bytes, stream, wp); break;
+      case 8: hipLaunchKernelGGL(wave_kernel<8>, grid, block, plan->wave_lds_bytes, stream, wp); break;
+      default: hipLaunchKernelGGL(wave_kernel<16>, grid, block, plan->wave_lds_bytes, stream, wp); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return HIPFEAT_OK;
+  }
   if (plan->variant == 3) {
     WhisperParams wp{};
     wp.wave = d_wave;

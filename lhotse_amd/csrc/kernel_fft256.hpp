@@ -41,28 +41,6 @@ __device__ __forceinline__ float row8i_negate_index(float keep, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, m), DPP_ROW_SHR2, 0xF, 0xF, false));
 }
 
-// 8-point complex FFT in registers (radix-4 x radix-2, natural order in and out)
-__device__ __forceinline__ void fft8(const v2* x, v2* X) {
-  constexpr float R2 = 0.70710678118654752f;
-  v2 e[4], o[4];
-  {
-    const v2 s0 = x[0] + x[4], s1 = x[0] - x[4], s2 = x[2] + x[6], u3 = swap2(x[2] - x[6]);
-    e[0] = s0 + s2, e[2] = s0 - s2, e[1] = u3 * HF_CJ + s1, e[3] = u3 * HF_NCJ + s1;
-  }
-  {
-    const v2 s0 = x[1] + x[5], s1 = x[1] - x[5], s2 = x[3] + x[7], u3 = swap2(x[3] - x[7]);
-    o[0] = s0 + s2, o[2] = s0 - s2, o[1] = u3 * HF_CJ + s1, o[3] = u3 * HF_NCJ + s1;
-  }
-  o[1] = cmulc(o[1], v2{R2, -R2}, v2{R2, R2});    // W8^1
-  o[2] = rot_mi(o[2]);                            // W8^2 = -i
-  o[3] = cmulc(o[3], v2{-R2, -R2}, v2{R2, -R2});  // W8^3
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    X[k] = e[k] + o[k];
-    X[k + 4] = e[k] - o[k];
-  }
-}
-
 // OUT = 0 fbank, 1 MFCC, 2 (log-)spectrogram -- see kernel_fft512b.hpp
 template <int NROWS, int OUT>
 __global__ __launch_bounds__(256, 5) void fft256_kernel(const Fft512Params p) {

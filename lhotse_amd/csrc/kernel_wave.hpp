@@ -1,0 +1,319 @@
+// "Wave per frame" kernel: every power-of-two FFT size from 256 to 2048 (complex size H = 128 .. 1024) that has no
+// specialised kernel -- 22.05 / 24 / 32 kHz (fft 1024) and 44.1 / 48 kHz (fft 2048) with 25 ms frames, and any option the
+// fast paths do not take (energy columns, magnitude spectra ...).  All four feature kinds.
+//
+// One WAVE owns one frame at a time and never synchronises with the rest of its workgroup (the only __syncthreads is
+// after the twiddle table load): samples come straight from global memory (coalesced, reflected at the cut edges,
+// overlapping frames hit L1/L2), the DC mean / log-energy are wave reductions, the windowed frame goes to a wave-private
+// LDS buffer as H complex numbers, the complex FFT runs as three register passes H = N1 x 8 x 8 (N1 = H/64 = 2..16,
+// two transposes through the same buffer with wave-level barriers), the split step and |X|^2 overwrite the buffer with
+// the power row, and the mel filterbank / DCT are lane-per-output dot products over a COMPACT band table
+// (mel_t[t][j] = weight of filter j at bin lo_j + t: coalesced across lanes for every t).
+//
+// Replaces, for these sizes, the workgroup-wide radix-2 passes of kernel_generic.hpp (11 barrier-separated LDS sweeps at
+// fft 2048, one workgroup per CU): measured in DESIGN.md section 4.2.
+#pragma once
+#include "common.hpp"
+#include "fft_common.hpp"
+
+namespace hipfeat {
+
+struct WaveParams {
+  const float* wave;
+  float* out;
+  const CutDesc* cuts;
+  const float* window;    // [N]
+  const float2* tw;       // W_2H^k, k < H
+  const float* mel_t;     // [maxband][M] compact filterbank
+  const int2* mel_range;  // [M] first bin, one-past-last bin
+  const float* dct;       // [M][C]
+  const float* lifter;    // [C]
+  int64_t out_stride;
+  int32_t num_cuts, uniform_bpc, frames_per_wave;
+  int32_t N, shift, H, K, M, C, maxband;
+  int32_t kind, flags, npad_left;
+  float preemph, log_energy_floor, mel_floor, log_offset;
+};
+
+__device__ __forceinline__ v2 twiddle_h(const float2* __restrict__ tw, int m, int H) {  // W_H^m, 0 <= m < H, from W_2H^k (k < H)
+  int t = 2 * m;
+  const bool neg = t >= H;
+  t -= neg ? H : 0;
+  const float2 w = tw[t];
+  return neg ? v2{-w.x, -w.y} : v2{w.x, w.y};
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int N1>
+__device__ __forceinline__ void small_fft(const v2* x, v2* X) {
+  if constexpr (N1 == 16) {
+    v2 a[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = x[i];
+    fft16(a, b);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) X[i] = b[i];
+  } else if constexpr (N1 == 8) {
+    fft8(x, X);
+  } else if constexpr (N1 == 4) {
+    const v2 s0 = x[0] + x[2], s1 = x[0] - x[2], s2 = x[1] + x[3], u3 = swap2(x[1] - x[3]);
+    X[0] = s0 + s2, X[2] = s0 - s2, X[1] = u3 * HF_CJ + s1, X[3] = u3 * HF_NCJ + s1;
+  } else {
+    X[0] = x[0] + x[1], X[1] = x[0] - x[1];
+  }
+}
+
+// Complex FFT of size H = N1 * 8 * 8 of one frame by one wave, in place in LDS, natural order in and out:
+//   n = 64 n1 + 8 n2 + n3,  k = k1 + N1 k2 + 8 N1 k3
+//   pass A  FFT_N1 over n1 (lane = (n2, n3)),      twiddle W_H^(8 n2 k1)
+//   pass B  FFT_8  over n2 (item = (k1, n3)),      twiddle W_H^(n3 (k1 + N1 k2))
+//   pass C  FFT_8  over n3 (item = (k1, k2))
+template <int N1>
+__device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw, int lane) {
+  constexpr int H = 64 * N1;
+  {
+    v2 x[N1], A[N1];
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) x[n1] = zf[64 * n1 + lane];
+    small_fft<N1>(x, A);
+    const int n2 = lane >> 3;
+#pragma unroll
+    for (int k1 = 1; k1 < N1; ++k1) A[k1] = cmul(A[k1], twiddle_h(tw, 8 * n2 * k1, H));
+#pragma unroll
+    for (int k1 = 0; k1 < N1; ++k1) zf[64 * k1 + lane] = A[k1];
+  }
+  wave_lds_sync();
+  constexpr int ITEMS = 8 * N1, ROUNDS = (ITEMS + 63) / 64;
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {  // pass B, in place (an item re-writes exactly the column it read)
+    const int it = lane + 64 * r;
+    if (it < ITEMS) {
+      const int k1 = it >> 3, n3 = it & 7;
+      v2 x[8], B[8];
+#pragma unroll
+      for (int n2 = 0; n2 < 8; ++n2) x[n2] = zf[64 * k1 + 8 * n2 + n3];
+      fft8(x, B);
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        B[k2] = cmul(B[k2], twiddle_h(tw, n3 * (k1 + N1 * k2), H));
+        zf[64 * k1 + 8 * k2 + n3] = B[k2];
+      }
+    }
+  }
+  wave_lds_sync();
+  {
+    v2 X[ROUNDS][8];  // pass C: all reads, barrier, then natural-order writes
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int it = lane + 64 * r;
+      if (it < ITEMS) {
+        const int k1 = it >> 3, k2 = it & 7;
+        v2 x[8];
+#pragma unroll
+        for (int n3 = 0; n3 < 8; ++n3) x[n3] = zf[64 * k1 + 8 * k2 + n3];
+        fft8(x, X[r]);
+      }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int it = lane + 64 * r;
+      if (it < ITEMS) {
+        const int k1 = it >> 3, k2 = it & 7;
+#pragma unroll
+        for (int k3 = 0; k3 < 8; ++k3) zf[k1 + N1 * k2 + 8 * N1 * k3] = X[r][k3];
+      }
+    }
+  }
+  wave_lds_sync();
+}
+
+constexpr int kWaveMaxRegs = 20;  // ceil(N / 64) sample registers per lane: N <= 1280
+
+template <int N1>
+__global__ __launch_bounds__(256, (N1 == 16 ? 2 : 4)) void wave_kernel(const WaveParams p) {
+  constexpr int H = 64 * N1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float2* tw = reinterpret_cast<float2*>(smem);                  // [H]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* buf = smem + 2 * H + wv * (2 * H + 8);                  // wave-private: H complex, later the power row
+  v2* zf = reinterpret_cast<v2*>(buf);
+
+  const int blk = blockIdx.x;
+  int cut, fb;
+  if (p.uniform_bpc > 0) {
+    cut = blk / p.uniform_bpc;
+    fb = blk - cut * p.uniform_bpc;
+  } else {
+    cut = find_cut(p.cuts, p.num_cuts, blk);
+    fb = blk - p.cuts[cut].first_block;
+  }
+  const CutDesc cd = p.cuts[cut];
+  const float* __restrict__ w = p.wave + cd.wave_off;
+  for (int i = tid; i < H; i += 256) tw[i] = p.tw[i];
+  __syncthreads();
+
+  const int N = p.N, K = p.K, M = p.M;
+  const int nreg = (N + 63) >> 6;
+  const bool use_e = (p.flags & F_USE_ENERGY) != 0;
+  const int fbase = fb * 4 * p.frames_per_wave;
+#pragma unroll 1
+  for (int i = 0; i < p.frames_per_wave; ++i) {
+    const int f = fbase + 4 * i + wv;
+    if (f >= cd.num_frames) break;
+    const int64_t j0 = (int64_t)f * p.shift - p.npad_left;
+
+    // ---- samples, DC mean, raw log-energy (layers.py:155-162) ------------------------------------------------------
+    constexpr int NREG = 2 * N1 < kWaveMaxRegs ? 2 * N1 : kWaveMaxRegs;  // N <= fft = 128 N1
+    float x[NREG];
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      const int m = lane + 64 * r;
+      x[r] = (r < nreg && m < N) ? load_sample(w, j0 + m, cd.num_samples, cd.padded_len) : 0.f;
+      s += x[r];
+    }
+    float mean = 0.f;
+    if (p.flags & F_REMOVE_DC) mean = wave_sum(s) / (float)N;
+    float log_e = 0.f;
+    if (use_e && (p.flags & F_RAW_ENERGY)) {
+      float e = 0.f;
+#pragma unroll
+      for (int r = 0; r < NREG; ++r) {
+        const int m = lane + 64 * r;
+        const float d = (r < nreg && m < N) ? x[r] - mean : 0.f;
+        e = fmaf(d, d, e);
+      }
+      log_e = fmaxf(logf(wave_sum(e) + 1e-15f), p.log_energy_floor);
+    }
+    // d = x - mean into the buffer (as floats), then y[m] = (d[m] - c d[max(m-1, 0)]) w[m], zero padded to 2H
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) {
+      const int m = lane + 64 * r;
+      if (r < nreg && m < N) buf[m] = x[r] - mean;
+    }
+    wave_lds_sync();
+    {
+      v2 y[2 * N1];  // z[n] = (y[2n], y[2n+1]) for n = lane + 64 q
+      float e = 0.f;
+#pragma unroll
+      for (int q = 0; q < N1; ++q) {
+        const int n = lane + 64 * q, m0 = 2 * n;
+        v2 v = {0.f, 0.f};
+        if (m0 < N) {
+          const float d0 = buf[m0], dm = buf[m0 > 0 ? m0 - 1 : 0];
+          v.x = (d0 - p.preemph * dm) * p.window[m0];
+          if (m0 + 1 < N) v.y = (buf[m0 + 1] - p.preemph * d0) * p.window[m0 + 1];
+        }
+        y[q] = v;
+        e = fmaf(v.x, v.x, fmaf(v.y, v.y, e));
+      }
+      if (use_e && !(p.flags & F_RAW_ENERGY)) log_e = fmaxf(logf(wave_sum(e) + 1e-15f), p.log_energy_floor);  // layers.py:183-185
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < N1; ++q) zf[lane + 64 * q] = y[q];
+    }
+    wave_lds_sync();
+
+    // ---- complex FFT, split step X[k] = E[k] + W_2H^k O[k], power (layers.py:32-42) --------------------------------
+    fft3_frame<N1>(zf, tw, lane);
+    {
+      float pw[N1 + 1];
+#pragma unroll
+      for (int q = 0; q <= N1; ++q) {
+        const int k = lane + 64 * q;
+        pw[q] = 0.f;
+        if (k < K) {
+          const v2 a = zf[k & (H - 1)], b = zf[(H - k) & (H - 1)];
+          const float ex = 0.5f * (a.x + b.x), ey = 0.5f * (a.y - b.y);
+          const float ox = 0.5f * (a.y + b.y), oy = -0.5f * (a.x - b.x);
+          const float2 wk = (k < H) ? tw[k] : make_float2(-1.f, 0.f);
+          const float xr = ex + (wk.x * ox - wk.y * oy);
+          const float xi = ey + (wk.x * oy + wk.y * ox);
+          float v = xr * xr + xi * xi;
+          if (p.flags & F_FFT_MAG) v = sqrtf(v);
+          pw[q] = v;
+        }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q <= N1; ++q) {
+        const int k = lane + 64 * q;
+        if (k < K) buf[k] = pw[q];
+      }
+    }
+    wave_lds_sync();
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    float* __restrict__ orow = p.out + (cd.out_row + f) * p.out_stride;
+    if (p.kind == 0 || p.kind == 1) {
+      for (int k = lane; k < K; k += 64) {
+        float v = buf[k];
+        if (p.kind == 1) v = logf(v + p.log_offset);
+        if (use_e && k == 0) v = log_e;
+        orow[k] = v;
+      }
+    } else {
+      const int ecol = (p.kind == 2 && use_e) ? 1 : 0;
+      // mel: FOUR lanes per filter (16 consecutive filters per round, similar band widths): lane (jj, sub) sums the
+      // taps t = sub, sub + 4, ... of filter j; two DPP adds combine the quarters.  Serial depth = band / 4.
+      const int jj = lane >> 2, sub = lane & 3;
+      for (int j0m = 0; j0m < M; j0m += 16) {
+        const int j = j0m + jj;
+        float acc = 0.f;
+        if (j < M) {
+          const int2 rg = p.mel_range[j];
+          const int len = rg.y - rg.x;
+          const float* __restrict__ mt = p.mel_t + j;
+          const float* pb = buf + rg.x;
+#pragma unroll 4
+          for (int t = sub; t < len; t += 4) acc = fmaf(pb[t], mt[(size_t)t * M], acc);
+        }
+        acc += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(acc);
+        acc += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(acc);
+        if (j < M && sub == 0) {
+          const float v = logf(fmaxf(acc, p.mel_floor));
+          if (p.kind == 2) orow[ecol + j] = v;
+          else buf[2 * H - 120 + j] = v;  // MFCC: log-mel vector stashed behind the power row (K = H + 1 <= 2H - 120, M <= 128)
+        }
+      }
+      if (p.kind == 2) {
+        if (ecol && lane == 0) orow[0] = log_e;
+      } else {
+        wave_lds_sync();
+        const float* lmv = buf + 2 * H - 120;  // log-mel vector [M <= 128]
+        const int cc = lane >> 2;              // DCT: four lanes per cepstrum as well
+        for (int c0 = 0; c0 < p.C; c0 += 16) {
+          const int c = c0 + cc;
+          float acc = 0.f;
+          if (c < p.C) {
+#pragma unroll 4
+            for (int m = sub; m < M; m += 4) acc = fmaf(lmv[m], p.dct[(size_t)m * p.C + c], acc);
+          }
+          acc += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(acc);
+          acc += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(acc);
+          if (c < p.C && sub == 0) {
+            if (p.flags & F_LIFTER) acc *= p.lifter[c];
+            if (use_e && c == 0) acc = log_e;
+            orow[c] = acc;
+          }
+        }
+      }
+    }
+    wave_lds_sync();  // the buffer is reused by the next frame
+  }
+}
+
+}  // namespace hipfeat

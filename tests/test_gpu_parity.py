@@ -137,7 +137,7 @@ def test_mfcc_use_energy_replaces_c0(raw):
     x = rng.rand(24000).astype(np.float32) - 0.5
     cfg = {"use_energy": True, "raw_energy": raw, "energy_floor": 1e-3}
     ex = make_hip("mfcc", cfg)
-    assert "generic" in ex.kernel_name
+    assert "wave_kernel" in ex.kernel_name or "generic" in ex.kernel_name
     got = ex.extract(x, 16000)
     plain = make_hip("mfcc", {}).extract(x, 16000)
     want = RefExtractor(RefConfig(kind="mfcc", num_filters=23, **cfg), np.float64).extract(x)
