@@ -549,7 +549,7 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
     if ((st = upload(&p->d_mel_t, mt.data(), mt.size())) != HIPFEAT_OK) return st;
     p->mel_maxband = maxband;
   }
-  p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)2 * H + 8)) * sizeof(float);
+  p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)144 * (H / 64) + 8)) * sizeof(float);  // twiddles + 4 padded wave buffers
   const void* fn = H == 128 ? wave_entry<2>() : (H == 256 ? wave_entry<4>() : (H == 512 ? wave_entry<8>() : wave_entry<16>()));
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->wave_lds_bytes);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(wave) failed: %s", hipGetErrorName(e));

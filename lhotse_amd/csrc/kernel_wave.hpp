@@ -79,19 +79,25 @@ __device__ __forceinline__ void small_fft(const v2* x, v2* X) {
 //   pass A  FFT_N1 over n1 (lane = (n2, n3)),      twiddle W_H^(8 n2 k1)
 //   pass B  FFT_8  over n2 (item = (k1, n3)),      twiddle W_H^(n3 (k1 + N1 k2))
 //   pass C  FFT_8  over n3 (item = (k1, k2))
+// While the three passes run, element e = 64 n1 + 8 n2 + n3 lives at e + (e >> 3) = 72 n1 + 9 n2 + n3: with these strides
+// the 8-byte accesses of passes B and C are bank-conflict free (unpadded, eight lanes share a bank pair: measured 45 % of
+// the LDS cycles were conflicts).  The caller stores its input with fft3_pad() and gets natural order back.
+__device__ __forceinline__ int fft3_pad(int e) { return e + (e >> 3); }
+
 template <int N1>
 __device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw, int lane) {
   constexpr int H = 64 * N1;
+  const int lp = lane + (lane >> 3);  // 9 n2 + n3
   {
     v2 x[N1], A[N1];
 #pragma unroll
-    for (int n1 = 0; n1 < N1; ++n1) x[n1] = zf[64 * n1 + lane];
+    for (int n1 = 0; n1 < N1; ++n1) x[n1] = zf[72 * n1 + lp];
     small_fft<N1>(x, A);
     const int n2 = lane >> 3;
 #pragma unroll
     for (int k1 = 1; k1 < N1; ++k1) A[k1] = cmul(A[k1], twiddle_h(tw, 8 * n2 * k1, H));
 #pragma unroll
-    for (int k1 = 0; k1 < N1; ++k1) zf[64 * k1 + lane] = A[k1];
+    for (int k1 = 0; k1 < N1; ++k1) zf[72 * k1 + lp] = A[k1];
   }
   wave_lds_sync();
   constexpr int ITEMS = 8 * N1, ROUNDS = (ITEMS + 63) / 64;
@@ -102,12 +108,12 @@ __device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw
       const int k1 = it >> 3, n3 = it & 7;
       v2 x[8], B[8];
 #pragma unroll
-      for (int n2 = 0; n2 < 8; ++n2) x[n2] = zf[64 * k1 + 8 * n2 + n3];
+      for (int n2 = 0; n2 < 8; ++n2) x[n2] = zf[72 * k1 + 9 * n2 + n3];
       fft8(x, B);
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
         B[k2] = cmul(B[k2], twiddle_h(tw, n3 * (k1 + N1 * k2), H));
-        zf[64 * k1 + 8 * k2 + n3] = B[k2];
+        zf[72 * k1 + 9 * k2 + n3] = B[k2];
       }
     }
   }
@@ -121,7 +127,7 @@ __device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw
         const int k1 = it >> 3, k2 = it & 7;
         v2 x[8];
 #pragma unroll
-        for (int n3 = 0; n3 < 8; ++n3) x[n3] = zf[64 * k1 + 8 * k2 + n3];
+        for (int n3 = 0; n3 < 8; ++n3) x[n3] = zf[72 * k1 + 9 * k2 + n3];
         fft8(x, X[r]);
       }
     }
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : 4)) void wave_kernel(const Wav
   float2* tw = reinterpret_cast<float2*>(smem);                  // [H]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* buf = smem + 2 * H + wv * (2 * H + 8);                  // wave-private: H complex, later the power row
+  float* buf = smem + 2 * H + wv * (144 * N1 + 8);               // wave-private: 72 N1 complex (padded FFT buffer), later the power row
   v2* zf = reinterpret_cast<v2*>(buf);
 
   const int blk = blockIdx.x;
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : 4)) void wave_kernel(const Wav
       if (use_e && !(p.flags & F_RAW_ENERGY)) log_e = fmaxf(logf(wave_sum(e) + 1e-15f), p.log_energy_floor);  // layers.py:183-185
       wave_lds_sync();
 #pragma unroll
-      for (int q = 0; q < N1; ++q) zf[lane + 64 * q] = y[q];
+      for (int q = 0; q < N1; ++q) zf[fft3_pad(lane + 64 * q)] = y[q];
     }
     wave_lds_sync();
 
