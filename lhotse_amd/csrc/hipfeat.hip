@@ -311,7 +311,7 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
   const bool mfcc = c.kind == HIPFEAT_MFCC;
   const bool spec = c.kind == HIPFEAT_SPECTROGRAM || c.kind == HIPFEAT_LOG_SPECTROGRAM;
-  if (c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || (!spec && c.use_fft_mag)) return HIPFEAT_OK;
+  if (c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || (!spec && c.use_fft_mag) || getenv("HIPFEAT_NO_FAST")) return HIPFEAT_OK;
   if (mfcc && (M > 8 * kMaxDctGroups || c.num_ceps > 64)) return HIPFEAT_OK;
   const int need = (N + 31) / 32;
   const int nrows = need <= 10 ? 10 : (need <= 13 ? 13 : 16);
@@ -429,7 +429,7 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
   const bool mfcc = c.kind == HIPFEAT_MFCC;
   const bool spec = c.kind == HIPFEAT_SPECTROGRAM || c.kind == HIPFEAT_LOG_SPECTROGRAM;
   if (c.kind > HIPFEAT_MFCC || c.fft_length != 256 || (shift & 1) || N < 16 || c.use_energy || (!spec && c.use_fft_mag) ||
-      getenv("HIPFEAT_FORCE_GENERIC"))
+      getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_FAST"))
     return HIPFEAT_OK;
   if (mfcc && (M > 8 * kMaxDctGroups || c.num_ceps > 64)) return HIPFEAT_OK;
   const int need = (N + 15) / 16;
@@ -525,7 +525,8 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
   const hipfeat_config& c = p->cfg;
   if (p->variant != 0 || !p->pow2 || c.kind > HIPFEAT_MFCC || getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_KERNEL")) return HIPFEAT_OK;
   const int H = p->H;
-  if (!(H == 128 || H == 256 || H == 512 || H == 1024) || c.frame_length > 64 * kWaveMaxRegs || c.num_filters > 128) return HIPFEAT_OK;
+  // H = 128 (fft 256) stays on the radix-2 kernel: measured 0.92 M vs 0.72 M cuts/s there; H = 256: 0.46 vs 0.48 M
+  if (!(H == 256 || H == 512 || H == 1024) || c.frame_length > 64 * kWaveMaxRegs || c.num_filters > 128) return HIPFEAT_OK;
   const bool need_mel = c.kind == HIPFEAT_FBANK || c.kind == HIPFEAT_MFCC;
   const int M = need_mel ? c.num_filters : 0;
   hipfeat_status st;
@@ -550,7 +551,7 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
     p->mel_maxband = maxband;
   }
   p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)144 * (H / 64) + 8)) * sizeof(float);  // twiddles + 4 padded wave buffers
-  const void* fn = H == 128 ? wave_entry<2>() : (H == 256 ? wave_entry<4>() : (H == 512 ? wave_entry<8>() : wave_entry<16>()));
+  const void* fn = H == 256 ? wave_entry<4>() : (H == 512 ? wave_entry<8>() : wave_entry<16>());
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->wave_lds_bytes);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(wave) failed: %s", hipGetErrorName(e));
   int nb = 0;
@@ -938,7 +939,6 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(256);
     switch (plan->H >> 6) {
-      case 2: hipLaunchKernelGGL(wave_kernel<2>, grid, block, plan->wave_lds_bytes, stream, wp); break;
       case 4: hipLaunchKernelGGL(wave_kernel<4>, grid, block, plan->wave_lds_bytes, stream, wp); break;
       case 8: hipLaunchKernelGGL(wave_kernel<8>, grid, block, plan->wave_lds_bytes, stream, wp); break;
       default: hipLaunchKernelGGL(wave_kernel<16>, grid, block, plan->wave_lds_bytes, stream, wp); break;

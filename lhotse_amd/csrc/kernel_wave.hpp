@@ -1,4 +1,4 @@
-// "Wave per frame" kernel: every power-of-two FFT size from 256 to 2048 (complex size H = 128 .. 1024) that has no
+// "Wave per frame" kernel: every power-of-two FFT size from 512 to 2048 (complex size H = 256 .. 1024) that has no
 // specialised kernel -- 22.05 / 24 / 32 kHz (fft 1024) and 44.1 / 48 kHz (fft 2048) with 25 ms frames, and any option the
 // fast paths do not take (energy columns, magnitude spectra ...).  All four feature kinds.
 //
