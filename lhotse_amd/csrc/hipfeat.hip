@@ -936,6 +936,7 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     wp.log_energy_floor = c.energy_floor > 0.0f ? logf(c.energy_floor) : -INFINITY;
     wp.mel_floor = c.mel_floor;
     wp.log_offset = c.log_offset;
+    if (const char* ab = getenv("HIPFEAT_WAVE_ABLATE")) wp.ablate = atoi(ab);
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(256);
     switch (plan->H >> 6) {

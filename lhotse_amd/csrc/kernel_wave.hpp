@@ -33,6 +33,7 @@ struct WaveParams {
   int32_t N, shift, H, K, M, C, maxband;
   int32_t kind, flags, npad_left;
   float preemph, log_energy_floor, mel_floor, log_offset;
+  int32_t ablate;  // experiments (HIPFEAT_WAVE_ABLATE): 1 no FFT, 2 no split/power, 4 no epilogue, 8 no sample loads
 };
 
 __device__ __forceinline__ v2 twiddle_h(const float2* __restrict__ tw, int m, int H) {  // W_H^m, 0 <= m < H, from W_2H^k (k < H)
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : 4)) void wave_kernel(const Wav
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       const int m = lane + 64 * r;
-      x[r] = (r < nreg && m < N) ? load_sample(w, j0 + m, cd.num_samples, cd.padded_len) : 0.f;
+      x[r] = (r < nreg && m < N && !(p.ablate & 8)) ? load_sample(w, j0 + m, cd.num_samples, cd.padded_len) : 0.f;
       s += x[r];
     }
     float mean = 0.f;
@@ -234,8 +235,8 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : 4)) void wave_kernel(const Wav
     wave_lds_sync();
 
     // ---- complex FFT, split step X[k] = E[k] + W_2H^k O[k], power (layers.py:32-42) --------------------------------
-    fft3_frame<N1>(zf, tw, lane);
-    {
+    if (!(p.ablate & 1)) fft3_frame<N1>(zf, tw, lane);
+    if (!(p.ablate & 2)) {
       float pw[N1 + 1];
 #pragma unroll
       for (int q = 0; q <= N1; ++q) {
@@ -264,7 +265,9 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : 4)) void wave_kernel(const Wav
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     float* __restrict__ orow = p.out + (cd.out_row + f) * p.out_stride;
-    if (p.kind == 0 || p.kind == 1) {
+    if (p.ablate & 4) {
+      if (lane < M) orow[lane] = buf[lane];
+    } else if (p.kind == 0 || p.kind == 1) {
       for (int k = lane; k < K; k += 64) {
         float v = buf[k];
         if (p.kind == 1) v = logf(v + p.log_offset);
