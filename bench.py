@@ -21,8 +21,9 @@ The JSON line also carries
                 per launch / average launch duration measured here with HIP events on the
                 launch stream; `traffic` = measured HBM bytes per launch from the committed
                 rocprofv3 PMC passes (profiles/traffic.json), or null;
-  cpu_baseline  the CPU restatement of the reference algorithm (oracle/, kind "port") timed on
-                this host on a bounded sample of the same workload (rank 0, N == 1 only).
+  cpu_baseline  the reference's CPU Fbank path restated with its own torch calls (oracle/kaldi_torch.py,
+                kind "port": /root/reference cannot travel) timed on this host on a bounded sample of the
+                same workload (rank 0, N == 1 only).
 """
 from __future__ import annotations
 
@@ -44,10 +45,12 @@ HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
 
 
 def cpu_baseline(seconds: float = 12.0, procs: int = 0):
-    """Time the oracle (numpy float32 restatement of lhotse's CPU Fbank path, one cut per call as in
-    CutSet.compute_and_store_features) on this host: `procs` single-threaded processes in parallel,
-    mirroring `num_jobs=procs` with torch.set_num_threads(1) (lhotse/bin/modes/features.py:25-32).
-    Workers are plain subprocesses with a hard timeout, so a stuck worker can never hang the bench."""
+    """Time lhotse's CPU Fbank path on this host.  /root/reference does not exist on the GPU box, so the path is
+    restated in oracle/kaldi_torch.py with the reference's own sequence of torch (ATen) calls -- as_strided framing,
+    rfft, matmul, log -- bit-identical to the reference on the golden vectors (tests/test_oracle.py): one cut per call
+    as in CutSet.compute_and_store_features, `procs` single-threaded processes in parallel, mirroring `num_jobs=procs`
+    with torch.set_num_threads(1) (lhotse/bin/modes/features.py:25-32).  Workers are plain subprocesses with a hard
+    timeout, so a stuck worker can never hang the bench."""
     import subprocess
 
     ncpu = os.cpu_count() or 1
@@ -73,8 +76,9 @@ def cpu_baseline(seconds: float = 12.0, procs: int = 0):
         "unit": "cuts/s",
         "cores": len(res),
         "kind": "port",
-        "sample": f"{total} x 10 s cuts in {seconds:.0f} s wall: {len(res)} single-threaded processes of the numpy float32 oracle "
-        f"({rate / len(res):.0f} cuts/s per core); host has {ncpu} logical cores",
+        "sample": f"{total} x 10 s cuts in {seconds:.0f} s wall: {len(res)} single-threaded processes of the reference's torch CPU Fbank "
+        f"call sequence (oracle/kaldi_torch.py, bit-identical to the reference on the goldens; {rate / len(res):.0f} cuts/s per core); "
+        f"host has {ncpu} logical cores",
     }
 
 

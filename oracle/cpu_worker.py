@@ -2,8 +2,10 @@
 
     python oracle/cpu_worker.py <seconds> <seed>
 
-Loops the numpy float32 oracle (one 10 s cut per call, as CutSet.compute_and_store_features does
-with the reference extractor) for <seconds> and prints "<cuts> <elapsed>".
+Loops the CPU Fbank path (oracle/kaldi_torch.py: the reference's own sequence of torch calls, bit-identical to the
+reference on the goldens; one 10 s cut per call with torch.set_num_threads(1), as CutSet.compute_and_store_features /
+`lhotse feat extract` run the reference extractor) for <seconds> and prints "<cuts> <elapsed>".
+`numpy` as third argument times the numpy restatement (oracle/kaldi_ref.py) instead.
 """
 import os
 import sys
@@ -21,7 +23,15 @@ from oracle.signals import make_signal  # noqa: E402
 
 def main():
     seconds, seed = float(sys.argv[1]), int(sys.argv[2])
-    ex = RefExtractor(RefConfig(kind="fbank"), np.float32)
+    if len(sys.argv) > 3 and sys.argv[3] == "numpy":
+        ex = RefExtractor(RefConfig(kind="fbank"), np.float32)
+    else:
+        import torch
+
+        from oracle.kaldi_torch import TorchFbank
+
+        torch.set_num_threads(1)  # lhotse/bin/modes/features.py:25-32
+        ex = TorchFbank()
     pool = [make_signal("uniform", 160000, seed + s) for s in range(4)]
     ex.extract(pool[0])
     n, t0 = 0, time.perf_counter()

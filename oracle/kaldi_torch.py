@@ -1,0 +1,64 @@
+"""
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+
+The CPU baseline of bench.py: the reference's CPU Fbank path restated with the SAME library calls the reference makes
+(torch.as_strided framing on a flip/cat-padded waveform, torch.mean, F.pad(replicate) pre-emphasis, window multiply,
+zero pad, torch.fft.rfft, abs()**2, matmul with the mel matrix, log) -- lhotse/features/kaldi/layers.py:151-187,
+:565-578, :727-772 as called by Fbank.extract (lhotse/features/kaldi/extractors.py:92-115).  It exists because
+/root/reference cannot travel to the GPU box, where "Lhotse's existing CPU Fbank path" has to be timed next to the GPU
+path; being the same sequence of ATen kernels, its speed is the reference's (BASELINE.md section 2 probe: ~150 cuts/s per
+single-threaded process in the authoring container).
+
+Parity status: PINNED -- tests/test_oracle.py::test_torch_baseline_equals_golden checks it against the reference's own
+outputs (tests/golden/fbank_default*.npz).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import kaldi_ref as K
+
+
+class TorchFbank:
+    """Default FbankConfig (16 kHz, 25/10 ms, povey, 80 mels, snip_edges=False) -- the BASELINE configuration."""
+
+    def __init__(self, cfg: K.RefConfig = None):
+        cfg = cfg or K.RefConfig(kind="fbank")
+        assert cfg.kind == "fbank" and not cfg.snip_edges and not cfg.use_energy
+        self.cfg = cfg
+        self.n, self.shift, self.fft = K.window_sizes(cfg)
+        assert cfg.window_type == "povey"
+        self.window = torch.hann_window(self.n, periodic=False).pow(0.85)  # layers.py:929 -- torch's own float32 kernels
+        self.fb = torch.from_numpy(np.ascontiguousarray(K.mel_matrix(cfg, np.float32).astype(np.float32)))  # (fft/2+1, M)
+        self.eps = torch.tensor(torch.finfo(torch.float32).eps)
+
+    def strided(self, x: torch.Tensor) -> torch.Tensor:
+        """layers.py:727-772 (snip_edges=False): reflect by flip/cat, then an as_strided view."""
+        S = x.shape[-1]
+        T = (S + self.shift // 2) // self.shift
+        npad_left = (self.n - self.shift) // 2
+        npad_right = (T - 1) * self.shift + self.n - S - npad_left
+        pad_left = torch.flip(x[:, :npad_left], (1,))
+        if npad_right >= 0:
+            pad_right = torch.flip(x[:, S - npad_right :], (1,))
+            x = torch.cat((pad_left, x, pad_right), dim=1)
+        else:
+            x = torch.cat((pad_left, x[:, :npad_right]), dim=1)
+        return x.as_strided((x.shape[0], T, self.n), (x.stride(0), self.shift * x.stride(1), x.stride(1)))
+
+    @torch.no_grad()
+    def extract(self, samples: np.ndarray) -> np.ndarray:
+        c = self.cfg
+        x = self.strided(torch.from_numpy(np.asarray(samples, dtype=np.float32)).reshape(1, -1))
+        if c.remove_dc_offset:
+            x = x - torch.mean(x, dim=2, keepdim=True)
+        if c.preemph_coeff != 0.0:
+            off = torch.nn.functional.pad(x, (1, 0), mode="replicate")
+            x = x - c.preemph_coeff * off[:, :, :-1]
+        x = x * self.window
+        if self.fft != self.n:
+            x = torch.nn.functional.pad(x.unsqueeze(1), [0, self.fft - self.n], mode="constant", value=0.0).squeeze(1)
+        pow_spec = torch.fft.rfft(x, dim=-1).abs() ** 2
+        mel = torch.matmul(pow_spec, self.fb)
+        return torch.max(mel, self.eps).log()[0].numpy()

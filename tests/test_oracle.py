@@ -130,3 +130,21 @@ def test_live_against_reference():
         got = RefExtractor(RefConfig(kind=kind, **rc), np.float32).extract(x)
         assert got.shape == want.shape
         assert err_stats(got, want)["rel_l2"] < 1e-4
+
+
+def test_torch_baseline_equals_golden():
+    """bench.py's CPU baseline (oracle/kaldi_torch.py: the reference's own torch call sequence) reproduces the
+    reference's outputs -- bit for bit on the standard cases."""
+    from _golden import golden_rows, load_case
+    from oracle.kaldi_torch import TorchFbank
+
+    tf = TorchFbank()
+    for name, exact in [("fbank80_tone", True), ("fbank80_uniform", True), ("fbank80_10s", True), ("fbank_long", True), ("impulse", True),
+                        ("fbank_lengths", False)]:
+        case, waves, z = load_case(name)
+        for i, w in enumerate(waves):
+            got, want = golden_rows(z, i, tf.extract(w))
+            if exact:
+                assert np.array_equal(got, want), (name, i)
+            else:
+                assert np.abs(got - want).max() <= 1e-5, (name, i)
