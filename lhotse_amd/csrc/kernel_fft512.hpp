@@ -206,10 +206,15 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512_WAVES_PER_SIMD) void fft512_fba
 #pragma unroll
       for (int k1 = 1; k1 < 16; ++k1) twp[k1] = ctwp[k1 * 16 + q];
 #endif
-      {  // only the last row can cross N
-        const int m0 = 32 * (NROWS - 1) + 2 * q;
-        if (m0 >= N) z[NROWS - 1].x = 0.f;
-        if (m0 + 1 >= N) z[NROWS - 1].y = 0.f;
+      // samples at or beyond N are not part of the frame (the template instance may carry up to three rows more than
+      // ceil(N / 32)): uniform test per row, lane mask only in the boundary rows
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        if (32 * (n1 + 1) > N) {
+          const int m0 = 32 * n1 + 2 * q;
+          if (m0 >= N) z[n1].x = 0.f;
+          if (m0 + 1 >= N) z[n1].y = 0.f;
+        }
       }
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) sum2 += z[n1];

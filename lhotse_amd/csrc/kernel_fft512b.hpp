@@ -146,10 +146,15 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
       for (int n1 = 0; n1 < NROWS; ++n1) z[n1] = *reinterpret_cast<const v2*>(x + 32 * n1);
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = cwin[n1 * 16 + q];
-      {
-        const int m0 = 32 * (NROWS - 1) + 2 * q;
-        if (m0 >= N) z[NROWS - 1].x = 0.f;
-        if (m0 + 1 >= N) z[NROWS - 1].y = 0.f;
+      // samples at or beyond N (the frame length) are not part of the frame: the template instance may carry up to three
+      // rows more than ceil(N / 32), so every row is checked (uniform test per row, lane mask only in the boundary rows)
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        if (32 * (n1 + 1) > N) {
+          const int m0 = 32 * n1 + 2 * q;
+          if (m0 >= N) z[n1].x = 0.f;
+          if (m0 + 1 >= N) z[n1].y = 0.f;
+        }
       }
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) sum2 += z[n1];
