@@ -79,3 +79,85 @@ def test_random_config_against_float64_oracle(idx):
         floor = np.linalg.norm(want - truth) / den
         rel = np.linalg.norm(got - truth) / den
         assert rel <= max(1e-4, 3 * floor), (ex.kernel_name, kind, cfg, len(x), rel, floor)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_batches_with_the_reference_edge_rule(seed):
+    """`edge_rule="batch_zero_pad"` (the reference's _extract_batch: shorter items see zeros past their end)
+    on random ragged batches, list and padded-tensor entry points, against the oracle's batch restatement."""
+    import torch
+
+    rng = np.random.RandomState(500 + seed)
+    kind = ["fbank", "mfcc", "fbank", "log-spectrogram"][seed % 4]
+    sr = [16000, 8000, 16000, 24000][seed % 4]
+    cfg = dict(sampling_rate=sr, edge_rule="batch_zero_pad")
+    lens = sorted((rng.randint(int(0.2 * sr), int(3 * sr), size=rng.randint(2, 7))).tolist(), reverse=bool(seed & 1))
+    xs = [(rng.rand(n).astype(np.float32) - 0.5) for n in lens]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ex = TABLE[kind][0](TABLE[kind][1](**cfg))
+    fields = {"sampling_rate": sr}
+    if kind == "mfcc":
+        fields["num_filters"] = 23
+    ref = K.RefExtractor(K.RefConfig(kind=kind, **fields), np.float64)
+    want = ref.extract_batch(xs, edge_rule="batch_zero_pad")
+    got = ex.extract_batch(xs, sr)
+    padded = torch.zeros(len(xs), max(lens))
+    for i, x in enumerate(xs):
+        padded[i, : len(x)] = torch.from_numpy(x)
+    got2 = ex.extract_batch(padded, sr, lengths=torch.tensor(lens, dtype=torch.int32))
+    for w, g, g2 in zip(want, got, got2):
+        assert g.shape == w.shape == g2.shape
+        assert np.linalg.norm(g - w) / np.linalg.norm(w) <= 2e-4  # float32 vs float64 truth; log-spectra noise dominated
+        assert np.array_equal(np.asarray(g), np.asarray(g2))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_resampling_ratios(seed):
+    from lhotse_amd import augmentation as A
+    from oracle import resample_ref as R
+
+    rng = np.random.RandomState(900 + seed)
+    rates = [8000, 11025, 12000, 16000, 22050, 24000, 32000, 44100, 48000]
+    if seed < 8:
+        orig, new = rng.choice(rates, size=2, replace=False)
+    else:  # speed perturbation factors around 1
+        new = 16000
+        orig = int(round(16000 * rng.choice([0.9, 0.95, 1.05, 1.1, 0.85, 1.15, 0.97, 1.03])))
+    xs = [(rng.rand(n).astype(np.float32) - 0.5) for n in (int(rng.randint(1, 50)), int(rng.randint(1000, 30000)), int(rng.randint(30000, 90000)))]
+    r = A.get_or_create_resampler(int(orig), int(new))
+    ys = r.resample_batch(xs)
+    for x, y in zip(xs, ys):
+        want = R.resample(x, int(orig), int(new), dtype=np.float64)
+        assert y.numel() == len(want)
+        assert np.abs(y.cpu().numpy() - want).max() <= 1e-5, (orig, new, len(x))
+
+
+@pytest.mark.parametrize("name", ["fbank16k", "mfcc16k", "fbank8k", "mfcc8k", "spec8k", "fbank24k", "whisper"])
+def test_repeated_launches_are_bit_identical(name):
+    """Race detector: the same ragged batch through the same plan 60 times, from device tensors and from host arrays
+    (pinned staging ring, async H2D, descriptor ring), must give bit-identical results every time."""
+    import torch
+
+    mk = {
+        "fbank16k": (lambda: LA.HipFbank(), 16000),
+        "mfcc16k": (lambda: LA.HipMfcc(), 16000),
+        "fbank8k": (lambda: LA.HipFbank(LA.HipFbankConfig(sampling_rate=8000, num_filters=40)), 8000),
+        "mfcc8k": (lambda: LA.HipMfcc(LA.HipMfccConfig(sampling_rate=8000)), 8000),
+        "spec8k": (lambda: LA.HipSpectrogram(LA.HipSpectrogramConfig(sampling_rate=8000)), 8000),
+        "fbank24k": (lambda: LA.HipFbank(LA.HipFbankConfig(sampling_rate=24000)), 24000),
+        "whisper": (lambda: LA.HipWhisperFbank(), 16000),
+    }[name]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ex = mk[0]()
+    sr = mk[1]
+    rng = np.random.RandomState(3)
+    lens = [int(2.08 * sr) + 30, int(0.98 * sr) - 19, 5 * sr, sr // 3, 3 * sr + 17]
+    xs_host = [(rng.rand(n).astype(np.float32) - 0.5) for n in lens]
+    xs_dev = [torch.from_numpy(x).cuda() for x in xs_host]
+    first = [np.asarray(o).copy() for o in ex.extract_batch(xs_host, sr)]
+    for rep in range(60):
+        outs = ex.extract_batch(xs_host, sr) if rep % 2 else [o.cpu().numpy() for o in ex.extract_batch(xs_dev, sr)]
+        for i, (a, b) in enumerate(zip(outs, first)):
+            assert np.array_equal(np.asarray(a), b), (name, rep, i)
