@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -226,6 +227,21 @@ static const void* fft512b_entry() {
   return reinterpret_cast<const void*>(&fft512b_kernel<NROWS, OUT>);
 }
 
+// The dynamic-LDS limit of a kernel is a property of the FUNCTION, shared by every plan of the process: it is only ever
+// raised (per device), so that a later plan with a smaller footprint cannot lower it under an earlier plan's launches.
+static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> high;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  size_t& cur = high[{fn, dev}];
+  if (bytes <= cur) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) cur = bytes;
+  return e;
+}
+
 // Mel work split of the fast kernels: band of every 16-mel tile in 8-bin groups, assigned to the 4 waves, and the MFMA
 // A operands in lane order.  Returns false when the filterbank does not fit the static schedule (-> generic kernel).
 static bool build_mel_schedule(const float* h_mel, int M, int K, int prow_stride, int ntiles, WaveWork (&work)[4], std::vector<float>& mel_a) {
@@ -398,7 +414,7 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
     fn = nrows == 10 ? fft512_entry<10>() : (nrows == 13 ? fft512_entry<13>() : fft512_entry<16>());
   }
   if (p->fast_lds_bytes > 160 * 1024) return HIPFEAT_OK;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->fast_lds_bytes);
+  hipError_t e = ensure_dynamic_lds(fn, p->fast_lds_bytes);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft512) failed: %s", hipGetErrorName(e));
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, p->fast_lds_bytes) == hipSuccess) p->blocks_per_cu = nb;
@@ -500,7 +516,7 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
   if (mfcc) fn = nrows == 13 ? fft256_entry<13, 1>() : fft256_entry<16, 1>();
   else if (spec) fn = nrows == 13 ? fft256_entry<13, 2>() : fft256_entry<16, 2>();
   else fn = nrows == 13 ? fft256_entry<13, 0>() : fft256_entry<16, 0>();
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->fast_lds_bytes);
+  hipError_t e = ensure_dynamic_lds(fn, p->fast_lds_bytes);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft256) failed: %s", hipGetErrorName(e));
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, p->fast_lds_bytes) == hipSuccess) p->blocks_per_cu = nb;
@@ -552,7 +568,7 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
   }
   p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)144 * (H / 64) + 8)) * sizeof(float);  // twiddles + 4 padded wave buffers
   const void* fn = H == 256 ? wave_entry<4>() : (H == 512 ? wave_entry<8>() : wave_entry<16>());
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->wave_lds_bytes);
+  hipError_t e = ensure_dynamic_lds(fn, p->wave_lds_bytes);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(wave) failed: %s", hipGetErrorName(e));
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, p->wave_lds_bytes) == hipSuccess) p->blocks_per_cu = nb;
@@ -759,8 +775,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
     if (carve(pick) > 160 * 1024) p->fpb = 0;
   }
   if (p->fpb < 1) return bail(fail(HIPFEAT_ERR_UNSUPPORTED, "configuration does not fit in LDS"));
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&generic_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_bytes);
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&generic_kernel), p->lds_bytes);
   if (e != hipSuccess) return bail(fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(LDS=%zu) failed: %s", p->lds_bytes, hipGetErrorName(e)));
 
   st = setup_fft512(p, h_window, h_mel, h_dct, h_lifter);

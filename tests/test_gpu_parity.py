@@ -438,3 +438,22 @@ def test_layout_launch_is_hip_graph_capturable():
     ref, _ = plan.run(wave, offs, lens, None)
     assert torch.equal(out, ref) and not torch.equal(out, want1)
     L.check("hipfeat_layout_destroy", layout)
+
+
+def test_plans_sharing_a_kernel_with_different_lds_footprints():
+    """The dynamic-LDS limit is per FUNCTION: a later, smaller plan of the same kernel instance must not lower it
+    under an earlier plan (hipfeat.hip ensure_dynamic_lds)."""
+    from _hip import make_hip
+    from oracle.kaldi_ref import RefConfig, RefExtractor
+
+    x = np.random.RandomState(5).rand(48000).astype(np.float32) - 0.5
+    big = make_hip("mfcc", {"num_filters": 40, "num_ceps": 40})
+    a0 = big.extract(x, 16000)
+    small = make_hip("mfcc", {})
+    assert big.kernel_name.split(" ")[0] == small.kernel_name.split(" ")[0] and big.kernel_name != small.kernel_name
+    b = small.extract(x, 16000)
+    a1 = big.extract(x, 16000)  # the big plan still launches with its own footprint
+    assert np.array_equal(a0, a1)
+    for got, cfg in ((a1, dict(num_filters=40, num_ceps=40)), (b, dict(num_filters=23, num_ceps=13))):
+        want = RefExtractor(RefConfig(kind="mfcc", **cfg), np.float64).extract(x)
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-4
