@@ -161,3 +161,31 @@ def test_repeated_launches_are_bit_identical(name):
         outs = ex.extract_batch(xs_host, sr) if rep % 2 else [o.cpu().numpy() for o in ex.extract_batch(xs_dev, sr)]
         for i, (a, b) in enumerate(zip(outs, first)):
             assert np.array_equal(np.asarray(a), b), (name, rep, i)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_whisper_and_collated_int16_batches(seed):
+    import torch
+
+    from oracle import whisper_ref as W
+
+    rng = np.random.RandomState(700 + seed)
+    n_mels = [80, 128, 80, 40, 80, 128][seed]
+    lens = [int(v) for v in rng.randint(201, 60000, size=rng.randint(3, 9))] + [201, 160 * 7 + 79, 160 * 7 + 80, 2560 * 3, 2560 * 3 + 1]
+    scale = rng.choice([1.0, 0.3, 0.01])
+    xs = [((rng.rand(n).astype(np.float32) - 0.5) * scale).astype(np.float32) for n in lens]
+    ex = LA.HipWhisperFbank(LA.HipWhisperFbankConfig(num_filters=n_mels))
+    filters = W.slaney_mel_filters(16000, 400, n_mels)
+    col, flens = ex.extract_collated(xs, 16000)
+    assert flens.tolist() == [W.num_rows(n) for n in lens] and col.shape == (len(xs), max(flens.tolist()), n_mels)
+    for i, x in enumerate(xs):
+        truth = W.log_mel_spectrogram(x, filters, dtype=np.float64)
+        got = col[i, : len(truth)].cpu().numpy()
+        assert np.abs(got - truth).max() <= 2e-4, (seed, i, len(x), np.abs(got - truth).max())
+        assert torch.all(col[i, len(truth):] == np.float32(LA.compat.LOG_EPSILON))
+    # int16 PCM through the Kaldi fbank path, collated: bit-identical to the float path
+    pcm = [np.round(x / max(scale, 1e-9) * 30000).astype(np.int16) for x in xs if len(x) >= 400]
+    fb = LA.HipFbank()
+    a, la = fb.extract_collated(pcm, 16000)
+    b, lb = fb.extract_collated([p.astype(np.float32) / 32768.0 for p in pcm], 16000)
+    assert torch.equal(a, b) and torch.equal(la, lb)
