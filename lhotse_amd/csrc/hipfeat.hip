@@ -566,7 +566,7 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
     if ((st = upload(&p->d_mel_t, mt.data(), mt.size())) != HIPFEAT_OK) return st;
     p->mel_maxband = maxband;
   }
-  p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)144 * (H / 64) + 8)) * sizeof(float);  // twiddles + 4 padded wave buffers
+  p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)144 * (H / 64) + 8) + (size_t)c.frame_length) * sizeof(float);  // twiddles + 4 padded wave buffers + window
   const void* fn = H == 256 ? wave_entry<4>() : (H == 512 ? wave_entry<8>() : wave_entry<16>());
   hipError_t e = ensure_dynamic_lds(fn, p->wave_lds_bytes);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(wave) failed: %s", hipGetErrorName(e));

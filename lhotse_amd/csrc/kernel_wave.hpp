@@ -148,11 +148,15 @@ __device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw
 
 constexpr int kWaveMaxRegs = 20;  // ceil(N / 64) sample registers per lane: N <= 1280
 
+#ifndef HIPFEAT_WAVE_OCC
+#define HIPFEAT_WAVE_OCC 4
+#endif
 template <int N1>
-__global__ __launch_bounds__(256, (N1 == 16 ? 2 : 4)) void wave_kernel(const WaveParams p) {
+__global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_kernel(const WaveParams p) {
   constexpr int H = 64 * N1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float2* tw = reinterpret_cast<float2*>(smem);                  // [H]
+  float* winl = smem + 2 * H + 4 * (144 * N1 + 8);               // [N] window, shared by the four waves
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* buf = smem + 2 * H + wv * (144 * N1 + 8);               // wave-private: 72 N1 complex (padded FFT buffer), later the power row
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : 4)) void wave_kernel(const Wav
   const CutDesc cd = p.cuts[cut];
   const float* __restrict__ w = p.wave + cd.wave_off;
   for (int i = tid; i < H; i += 256) tw[i] = p.tw[i];
+  for (int i = tid; i < p.N; i += 256) winl[i] = p.window[i];
   __syncthreads();
 
   const int N = p.N, K = p.K, M = p.M;
@@ -221,8 +226,8 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : 4)) void wave_kernel(const Wav
         v2 v = {0.f, 0.f};
         if (m0 < N) {
           const float d0 = buf[m0], dm = buf[m0 > 0 ? m0 - 1 : 0];
-          v.x = (d0 - p.preemph * dm) * p.window[m0];
-          if (m0 + 1 < N) v.y = (buf[m0 + 1] - p.preemph * d0) * p.window[m0 + 1];
+          v.x = (d0 - p.preemph * dm) * winl[m0];
+          if (m0 + 1 < N) v.y = (buf[m0 + 1] - p.preemph * d0) * winl[m0 + 1];
         }
         y[q] = v;
         e = fmaf(v.x, v.x, fmaf(v.y, v.y, e));
