@@ -393,7 +393,7 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
     size_t lds_floats = (size_t)p->xs_floats + const_floats + 4 * kBWaveRegion;
     if (mfcc) {
       p->dct_groups = (M + 7) / 8;
-      p->lm_stride = ntiles <= 4 ? 68 : 132;  // == 4 mod 64: conflict-free 8-byte reads of the log-mel tile
+      p->lm_stride = ntiles <= 2 ? 36 : (ntiles <= 4 ? 68 : 132);  // 4 mod 32: conflict-free 8-byte reads of the log-mel tile; 36 keeps MFCC-13 at 4 workgroups/CU
       std::vector<float> da = build_dct_operands(c, h_dct, h_lifter, p->dct_groups);
       p->dct_floats = (int)da.size();
       if ((st = upload(&p->d_dct_consts, da.data(), da.size())) != HIPFEAT_OK) return st;
@@ -502,7 +502,7 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
   size_t lds_floats = (size_t)p->xs_floats + const_floats + 4 * k256WaveRegion;
   if (mfcc) {
     p->dct_groups = (M + 7) / 8;
-    p->lm_stride = ntiles <= 4 ? 68 : 132;
+    p->lm_stride = ntiles <= 2 ? 36 : (ntiles <= 4 ? 68 : 132);
     std::vector<float> da = build_dct_operands(c, h_dct, h_lifter, p->dct_groups);
     p->dct_floats = (int)da.size();
     if ((st = upload(&p->d_dct_consts, da.data(), da.size())) != HIPFEAT_OK) return st;
