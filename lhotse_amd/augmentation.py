@@ -117,14 +117,13 @@ class HipResampleTensor:
         for t in ts:
             if t.dtype != torch.float32:
                 raise TypeError(f"expected float32 samples, got {t.dtype}")
-        lengths = np.array([t.numel() for t in ts], dtype=np.int64)
-        offsets = np.zeros(len(ts), dtype=np.int64)
-        np.cumsum(lengths[:-1], out=offsets[1:])
         if not ts:
             return []
-        wave = torch.cat([t.to(self.device, non_blocking=True) for t in ts]) if len(ts) > 1 else ts[0].to(self.device).contiguous()
+        from .extractors import pack_to_device  # pinned staging + one H2D for host inputs
+
+        wave, offsets, lengths = pack_to_device(ts, self.device)
         if self.orig == self.new:
-            return list(wave.split(lengths.tolist()))
+            return [wave[o : o + n] for o, n in zip(offsets.tolist(), lengths.tolist())]
         out, out_offs, out_lens = self.run(wave, offsets, lengths)
         return [out[o : o + n] for o, n in zip(out_offs.tolist(), out_lens.tolist())]
 

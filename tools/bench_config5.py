@@ -12,6 +12,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lhotse_amd as LA
 from lhotse_amd import augmentation as A
+from lhotse_amd.extractors import pack_to_device
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batches", type=int, default=40)
@@ -31,7 +32,8 @@ res = {f: A.get_or_create_resampler(round(16000 * f), 16000) for f in (0.9, 1.1)
 
 def run(batch, timers=None):
     t0 = time.perf_counter()
-    dev = [torch.from_numpy(x).cuda(non_blocking=True) for x, _ in batch]   # H2D (pageable here; pinned staging inside extract* otherwise)
+    packed, offs, lens_ = pack_to_device([x for x, _ in batch], torch.device("cuda", 0))   # pinned staging, one H2D
+    dev = [packed[o : o + n] for o, n in zip(offs.tolist(), lens_.tolist())]
     if timers is not None: torch.cuda.synchronize(); t1 = time.perf_counter()
     out = list(dev)
     for f, r in res.items():
