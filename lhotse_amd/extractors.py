@@ -400,7 +400,7 @@ class _HostStaging:
 _SHARED_STAGING: Dict[int, "_HostStaging"] = {}
 
 
-def pack_to_device(items: Sequence[ArrayLike], device: torch.device) -> Tuple[torch.Tensor, np.ndarray, np.ndarray]:
+def pack_to_device(items: Sequence[ArrayLike], device: torch.device, stage: Optional["_HostStaging"] = None) -> Tuple[torch.Tensor, np.ndarray, np.ndarray]:
     """1-D float32 waveforms (host arrays / CPU tensors / tensors already on ``device``) -> one packed device buffer,
     element offsets and lengths.  Host items go through reusable pinned staging with multi-threaded copies and ONE H2D
     transfer (a pageable ``.cuda()`` per cut is several times slower); every cut starts on a 16-byte boundary."""
@@ -415,7 +415,8 @@ def pack_to_device(items: Sequence[ArrayLike], device: torch.device) -> Tuple[to
     offs = np.zeros(len(items), dtype=np.int64)
     np.cumsum(padded[:-1], out=offs[1:])
     total = int(offs[-1] + lens[-1]) if len(items) else 0
-    stage = _SHARED_STAGING.setdefault(int(device.index or 0), _HostStaging())
+    if stage is None:
+        stage = _SHARED_STAGING.setdefault(int(device.index or 0), _HostStaging())
     host, slot = stage.input(total)
     pieces = []
     for x, o in zip(items, offs):
@@ -529,34 +530,16 @@ class _HipExtractor(FeatureExtractor):
             if not all(pcm):
                 raise TypeError("a batch must be all float32 or all int16 PCM")
             return self._pack_pcm16(items, lens)
-        if all(isinstance(x, torch.Tensor) and x.device == dev for x in items):
-            if len(items) == 1:
-                return items[0].contiguous(), np.zeros(1, dtype=np.int64), lens
-            offs = np.zeros(len(items), dtype=np.int64)
-            np.cumsum(lens[:-1], out=offs[1:])
-            return torch.cat([x.contiguous() for x in items]), offs, lens
-        padded = (lens + 3) & ~3
-        offs = np.zeros(len(items), dtype=np.int64)
-        np.cumsum(padded[:-1], out=offs[1:])
-        total = int(offs[-1] + lens[-1]) if len(items) else 0
         if dev.type != "cuda":  # only reachable with a stand-in plan (tests); no staging needed
+            padded = (lens + 3) & ~3
+            offs = np.zeros(len(items), dtype=np.int64)
+            np.cumsum(padded[:-1], out=offs[1:])
+            total = int(offs[-1] + lens[-1]) if len(items) else 0
             host = torch.zeros(total, dtype=torch.float32)
             for x, o, n in zip(items, offs, lens):
                 host[o : o + n] = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
             return host, offs, lens
-        stage = self._stage()
-        host, slot = stage.input(total)
-        hv = host.numpy()
-        pieces = []
-        for x, o in zip(items, offs):
-            if isinstance(x, torch.Tensor):
-                x = x.detach().cpu().contiguous().numpy()
-            pieces.append((int(o), np.ascontiguousarray(x)))
-        _parallel_copy(hv, pieces)
-        wave = torch.empty(total, dtype=torch.float32, device=dev)
-        wave.copy_(host[:total], non_blocking=True)
-        stage.sent(slot, dev)
-        return wave, offs, lens
+        return pack_to_device(items, dev, self._stage())
 
     def _pack_pcm16(self, items: Sequence[ArrayLike], lens: np.ndarray) -> Tuple[torch.Tensor, np.ndarray, np.ndarray]:
         """int16 PCM items -> one pinned int16 buffer -> H2D (half the bytes) -> float32 on the device."""
