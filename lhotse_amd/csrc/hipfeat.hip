@@ -495,7 +495,7 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
         mel_a4[(((size_t)w * kBMelVec + s4 / 4) * 64 + lane) * 4 + (s4 & 3)] = mel_a[((size_t)w * kMelARegs + s4) * 64 + lane];
   if ((st = upload(&p->d_mel_a4, mel_a4.data(), mel_a4.size())) != HIPFEAT_OK) return st;
   p->nrows = nrows;
-  p->tiles_per_block = 8;  // 256 frames per workgroup, as the 512 kernel
+  p->tiles_per_block = 16;  // 512 frames per workgroup (measured: 8 -> 3.84 M, 16 -> 3.99 M, 32 -> 3.93 M cuts/s at 8 kHz fbank-80)
   if (const char* tpb = getenv("HIPFEAT_TILES_PER_BLOCK")) p->tiles_per_block = std::max(1, atoi(tpb));
   p->const_floats = const_floats;
   p->xs_floats = ((k256TileFrames - 1) * shift + 16 * nrows + 255) & ~255;  // whole 1 KiB LDS-DMA chunks
