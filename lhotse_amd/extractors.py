@@ -27,6 +27,7 @@ and default-constructible without a GPU, as lhotse requires of registered extrac
 from __future__ import annotations
 
 import os
+import threading
 import warnings
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
@@ -368,6 +369,9 @@ class _HostStaging:
         self._ev = [None, None]
         self._out = None
         self._turn = 0
+        # one host thread at a time packs into / fetches through these buffers (extractors may be shared by the
+        # reader threads of a data pipeline); held across pack + H2D issue and across D2H + copy-out
+        self.lock = threading.RLock()
 
     def input(self, n: int) -> Tuple[torch.Tensor, int]:
         i = self._turn
@@ -388,12 +392,13 @@ class _HostStaging:
     def fetch(self, dev_tensor: torch.Tensor) -> torch.Tensor:
         """Device tensor -> fresh CPU tensor (D2H through the pinned buffer, then one host copy)."""
         n = dev_tensor.numel()
-        if self._out is None or self._out.numel() < n:
-            self._out = torch.empty(max(n, 1 << 20), dtype=torch.float32, pin_memory=True)
-        view = self._out[:n].view(dev_tensor.shape)
-        view.copy_(dev_tensor, non_blocking=False)
-        fresh = torch.empty(dev_tensor.shape, dtype=torch.float32)
-        _parallel_copy(fresh.view(-1).numpy(), [(0, self._out[:n].numpy())])
+        with self.lock:
+            if self._out is None or self._out.numel() < n:
+                self._out = torch.empty(max(n, 1 << 20), dtype=torch.float32, pin_memory=True)
+            view = self._out[:n].view(dev_tensor.shape)
+            view.copy_(dev_tensor, non_blocking=False)
+            fresh = torch.empty(dev_tensor.shape, dtype=torch.float32)
+            _parallel_copy(fresh.view(-1).numpy(), [(0, self._out[:n].numpy())])
         return fresh
 
 
@@ -417,16 +422,17 @@ def pack_to_device(items: Sequence[ArrayLike], device: torch.device, stage: Opti
     total = int(offs[-1] + lens[-1]) if len(items) else 0
     if stage is None:
         stage = _SHARED_STAGING.setdefault(int(device.index or 0), _HostStaging())
-    host, slot = stage.input(total)
-    pieces = []
-    for x, o in zip(items, offs):
-        if isinstance(x, torch.Tensor):
-            x = x.detach().cpu().contiguous().numpy()
-        pieces.append((int(o), np.ascontiguousarray(x)))
-    _parallel_copy(host.numpy(), pieces)
-    wave = torch.empty(total, dtype=torch.float32, device=device)
-    wave.copy_(host[:total], non_blocking=True)
-    stage.sent(slot, device)
+    with stage.lock:
+        host, slot = stage.input(total)
+        pieces = []
+        for x, o in zip(items, offs):
+            if isinstance(x, torch.Tensor):
+                x = x.detach().cpu().contiguous().numpy()
+            pieces.append((int(o), np.ascontiguousarray(x)))
+        _parallel_copy(host.numpy(), pieces)
+        wave = torch.empty(total, dtype=torch.float32, device=device)
+        wave.copy_(host[:total], non_blocking=True)
+        stage.sent(slot, device)
     return wave, offs, lens
 
 
@@ -554,17 +560,18 @@ class _HipExtractor(FeatureExtractor):
                 pcm[o : o + n] = x
         else:
             stage = self._stage()
-            host, slot = stage.input((total + 1) // 2)
-            hv = host.numpy().view(np.int16)
-            pieces = []
-            for x, o in zip(items, offs):
-                if isinstance(x, torch.Tensor):
-                    x = x.detach().cpu().contiguous().numpy()
-                pieces.append((int(o), np.ascontiguousarray(x)))
-            _parallel_copy(hv, pieces)
-            pcm = torch.empty(total, dtype=torch.int16, device=dev)
-            pcm.copy_(host.view(torch.int16)[:total], non_blocking=True)
-            stage.sent(slot, dev)
+            with stage.lock:
+                host, slot = stage.input((total + 1) // 2)
+                hv = host.numpy().view(np.int16)
+                pieces = []
+                for x, o in zip(items, offs):
+                    if isinstance(x, torch.Tensor):
+                        x = x.detach().cpu().contiguous().numpy()
+                    pieces.append((int(o), np.ascontiguousarray(x)))
+                _parallel_copy(hv, pieces)
+                pcm = torch.empty(total, dtype=torch.int16, device=dev)
+                pcm.copy_(host.view(torch.int16)[:total], non_blocking=True)
+                stage.sent(slot, dev)
         with torch.cuda.device(dev):
             wave = torch.empty(total, dtype=torch.float32, device=dev)
             self.plan.lib.check("hipfeat_pcm16_to_float", pcm.data_ptr(), wave.data_ptr(), total, int(torch.cuda.current_stream(dev).cuda_stream))
@@ -638,11 +645,12 @@ class _HipExtractor(FeatureExtractor):
                 if wave.device != dev:
                     if wave.device.type == "cpu" and dev.type == "cuda":
                         stage = self._stage()
-                        host, slot = stage.input(wave.numel())
-                        _parallel_copy(host.numpy(), [(0, wave.view(-1).numpy())])
-                        dwave = torch.empty(wave.shape, dtype=torch.float32, device=dev)
-                        dwave.copy_(host[: wave.numel()].view(wave.shape), non_blocking=True)
-                        stage.sent(slot, dev)
+                        with stage.lock:
+                            host, slot = stage.input(wave.numel())
+                            _parallel_copy(host.numpy(), [(0, wave.view(-1).numpy())])
+                            dwave = torch.empty(wave.shape, dtype=torch.float32, device=dev)
+                            dwave.copy_(host[: wave.numel()].view(wave.shape), non_blocking=True)
+                            stage.sent(slot, dev)
                         wave = dwave
                     else:
                         wave = wave.to(dev)

@@ -189,3 +189,31 @@ def test_random_whisper_and_collated_int16_batches(seed):
     a, la = fb.extract_collated(pcm, 16000)
     b, lb = fb.extract_collated([p.astype(np.float32) / 32768.0 for p in pcm], 16000)
     assert torch.equal(a, b) and torch.equal(la, lb)
+
+
+def test_one_extractor_shared_by_several_host_threads():
+    """Reader threads of a data pipeline may share one extractor: concurrent extract_batch calls on host arrays (pinned
+    staging ring, descriptor ring) must not corrupt each other."""
+    import threading
+
+    ex = LA.HipFbank()
+    rng = np.random.RandomState(11)
+    batches = [[(rng.rand(n).astype(np.float32) - 0.5) for n in rng.randint(8000, 90000, size=5)] for _ in range(6)]
+    want = [[np.asarray(o).copy() for o in ex.extract_batch(b, 16000)] for b in batches]
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(25):
+                i = (tid + rep) % len(batches)
+                outs = ex.extract_batch(batches[i], 16000)
+                for a, b in zip(outs, want[i]):
+                    if not np.array_equal(np.asarray(a), b):
+                        errors.append((tid, rep, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:5]
