@@ -53,6 +53,11 @@ def test_slaney_filterbank_properties():
     # area normalisation: each continuous triangle has unit area -> discrete sums ~ 1 / (40 Hz bin width) for wide filters
     wide = f[40:].astype(np.float64).sum(axis=1) * 40.0
     assert np.all(np.abs(wide - 1.0) < 0.08)
+    # known-answer tripwires: the leading non-zero weights of librosa.filters.mel(sr=16000, n_fft=400, n_mels=80 / 128),
+    # i.e. of the arrays OpenAI Whisper ships as assets/mel_filters.npz ("mel_80", "mel_128") -- quoted from memory of
+    # that published asset, which is not available offline
+    assert abs(float(f[0, 1]) - 0.02486259) < 5e-9 and abs(float(f[1, 1]) - 0.00199082) < 5e-9 and abs(float(f[1, 2]) - 0.02287177) < 5e-9
+    assert abs(float(W.slaney_mel_filters(16000, 400, 128)[0, 1]) - 0.01237399) < 5e-9
     # window
     w = W.hann_periodic()
     assert w[0] == 0 and abs(w[200] - 1) < 1e-7 and np.allclose(w[1:], w[1:][::-1])
