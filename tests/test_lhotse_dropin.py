@@ -47,6 +47,9 @@ def lhotse_mod():
 
         importlib.reload(ins)
         importlib.reload(wh)
+        import lhotse_amd.storage as st
+
+        importlib.reload(st)
         importlib.reload(lhotse_amd)
     return lhotse
 
@@ -300,3 +303,33 @@ def test_fused_on_the_fly_features_equal_the_reference_strategy(cutset, cpu_devi
     assert ours.supervision_intervals is not None
     with pytest.raises(TypeError):
         LA.HipOnTheFlyFeatures(Fbank())
+
+
+def test_bulk_save_driver_equals_the_reference_driver(tmp_path, cutset, cpu_device):
+    """lhotse_amd.compute_and_store_features_batch (one D2H per batch, threaded array writes, one manifest flush per
+    batch) must produce what CutSet.compute_and_store_features_batch produces: same cuts in the same order, same
+    Features manifests, same stored arrays; and it must resume like the reference."""
+    import lhotse_amd as LA
+    from lhotse import CutSet, NumpyFilesWriter
+
+    ex = LA.HipFbank()
+    ref = cutset.compute_and_store_features_batch(extractor=ex, storage_path=tmp_path / "ref", manifest_path=tmp_path / "ref.jsonl.gz",
+                                                  batch_duration=3.0, num_workers=0, storage_type=NumpyFilesWriter)
+    ours = LA.compute_and_store_features_batch(cutset, extractor=ex, storage_path=tmp_path / "ours", manifest_path=tmp_path / "ours.jsonl.gz",
+                                               batch_duration=3.0, num_workers=0, storage_type=NumpyFilesWriter, save_threads=4)
+    ref, ours = list(ref), list(ours)
+    assert [c.id for c in ours] == [c.id for c in ref] and len(ours) == 5
+    for a, b in zip(ours, ref):
+        fa, fb = a.features, b.features
+        assert (fa.type, fa.num_frames, fa.num_features, fa.frame_shift, fa.sampling_rate, fa.start, fa.duration, fa.storage_type, fa.storage_key,
+                fa.recording_id, fa.channels) == (fb.type, fb.num_frames, fb.num_features, fb.frame_shift, fb.sampling_rate, fb.start, fb.duration,
+                                                  fb.storage_type, fb.storage_key, fb.recording_id, fb.channels)
+        assert np.array_equal(a.load_features(), b.load_features())
+    # resume: everything is already in the manifest -> nothing is recomputed, same manifest comes back
+    again = LA.compute_and_store_features_batch(cutset, extractor=ex, storage_path=tmp_path / "ours", manifest_path=tmp_path / "ours.jsonl.gz",
+                                                batch_duration=3.0, num_workers=0, storage_type=NumpyFilesWriter)
+    assert [c.id for c in again] == [c.id for c in ours]
+    # in-memory manifests, collated batches, the reference's own extractor as a fallback path
+    mem = LA.compute_and_store_features_batch(cutset, extractor=ex, storage_path=tmp_path / "mem", batch_duration=100.0, num_workers=0,
+                                              collate=True, storage_type=NumpyFilesWriter, overwrite=True)
+    assert len(list(mem)) == 5 and all(c.has_features for c in mem)
