@@ -510,6 +510,7 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
     p->fast_mfcc = true;
   }
   p->fast_lds_bytes = lds_floats * sizeof(float);
+  if (const char* pad = getenv("HIPFEAT_LDS_PAD")) p->fast_lds_bytes += (size_t)atoi(pad);  // occupancy experiments
   p->fast_out = mfcc ? 1 : (spec ? 2 : 0);
   if (p->fast_lds_bytes > 64 * 1024) return HIPFEAT_OK;  // keep at least two workgroups per CU; otherwise the generic kernel
   const void* fn;
