@@ -23,8 +23,9 @@ from . import kaldi_ref as K
 class TorchFbank:
     """Default FbankConfig (16 kHz, 25/10 ms, povey, 80 mels, snip_edges=False) -- the BASELINE configuration."""
 
-    def __init__(self, cfg: K.RefConfig = None):
+    def __init__(self, cfg: K.RefConfig = None, device: str = "cpu"):
         cfg = cfg or K.RefConfig(kind="fbank")
+        self.device = torch.device(device)
         assert cfg.kind == "fbank" and not cfg.snip_edges and not cfg.use_energy
         self.cfg = cfg
         self.n, self.shift, self.fft = K.window_sizes(cfg)
@@ -32,6 +33,8 @@ class TorchFbank:
         self.window = torch.hann_window(self.n, periodic=False).pow(0.85)  # layers.py:929 -- torch's own float32 kernels
         self.fb = torch.from_numpy(np.ascontiguousarray(K.mel_matrix(cfg, np.float32).astype(np.float32)))  # (fft/2+1, M)
         self.eps = torch.tensor(torch.finfo(torch.float32).eps)
+        if self.device.type != "cpu":  # the reference's own GPU mode: the same ops on device tensors (FbankConfig(device="cuda"))
+            self.window, self.fb, self.eps = self.window.to(self.device), self.fb.to(self.device), self.eps.to(self.device)
 
     def strided(self, x: torch.Tensor) -> torch.Tensor:
         """layers.py:727-772 (snip_edges=False): reflect by flip/cat, then an as_strided view."""
@@ -46,6 +49,22 @@ class TorchFbank:
         else:
             x = torch.cat((pad_left, x[:, :npad_right]), dim=1)
         return x.as_strided((x.shape[0], T, self.n), (x.stride(0), self.shift * x.stride(1), x.stride(1)))
+
+    @torch.no_grad()
+    def forward_batch(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, S) equal-length batch on self.device -> (B, T, M): Wav2LogFilterBank.forward on a batch (layers.py:322-324)."""
+        c = self.cfg
+        x = self.strided(x)
+        if c.remove_dc_offset:
+            x = x - torch.mean(x, dim=2, keepdim=True)
+        if c.preemph_coeff != 0.0:
+            off = torch.nn.functional.pad(x, (1, 0), mode="replicate")
+            x = x - c.preemph_coeff * off[:, :, :-1]
+        x = x * self.window
+        if self.fft != self.n:
+            x = torch.nn.functional.pad(x.unsqueeze(1), [0, self.fft - self.n], mode="constant", value=0.0).squeeze(1)
+        pow_spec = torch.fft.rfft(x, dim=-1).abs() ** 2
+        return torch.max(torch.matmul(pow_spec, self.fb), self.eps).log()
 
     @torch.no_grad()
     def extract(self, samples: np.ndarray) -> np.ndarray:
