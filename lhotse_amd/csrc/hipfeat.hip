@@ -578,6 +578,7 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
   p->kernel_name = nm;
   p->variant = 5;
   p->fpb = 16;  // 4 waves x 4 frames
+  if (const char* f = getenv("HIPFEAT_WAVE_FPW")) p->fpb = 4 * std::max(1, atoi(f));  // experiments
   return HIPFEAT_OK;
 }
 
