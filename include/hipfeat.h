@@ -61,7 +61,11 @@ typedef enum hipfeat_kind {
    * "reflect" edges without repeating the edge sample, fft_length == frame_length (any size, direct DFT),
    * S / shift computed frames, log10(max(mel, mel_floor)) clamped to (per-cut max - 8), then (x + 4) / 4,
    * and (S + shift/2) / shift output rows, the extra one (if any) all zeros.  window / mel as for HIPFEAT_FBANK. */
-  HIPFEAT_WHISPER = 4
+  HIPFEAT_WHISPER = 4,
+  /* librosa-style log-mel (lhotse/features/librosa_fbank.py:66-137): the arithmetic of HIPFEAT_FBANK (set use_fft_mag = 1
+   * for librosa's |X|) on centred frames with "reflect" edges (librosa.stft center=True, pad_mode="reflect"), log10 instead of
+   * ln, (S + shift/2) / shift rows.  window = periodic hann of fft_length samples, mel = slaney filters (caller's values). */
+  HIPFEAT_LIBROSA_FBANK = 5
 } hipfeat_kind;
 
 /*

@@ -30,11 +30,15 @@ from .input_strategies import HipOnTheFlyFeatures  # noqa: F401,E402
 
 from .whisper import HipWhisperFbank, HipWhisperFbankConfig  # noqa: F401,E402
 
+from .librosa_fbank import HipLibrosaFbank, HipLibrosaFbankConfig  # noqa: F401,E402
+
 from .storage import compute_and_store_features_batch  # noqa: F401,E402
 
 __all__ = [
     "compute_and_store_features_batch",
     "HipWhisperFbank",
+    "HipLibrosaFbank",
+    "HipLibrosaFbankConfig",
     "HipWhisperFbankConfig",
     "HipOnTheFlyFeatures",
     "HipKaldifeatFbank",

@@ -108,6 +108,29 @@ def make_htk_mel(num_filters: int, fft: int, sampling_rate: int, low_freq: float
     return np.ascontiguousarray(out, dtype=np.float32)
 
 
+def make_stft_window(window: str, win_length: int, fft: int) -> np.ndarray:
+    """The analysis window of ``librosa.stft(window=..., win_length=...)``: ``scipy.signal.get_window(window, win_length,
+    fftbins=True)`` (periodic) zero-padded on both sides to ``fft`` samples (librosa.util.pad_center)."""
+    n = np.arange(win_length, dtype=np.float64)
+    x = 2.0 * np.pi * n / win_length
+    if window in ("hann", "hanning"):
+        w = 0.5 - 0.5 * np.cos(x)
+    elif window == "hamming":
+        w = 0.54 - 0.46 * np.cos(x)
+    elif window == "blackman":
+        w = 0.42 - 0.5 * np.cos(x) + 0.08 * np.cos(2.0 * x)
+    elif window in ("boxcar", "rectangular", "ones", "rect", "box"):
+        w = np.ones(win_length)
+    else:
+        from scipy.signal import get_window  # any other scipy window name
+
+        w = get_window(window, win_length, fftbins=True)
+    left = (fft - win_length) // 2
+    out = np.zeros(fft, dtype=np.float64)
+    out[left : left + win_length] = w
+    return out.astype(np.float32)
+
+
 def make_dct(num_ceps: int, num_filters: int) -> np.ndarray:
     """(num_filters, num_ceps) DCT-II basis, first column scaled by 1/sqrt(2)."""
     rows = torch.arange(float(num_filters)).unsqueeze(1)
@@ -162,12 +185,14 @@ def _slaney_mel_to_hz(m):
     return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), m * (200.0 / 3.0))
 
 
-def make_slaney_mel(num_filters: int, fft: int, sampling_rate: int) -> np.ndarray:
-    """(fft/2+1, M) float32 -- the transpose of ``librosa.filters.mel(sr, n_fft, n_mels)`` (slaney mel scale, triangles
-    built from frequency ramps, area ("slaney") normalisation), which the reference loads in
-    lhotse/features/whisper_fbank.py:116-119 and multiplies from the left (:65)."""
+def make_slaney_mel(num_filters: int, fft: int, sampling_rate: int, fmin: float = 0.0, fmax: Optional[float] = None) -> np.ndarray:
+    """(fft/2+1, M) float32 -- the transpose of ``librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax)`` (slaney mel scale,
+    triangles built from frequency ramps, area ("slaney") normalisation), which the reference loads in
+    lhotse/features/whisper_fbank.py:116-119 and multiplies from the left (:65), and builds with fmin/fmax in
+    lhotse/features/librosa_fbank.py:121-125."""
+    fmax = sampling_rate / 2.0 if fmax is None else float(fmax)
     bins = np.fft.rfftfreq(fft, 1.0 / sampling_rate)
-    edges = _slaney_mel_to_hz(np.linspace(_slaney_hz_to_mel(0.0), _slaney_hz_to_mel(sampling_rate / 2.0), num_filters + 2))
+    edges = _slaney_mel_to_hz(np.linspace(_slaney_hz_to_mel(float(fmin)), _slaney_hz_to_mel(fmax), num_filters + 2))
     width = np.diff(edges)
     ramps = edges[:, None] - bins[None, :]
     rising = -ramps[:-2] / width[:-1, None]

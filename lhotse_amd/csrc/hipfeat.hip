@@ -327,7 +327,8 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
   const bool mfcc = c.kind == HIPFEAT_MFCC;
   const bool spec = c.kind == HIPFEAT_SPECTROGRAM || c.kind == HIPFEAT_LOG_SPECTROGRAM;
-  if (c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || (!spec && c.use_fft_mag) || getenv("HIPFEAT_NO_FAST")) return HIPFEAT_OK;
+  if (c.kind > HIPFEAT_MFCC || c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || (!spec && c.use_fft_mag) || getenv("HIPFEAT_NO_FAST"))
+    return HIPFEAT_OK;
   if (mfcc && (M > 8 * kMaxDctGroups || c.num_ceps > 64)) return HIPFEAT_OK;
   const int need = (N + 31) / 32;
   const int nrows = need <= 10 ? 10 : (need <= 13 ? 13 : 16);
@@ -540,11 +541,13 @@ static const void* wave_entry() {
 
 static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
   const hipfeat_config& c = p->cfg;
-  if (p->variant != 0 || !p->pow2 || c.kind > HIPFEAT_MFCC || getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_KERNEL")) return HIPFEAT_OK;
+  const bool librosa = c.kind == HIPFEAT_LIBROSA_FBANK;
+  if (p->variant != 0 || !p->pow2 || (c.kind > HIPFEAT_MFCC && !librosa) || getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_KERNEL"))
+    return HIPFEAT_OK;
   const int H = p->H;
   // H = 128 (fft 256) stays on the radix-2 kernel: measured 0.92 M vs 0.72 M cuts/s there; H = 256: 0.46 vs 0.48 M
   if (!(H == 256 || H == 512 || H == 1024) || c.frame_length > 64 * kWaveMaxRegs || c.num_filters > 128) return HIPFEAT_OK;
-  const bool need_mel = c.kind == HIPFEAT_FBANK || c.kind == HIPFEAT_MFCC;
+  const bool need_mel = c.kind == HIPFEAT_FBANK || c.kind == HIPFEAT_MFCC || librosa;
   const int M = need_mel ? c.num_filters : 0;
   hipfeat_status st;
   if (need_mel) {
@@ -671,7 +674,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
     return fail(HIPFEAT_ERR_INVALID, "hipfeat_config.struct_size %d != %zu (ABI mismatch)", cfg->struct_size,
                 sizeof(hipfeat_config));
   const int N = cfg->frame_length, shift = cfg->frame_shift, fft = cfg->fft_length;
-  if (cfg->kind < 0 || cfg->kind > 4) return fail(HIPFEAT_ERR_INVALID, "unknown kind %d", cfg->kind);
+  if (cfg->kind < 0 || cfg->kind > 5) return fail(HIPFEAT_ERR_INVALID, "unknown kind %d", cfg->kind);
   if (N <= 0 || shift <= 0 || fft < N)
     return fail(HIPFEAT_ERR_INVALID, "need frame_length>0, frame_shift>0, fft_length>=frame_length (got %d, %d, %d)",
                 N, shift, fft);
@@ -683,7 +686,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   const bool whisper = cfg->kind == HIPFEAT_WHISPER;
   if (whisper && (fft != N || cfg->snip_edges || cfg->use_energy || cfg->use_fft_mag || cfg->remove_dc_offset || cfg->preemph_coeff != 0.0f))
     return fail(HIPFEAT_ERR_INVALID, "whisper: needs fft_length == frame_length and no snip_edges / energy / magnitude / DC removal / pre-emphasis");
-  const bool need_mel = cfg->kind == HIPFEAT_FBANK || cfg->kind == HIPFEAT_MFCC || whisper;
+  const bool librosa = cfg->kind == HIPFEAT_LIBROSA_FBANK;
+  if (librosa && (cfg->snip_edges || cfg->use_energy))
+    return fail(HIPFEAT_ERR_INVALID, "librosa fbank: snip_edges / use_energy are not defined");
+  const bool need_mel = cfg->kind == HIPFEAT_FBANK || cfg->kind == HIPFEAT_MFCC || whisper || librosa;
   if (need_mel && (cfg->num_filters <= 0 || !h_mel))
     return fail(HIPFEAT_ERR_INVALID, "fbank/mfcc need num_filters>0 and a mel matrix");
   if (cfg->kind == HIPFEAT_MFCC) {
@@ -701,10 +707,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   p->H = p->pow2 ? fft / 2 : 0;
   p->log2H = 0;
   while (p->pow2 && (1 << p->log2H) < p->H) ++p->log2H;
-  p->npad_left = whisper ? N / 2 : (cfg->snip_edges ? 0 : (N - shift) / 2);
+  p->npad_left = (whisper || librosa) ? N / 2 : (cfg->snip_edges ? 0 : (N - shift) / 2);
   const int M = need_mel ? cfg->num_filters : 0;
   const int C = cfg->kind == HIPFEAT_MFCC ? cfg->num_ceps : 0;
-  p->feature_dim = cfg->kind == HIPFEAT_FBANK ? M + (cfg->use_energy ? 1 : 0) : (cfg->kind == HIPFEAT_MFCC ? C : (whisper ? M : p->K));
+  p->feature_dim = cfg->kind == HIPFEAT_FBANK ? M + (cfg->use_energy ? 1 : 0) : (cfg->kind == HIPFEAT_MFCC ? C : ((whisper || librosa) ? M : p->K));
 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
@@ -822,8 +828,8 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
     if (S < 0 || P < S || P > INT32_MAX)
       return fail(HIPFEAT_ERR_INVALID, "cut %lld: num_samples=%lld padded_len=%lld out of range", (long long)b, (long long)S, (long long)P);
     int64_t T = hipfeat_num_frames(S, c.frame_length, c.frame_shift, c.snip_edges);
-    if (c.kind == HIPFEAT_WHISPER) {
-      if (P != S) return fail(HIPFEAT_ERR_INVALID, "whisper: zero-padded batch rows (padded_len != num_samples) are not defined");
+    if (c.kind == HIPFEAT_WHISPER || c.kind == HIPFEAT_LIBROSA_FBANK) {
+      if (P != S) return fail(HIPFEAT_ERR_INVALID, "centred framing: zero-padded batch rows (padded_len != num_samples) are not defined");
       if (S <= c.frame_length / 2)  // torch.stft: reflect padding must be shorter than the signal
         return fail(HIPFEAT_ERR_TOO_SHORT, "cut %lld: %lld samples are not longer than the reflect padding (%d)", (long long)b, (long long)S,
                     c.frame_length / 2);
@@ -834,7 +840,7 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
       T = std::min<int64_t>((S + c.frame_shift / 2) / c.frame_shift,
                             hipfeat_num_frames(P, c.frame_length, c.frame_shift, c.snip_edges));
     }
-    if (!c.snip_edges && T > 0 && c.kind != HIPFEAT_WHISPER) {
+    if (!c.snip_edges && T > 0 && c.kind != HIPFEAT_WHISPER && c.kind != HIPFEAT_LIBROSA_FBANK) {
       hipfeat_status st = hipfeat_check_length(P, c.frame_length, c.frame_shift, 0);
       if (st != HIPFEAT_OK) return st;
     }
@@ -945,9 +951,10 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     wp.M = c.num_filters;
     wp.C = c.num_ceps;
     wp.maxband = plan->mel_maxband;
-    wp.kind = c.kind;
+    const bool librosa = c.kind == HIPFEAT_LIBROSA_FBANK;
+    wp.kind = librosa ? (int)HIPFEAT_FBANK : c.kind;
     wp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0) | (c.use_energy ? F_USE_ENERGY : 0) | (c.raw_energy ? F_RAW_ENERGY : 0) |
-               (c.use_fft_mag ? F_FFT_MAG : 0) | (c.apply_lifter ? F_LIFTER : 0);
+               (c.use_fft_mag ? F_FFT_MAG : 0) | (c.apply_lifter ? F_LIFTER : 0) | (librosa ? (F_CENTER | F_LOG10) : 0);
     wp.npad_left = plan->npad_left;
     wp.preemph = c.preemph_coeff;
     wp.log_energy_floor = c.energy_floor > 0.0f ? logf(c.energy_floor) : -INFINITY;
@@ -1077,10 +1084,10 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
   gp.K = plan->K;
   gp.M = c.num_filters;
   gp.C = c.num_ceps;
-  const bool whisper = c.kind == HIPFEAT_WHISPER;
-  gp.kind = whisper ? (int)HIPFEAT_FBANK : c.kind;  // same epilogue with log10; the post-pass below finishes it
+  const bool whisper = c.kind == HIPFEAT_WHISPER, librosa = c.kind == HIPFEAT_LIBROSA_FBANK;
+  gp.kind = (whisper || librosa) ? (int)HIPFEAT_FBANK : c.kind;  // same epilogue with log10; the post-pass below finishes it
   gp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0) | (c.use_energy ? F_USE_ENERGY : 0) | (c.raw_energy ? F_RAW_ENERGY : 0) |
-             (c.use_fft_mag ? F_FFT_MAG : 0) | (c.apply_lifter ? F_LIFTER : 0) | (plan->pow2 ? F_POW2 : 0) | (whisper ? (F_CENTER | F_LOG10) : 0);
+             (c.use_fft_mag ? F_FFT_MAG : 0) | (c.apply_lifter ? F_LIFTER : 0) | (plan->pow2 ? F_POW2 : 0) | ((whisper || librosa) ? (F_CENTER | F_LOG10) : 0);
   gp.fpb = plan->fpb;
   gp.npad_left = plan->npad_left;
   gp.preemph = c.preemph_coeff;

@@ -146,7 +146,7 @@ __device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw
   wave_lds_sync();
 }
 
-constexpr int kWaveMaxRegs = 20;  // ceil(N / 64) sample registers per lane: N <= 1280
+constexpr int kWaveMaxRegs = 32;  // ceil(N / 64) sample registers per lane: N <= 2048
 
 #ifndef HIPFEAT_WAVE_OCC
 #define HIPFEAT_WAVE_OCC 4
@@ -194,7 +194,9 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
 #pragma unroll
     for (int r = 0; r < NREG; ++r) {
       const int m = lane + 64 * r;
-      x[r] = (r < nreg && m < N && !(p.ablate & 8)) ? load_sample(w, j0 + m, cd.num_samples, cd.padded_len) : 0.f;
+      x[r] = (r < nreg && m < N && !(p.ablate & 8))
+                 ? ((p.flags & F_CENTER) ? load_sample_center(w, j0 + m, cd.num_samples) : load_sample(w, j0 + m, cd.num_samples, cd.padded_len))
+                 : 0.f;
       s += x[r];
     }
     float mean = 0.f;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
         acc += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(acc);
         acc += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(acc);
         if (j < M && sub == 0) {
-          const float v = logf(fmaxf(acc, p.mel_floor));
+          const float v = (p.flags & F_LOG10) ? log10f(fmaxf(acc, p.mel_floor)) : logf(fmaxf(acc, p.mel_floor));
           if (p.kind == 2) orow[ecol + j] = v;
           else buf[2 * H - 120 + j] = v;  // MFCC: log-mel vector stashed behind the power row (K = H + 1 <= 2H - 120, M <= 128)
         }

@@ -39,7 +39,7 @@ import torch
 from . import _lib, constants
 from .compat import EPSILON, LOG_EPSILON, FeatureExtractor, Seconds, asdict_nonull, compute_num_frames_from_samples, register_extractor
 
-KIND_SPECTROGRAM, KIND_LOG_SPECTROGRAM, KIND_FBANK, KIND_MFCC, KIND_WHISPER = 0, 1, 2, 3, 4
+KIND_SPECTROGRAM, KIND_LOG_SPECTROGRAM, KIND_FBANK, KIND_MFCC, KIND_WHISPER, KIND_LIBROSA_FBANK = 0, 1, 2, 3, 4, 5
 EDGE_RULES = ("reflect", "batch_zero_pad")
 
 ArrayLike = Union[np.ndarray, torch.Tensor]
@@ -185,15 +185,22 @@ class _Plan:
         if not torch.cuda.is_available():
             raise _lib.HipFeatError(2, "no HIP device is visible (torch.cuda.is_available() is False); there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device() if device.index is None else device.index)
-        n, shift, fft = constants.frame_sizes(cfg.sampling_rate, cfg.frame_length, cfg.frame_shift, cfg.round_to_power_of_two)
+        if kind == KIND_LIBROSA_FBANK:  # sizes in samples; the window is the zero-padded STFT window (librosa_fbank.py:111-118)
+            n = fft = int(cfg.fft_size)
+            shift = int(cfg.hop_size)
+            window = constants.make_stft_window(cfg.window, int(cfg.win_length or fft), fft)
+        else:
+            n, shift, fft = constants.frame_sizes(cfg.sampling_rate, cfg.frame_length, cfg.frame_shift, cfg.round_to_power_of_two)
+            window = constants.make_window(n, cfg.window_type, getattr(cfg, "blackman_coeff", 0.42))
         self.n, self.shift, self.fft = n, shift, fft
-        window = constants.make_window(n, cfg.window_type, getattr(cfg, "blackman_coeff", 0.42))
         mel = dct = lifter = None
         num_filters = num_ceps = 0
         apply_lifter = 0
-        if kind in (KIND_FBANK, KIND_MFCC, KIND_WHISPER):
+        if kind in (KIND_FBANK, KIND_MFCC, KIND_WHISPER, KIND_LIBROSA_FBANK):
             num_filters = int(cfg.num_filters)
-            if kind == KIND_WHISPER:
+            if kind == KIND_LIBROSA_FBANK:
+                mel = constants.make_slaney_mel(num_filters, fft, cfg.sampling_rate, cfg.fmin or 0.0, cfg.fmax)
+            elif kind == KIND_WHISPER:
                 mel = constants.make_slaney_mel(num_filters, fft, cfg.sampling_rate)
             elif cfg.torchaudio_compatible_mel_scale:
                 mel = constants.make_kaldi_mel(num_filters, fft, cfg.sampling_rate, cfg.low_freq, cfg.high_freq)

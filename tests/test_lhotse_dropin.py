@@ -47,6 +47,9 @@ def lhotse_mod():
 
         importlib.reload(ins)
         importlib.reload(wh)
+        import lhotse_amd.librosa_fbank as lf
+
+        importlib.reload(lf)
         import lhotse_amd.storage as st
 
         importlib.reload(st)
