@@ -193,6 +193,33 @@ HIPFEAT_API hipfeat_status hipfeat_extract_collated(const hipfeat_plan* plan, co
  * (so features are bit-identical to the float32 path); lets the host send half the bytes over PCIe. */
 HIPFEAT_API hipfeat_status hipfeat_pcm16_to_float(const int16_t* d_pcm, float* d_wave, int64_t num_samples, void* stream);
 
+/* ---- "next" row: post-feature transforms on the collated (B, T, F) batch ------- */
+/* GlobalMVN.forward: (x - means) / stds, and .inverse: x * stds + means, over `rows` rows of `feature_dim` floats
+ * (lhotse/dataset/signal_transforms.py:50-60).  IEEE single operations in the reference's order: bit-identical. */
+HIPFEAT_API hipfeat_status hipfeat_global_mvn(const float* d_in, float* d_out, const float* d_means, const float* d_stds, int64_t rows,
+                                              int64_t feature_dim, int inverse, void* stream);
+/*
+ * SpecAugment._forward_single for every sequence of a batch in two launches
+ * (lhotse/dataset/signal_transforms.py:173-266): d_out = clone of d_in with
+ *   - every warp segment time-warped: rows [0, center) of the segment are resampled to [0, warped) and rows
+ *     [center, num_frames) to [warped, num_frames) with torch's bicubic interpolation (time_warp, :338-371;
+ *     F.interpolate(mode="bicubic", align_corners=False)).  `center` and `warped` are the two np.random.randint draws;
+ *     segments of one sequence must not overlap (the reference applies them one after another);
+ *   - every mask region set to the mean of ITS sequence (all num_frames * feature_dim values, after warping):
+ *     axis 1 = frames [begin, end), axis 2 = feature bins [begin, end) (mask_along_axis_optimized, :297-335).
+ * The random draws stay with the caller (the host mirror makes them with the reference's RNG calls in the reference's order).
+ * Descriptors are host arrays; the call is asynchronous on `stream`.  d_in and d_out must not alias.
+ */
+typedef struct hipfeat_warp_segment {
+  int32_t sequence, start, num_frames, center, warped;
+} hipfeat_warp_segment;
+typedef struct hipfeat_mask {
+  int32_t sequence, axis, begin, end;
+} hipfeat_mask;
+HIPFEAT_API hipfeat_status hipfeat_specaug(const float* d_in, float* d_out, int64_t batch, int64_t num_frames, int64_t feature_dim,
+                                           const hipfeat_warp_segment* h_segments, int64_t num_segments, const hipfeat_mask* h_masks,
+                                           int64_t num_masks, void* stream);
+
 /* ---- "next" row: speed perturbation = polyphase sinc resampling --------------- */
 /*
  * Replaces ResampleTensor (lhotse/augmentation/resample.py:42-142, :284-315) as used by

@@ -32,12 +32,16 @@ from .whisper import HipWhisperFbank, HipWhisperFbankConfig  # noqa: F401,E402
 
 from .librosa_fbank import HipLibrosaFbank, HipLibrosaFbankConfig  # noqa: F401,E402
 
+from .signal_transforms import HipGlobalMVN, HipSpecAugment  # noqa: F401,E402
+
 from .storage import compute_and_store_features_batch  # noqa: F401,E402
 
 __all__ = [
     "compute_and_store_features_batch",
     "HipWhisperFbank",
     "HipLibrosaFbank",
+    "HipGlobalMVN",
+    "HipSpecAugment",
     "HipLibrosaFbankConfig",
     "HipWhisperFbankConfig",
     "HipOnTheFlyFeatures",

@@ -54,6 +54,11 @@ _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
          "int64_t*", "void*"],
     ),
     "hipfeat_pcm16_to_float": ("int", ["const int16_t*", "float*", "int64_t", "void*"]),
+    "hipfeat_global_mvn": ("int", ["const float*", "float*", "const float*", "const float*", "int64_t", "int64_t", "int", "void*"]),
+    "hipfeat_specaug": (
+        "int",
+        ["const float*", "float*", "int64_t", "int64_t", "int64_t", "const hipfeat_warp_segment*", "int64_t", "const hipfeat_mask*", "int64_t", "void*"],
+    ),
     "hipfeat_resampler_create": ("int", ["int32_t", "int32_t", "int32_t", "const float*", "int32_t", "hipfeat_resampler**"]),
     "hipfeat_resampler_destroy": ("int", ["hipfeat_resampler*"]),
     "hipfeat_resampled_length": ("int64_t", ["int64_t", "int32_t", "int32_t"]),
@@ -91,6 +96,10 @@ CONFIG_DTYPE = np.dtype(
     ],
     align=True,
 )
+
+# numpy mirrors of `hipfeat_warp_segment` / `hipfeat_mask`
+WARP_SEGMENT_DTYPE = np.dtype([("sequence", "<i4"), ("start", "<i4"), ("num_frames", "<i4"), ("center", "<i4"), ("warped", "<i4")])
+MASK_DTYPE = np.dtype([("sequence", "<i4"), ("axis", "<i4"), ("begin", "<i4"), ("end", "<i4")])
 
 STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "HIP", 3: "UNSUPPORTED", 4: "TOO_SHORT"}
 ERR_INVALID = 1

@@ -19,6 +19,7 @@
 #include "kernel_fft512.hpp"
 #include "kernel_fft512b.hpp"
 #include "kernel_resample.hpp"
+#include "kernel_specaug.hpp"
 #include "kernel_whisper.hpp"
 #include "kernel_fft256.hpp"
 #include "kernel_wave.hpp"
@@ -1294,6 +1295,149 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_extract_host(const hipfeat_plan* p
   if (st != HIPFEAT_OK) return st;
   if (out_elems) HIP_TRY(hipMemcpyAsync(h_out, dout, (size_t)out_elems * sizeof(float), hipMemcpyDeviceToHost, st_));
   HIP_TRY(hipStreamSynchronize(st_));
+  return HIPFEAT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// post-feature transforms on the collated batch (GlobalMVN, SpecAugment)
+// --------------------------------------------------------------------------------------
+extern "C" HIPFEAT_API hipfeat_status hipfeat_global_mvn(const float* d_in, float* d_out, const float* d_means, const float* d_stds,
+                                                         int64_t rows, int64_t feature_dim, int inverse, void* stream) {
+  if (rows < 0 || feature_dim <= 0 || feature_dim > INT32_MAX || (rows > 0 && (!d_in || !d_out)) || !d_means || !d_stds)
+    return fail(HIPFEAT_ERR_INVALID, "bad global_mvn arguments");
+  const int64_t n = rows * feature_dim;
+  if (n == 0) return HIPFEAT_OK;
+  const int64_t blocks = std::min<int64_t>((n + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(global_mvn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_in, d_out, d_means, d_stds, n,
+                     (int32_t)feature_dim, (int32_t)(inverse != 0));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "global_mvn launch failed: %s", hipGetErrorName(e));
+  return HIPFEAT_OK;
+}
+
+namespace {
+struct StagingRing {
+  std::mutex mu;
+  StagingSlot slots[4];
+  int next = 0;
+};
+StagingRing g_rings[64];  // per device, process lifetime (descriptors of plan-less calls)
+}  // namespace
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_specaug(const float* d_in, float* d_out, int64_t batch, int64_t num_frames, int64_t feature_dim,
+                                                      const hipfeat_warp_segment* h_segments, int64_t num_segments,
+                                                      const hipfeat_mask* h_masks, int64_t num_masks, void* stream) {
+  if (batch < 0 || num_frames < 0 || feature_dim < 0 || num_segments < 0 || num_masks < 0 || (num_segments && !h_segments) ||
+      (num_masks && !h_masks))
+    return fail(HIPFEAT_ERR_INVALID, "bad specaug arguments");
+  if (batch > 65535 || num_frames > (1 << 24) || feature_dim > 32768)
+    return fail(HIPFEAT_ERR_INVALID, "specaug: batch <= 65535, num_frames <= 2^24, feature_dim <= 32768");
+  if (batch * num_frames * feature_dim == 0) return HIPFEAT_OK;
+  if (!d_in || !d_out || d_in == d_out) return fail(HIPFEAT_ERR_INVALID, "specaug: needs distinct input and output buffers");
+  const int B = (int)batch, T = (int)num_frames, F = (int)feature_dim;
+  // group by sequence (stable), validate
+  std::vector<int32_t> seg_off((size_t)B + 1, 0), mask_off((size_t)B + 1, 0);
+  for (int64_t i = 0; i < num_segments; ++i) {
+    const hipfeat_warp_segment& g = h_segments[i];
+    if (g.sequence < 0 || g.sequence >= B || g.start < 0 || g.num_frames < 2 || g.start + (int64_t)g.num_frames > T || g.center < 1 ||
+        g.center >= g.num_frames || g.warped < 1 || g.warped >= g.num_frames)
+      return fail(HIPFEAT_ERR_INVALID, "specaug: warp segment %lld is out of range", (long long)i);
+    seg_off[(size_t)g.sequence + 1]++;
+  }
+  for (int64_t i = 0; i < num_masks; ++i) {
+    const hipfeat_mask& m = h_masks[i];
+    if (m.sequence < 0 || m.sequence >= B || (m.axis != 1 && m.axis != 2) || m.begin < 0 || m.end < m.begin)
+      return fail(HIPFEAT_ERR_INVALID, "specaug: mask %lld is out of range", (long long)i);
+    mask_off[(size_t)m.sequence + 1]++;
+  }
+  for (int b = 0; b < B; ++b) {
+    seg_off[(size_t)b + 1] += seg_off[(size_t)b];
+    mask_off[(size_t)b + 1] += mask_off[(size_t)b];
+  }
+  std::vector<WarpSeg> segs((size_t)num_segments);
+  std::vector<int32_t> masks((size_t)num_masks * 3);
+  {
+    std::vector<int32_t> cur(seg_off.begin(), seg_off.end() - 1);
+    for (int64_t i = 0; i < num_segments; ++i) {
+      const hipfeat_warp_segment& g = h_segments[i];
+      segs[(size_t)cur[(size_t)g.sequence]++] = WarpSeg{g.sequence, g.start, g.num_frames, g.center, g.warped};
+    }
+    for (int b = 0; b < B; ++b)  // the reference warps segment after segment: overlapping ones would read each other's output
+      for (int i = seg_off[(size_t)b]; i < seg_off[(size_t)b + 1]; ++i)
+        for (int j = i + 1; j < seg_off[(size_t)b + 1]; ++j)
+          if (segs[(size_t)i].start < segs[(size_t)j].start + segs[(size_t)j].len && segs[(size_t)j].start < segs[(size_t)i].start + segs[(size_t)i].len)
+            return fail(HIPFEAT_ERR_INVALID, "specaug: warp segments of sequence %d overlap (apply them in separate calls)", b);
+    std::vector<int32_t> mc(mask_off.begin(), mask_off.end() - 1);
+    for (int64_t i = 0; i < num_masks; ++i) {
+      const hipfeat_mask& m = h_masks[i];
+      const size_t k = (size_t)mc[(size_t)m.sequence]++ * 3;
+      masks[k] = m.axis;
+      masks[k + 1] = m.begin;
+      masks[k + 2] = m.end;
+    }
+  }
+  int tile_elems = 8192;
+  if (const char* t = getenv("HIPFEAT_SPECAUG_TILE")) tile_elems = std::max(256, atoi(t));  // experiments
+  const int rows_per_tile = std::max(1, std::min(T, tile_elems / std::max(F, 1)));
+  const int tiles = (T + rows_per_tile - 1) / rows_per_tile;
+  auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t o_seg_off = 0, o_mask_off = up16(o_seg_off + seg_off.size() * 4), o_segs = up16(o_mask_off + mask_off.size() * 4),
+               o_masks = up16(o_segs + segs.size() * sizeof(WarpSeg)), o_part = up16(o_masks + masks.size() * 4),
+               h_bytes = o_part, total = o_part + (size_t)B * tiles * 4;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(HIPFEAT_ERR_INVALID, "device index %d out of range", dev);
+  StagingRing& ring = g_rings[dev];
+  std::lock_guard<std::mutex> lk(ring.mu);
+  StagingSlot& sl = ring.slots[ring.next];
+  ring.next = (ring.next + 1) % 4;
+  if (sl.busy) {
+    HIP_TRY(hipEventSynchronize(sl.ev));
+    sl.busy = false;
+  }
+  if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+  if (sl.cap < total) {
+    if (sl.h) (void)hipHostFree(sl.h);
+    if (sl.d) (void)hipFree(sl.d);
+    sl.h = sl.d = nullptr;
+    sl.cap = 0;
+    const size_t cap = std::max<size_t>(total * 2, 1 << 16);
+    HIP_TRY(hipHostMalloc(&sl.h, cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&sl.d, cap));
+    sl.cap = cap;
+  }
+  char* h = static_cast<char*>(sl.h);
+  std::memcpy(h + o_seg_off, seg_off.data(), seg_off.size() * 4);
+  std::memcpy(h + o_mask_off, mask_off.data(), mask_off.size() * 4);
+  if (!segs.empty()) std::memcpy(h + o_segs, segs.data(), segs.size() * sizeof(WarpSeg));
+  if (!masks.empty()) std::memcpy(h + o_masks, masks.data(), masks.size() * 4);
+  hipStream_t st_ = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(sl.d, sl.h, h_bytes, hipMemcpyHostToDevice, st_));
+  char* d = static_cast<char*>(sl.d);
+  SpecAugParams sp{};
+  sp.in = d_in;
+  sp.out = d_out;
+  sp.B = B;
+  sp.T = T;
+  sp.F = F;
+  sp.seg_off = reinterpret_cast<const int32_t*>(d + o_seg_off);
+  sp.mask_off = reinterpret_cast<const int32_t*>(d + o_mask_off);
+  sp.segs = reinterpret_cast<const WarpSeg*>(d + o_segs);
+  sp.masks = reinterpret_cast<const int32_t*>(d + o_masks);
+  sp.partials = reinterpret_cast<float*>(d + o_part);
+  sp.tiles = tiles;
+  sp.rows_per_tile = rows_per_tile;
+  const bool vec4 = F % 4 == 0 && ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15) == 0;
+  if (vec4) hipLaunchKernelGGL(specaug_warp_kernel<4>, dim3((unsigned)tiles, (unsigned)B), dim3(256), 0, st_, sp);
+  else hipLaunchKernelGGL(specaug_warp_kernel<1>, dim3((unsigned)tiles, (unsigned)B), dim3(256), 0, st_, sp);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && num_masks > 0) {
+    hipLaunchKernelGGL(specaug_mask_kernel, dim3((unsigned)tiles, (unsigned)B), dim3(256), (size_t)F + rows_per_tile, st_, sp);
+    e = hipGetLastError();
+  }
+  hipError_t e2 = hipEventRecord(sl.ev, st_);
+  sl.busy = (e2 == hipSuccess);
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "specaug launch failed: %s", hipGetErrorName(e));
   return HIPFEAT_OK;
 }
 
