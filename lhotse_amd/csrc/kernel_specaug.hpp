@@ -67,8 +67,11 @@ __global__ __launch_bounds__(256) void specaug_warp_kernel(SpecAugParams p) {
   float* __restrict__ dst = p.out + (int64_t)b * p.T * F;
   float acc = 0.f;
   const int n = nrows * FV;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int rr = i / FV, col = (i - rr * FV) * V;
+  const int drr = 256 / FV, dcc = 256 - drr * FV;  // (row, column) of element i + 256 from those of element i: no division in the loop
+  int rr = threadIdx.x / FV, cc = threadIdx.x - rr * FV;
+  for (int i = threadIdx.x; i < n; i += 256, rr += drr, cc += dcc) {
+    if (cc >= FV) { cc -= FV; ++rr; }
+    const int col = cc * V;
     const int row = r0 + rr;
     float v[V];
     int hit = -1;
@@ -157,10 +160,15 @@ __global__ __launch_bounds__(256) void specaug_mask_kernel(SpecAugParams p) {
   if (!any) return;  // uniform across the block
   __syncthreads();
   float* __restrict__ dst = p.out + ((int64_t)b * p.T + r0) * F;
-  const int n = nrows * F;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int rr = i / F, col = i - rr * F;
-    if (rowf[rr] | colf[col]) dst[i] = mean;
+  const int lane = threadIdx.x & 63;
+  for (int rr = threadIdx.x >> 6; rr < nrows; rr += 4) {  // a wave per row: no index arithmetic, 256-byte store bursts
+    float* __restrict__ row = dst + (int64_t)rr * F;
+    if (rowf[rr]) {
+      for (int c = lane; c < F; c += 64) row[c] = mean;
+    } else {
+      for (int c = lane; c < F; c += 64)
+        if (colf[c]) row[c] = mean;
+    }
   }
 }
 
