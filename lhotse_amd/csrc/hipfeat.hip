@@ -106,8 +106,10 @@ struct hipfeat_plan {
   float* d_mel_a = nullptr;
   WaveWork* d_work = nullptr;
   // wave-per-frame kernel (variant 5)
-  float* d_mel_t = nullptr;
+  float* d_mel_t = nullptr;  // filterbank blob (descriptors + compact weights)
   int mel_maxband = 0;
+  int wave_blob_floats = 0;
+  bool wave_dct_in_lds = false;
   size_t wave_lds_bytes = 0;
   // whisper fast path (variant 3)
   float* d_wh_dft = nullptr;
@@ -565,13 +567,33 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
       rng[j] = make_int2(lo, hi);
       maxband = std::max(maxband, hi - lo);
     }
-    std::vector<float> mt((size_t)maxband * M, 0.0f);  // mel_t[t][j] = W[lo_j + t][j]
-    for (int j = 0; j < M; ++j)
-      for (int k = rng[j].x; k < rng[j].y; ++k) mt[(size_t)(k - rng[j].x) * M + j] = h_mel[(size_t)k * M + j];
-    if ((st = upload(&p->d_mel_t, mt.data(), mt.size())) != HIPFEAT_OK) return st;
+    // blob = [M] int4 {lo rounded down to a multiple of 4, offset of the filter's weights, number of float4 groups, 0} followed
+    // by the weights themselves, each filter zero-padded to whole float4 groups
+    std::vector<int32_t> desc((size_t)4 * M, 0);
+    std::vector<float> wts;
+    for (int j = 0; j < M; ++j) {
+      const int lo4 = rng[j].x & ~3;
+      const int groups = rng[j].y > rng[j].x ? (rng[j].y - lo4 + 3) / 4 : 0;
+      desc[(size_t)4 * j] = lo4;
+      desc[(size_t)4 * j + 1] = (int32_t)wts.size();
+      desc[(size_t)4 * j + 2] = groups;
+      for (int t = 0; t < 4 * groups; ++t) {
+        const int k = lo4 + t;
+        wts.push_back(k < p->K ? h_mel[(size_t)k * M + j] : 0.0f);
+      }
+    }
+    std::vector<float> blob((size_t)4 * M + wts.size());
+    std::memcpy(blob.data(), desc.data(), desc.size() * sizeof(int32_t));
+    std::memcpy(blob.data() + 4 * M, wts.data(), wts.size() * sizeof(float));
+    if ((st = upload(&p->d_mel_t, blob.data(), blob.size())) != HIPFEAT_OK) return st;
     p->mel_maxband = maxband;
+    p->wave_blob_floats = (int)blob.size();
   }
-  p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)144 * (H / 64) + 8) + (size_t)c.frame_length) * sizeof(float);  // twiddles + 4 padded wave buffers + window
+  p->wave_dct_in_lds = c.kind == HIPFEAT_MFCC && (size_t)M * c.num_ceps <= 2560;
+  auto up4 = [](size_t v) { return (v + 3) & ~(size_t)3; };
+  // twiddles + 4 padded wave buffers + window + filterbank blob (+ DCT matrix)
+  p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)144 * (H / 64) + 8) + up4((size_t)c.frame_length) + up4((size_t)p->wave_blob_floats) +
+                       (p->wave_dct_in_lds ? (size_t)M * c.num_ceps : 0)) * sizeof(float);
   const void* fn = H == 256 ? wave_entry<4>() : (H == 512 ? wave_entry<8>() : wave_entry<16>());
   hipError_t e = ensure_dynamic_lds(fn, p->wave_lds_bytes);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(wave) failed: %s", hipGetErrorName(e));
@@ -937,8 +959,9 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     wp.cuts = lay->d_cuts;
     wp.window = plan->d_window;
     wp.tw = plan->d_tw;
-    wp.mel_t = plan->d_mel_t;
-    wp.mel_range = plan->d_mel_range;
+    wp.mel_blob = plan->d_mel_t;
+    wp.mel_blob_floats = plan->wave_blob_floats;
+    wp.dct_in_lds = plan->wave_dct_in_lds ? 1 : 0;
     wp.dct = plan->d_dct;
     wp.lifter = plan->d_lifter;
     wp.out_stride = lay->out_row_stride;
@@ -951,7 +974,6 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     wp.K = plan->K;
     wp.M = c.num_filters;
     wp.C = c.num_ceps;
-    wp.maxband = plan->mel_maxband;
     const bool librosa = c.kind == HIPFEAT_LIBROSA_FBANK;
     wp.kind = librosa ? (int)HIPFEAT_FBANK : c.kind;
     wp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0) | (c.use_energy ? F_USE_ENERGY : 0) | (c.raw_energy ? F_RAW_ENERGY : 0) |

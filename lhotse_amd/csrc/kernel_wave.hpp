@@ -24,13 +24,13 @@ struct WaveParams {
   const CutDesc* cuts;
   const float* window;    // [N]
   const float2* tw;       // W_2H^k, k < H
-  const float* mel_t;     // [maxband][M] compact filterbank
-  const int2* mel_range;  // [M] first bin, one-past-last bin
-  const float* dct;       // [M][C]
+  const float* mel_blob;  // [M] int4 {first bin rounded down to 4, offset into the weights, float4 groups, 0}, then the compact
+                          // zero-padded weights: copied to LDS by every workgroup (~1100 + 6 M floats)
+  const float* dct;       // [M][C]  (copied to LDS when dct_in_lds)
   const float* lifter;    // [C]
   int64_t out_stride;
   int32_t num_cuts, uniform_bpc, frames_per_wave;
-  int32_t N, shift, H, K, M, C, maxband;
+  int32_t N, shift, H, K, M, C, mel_blob_floats, dct_in_lds;
   int32_t kind, flags, npad_left;
   float preemph, log_energy_floor, mel_floor, log_offset;
   int32_t ablate;  // experiments (HIPFEAT_WAVE_ABLATE): 1 no FFT, 2 no split/power, 4 no epilogue, 8 no sample loads
@@ -157,6 +157,8 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float2* tw = reinterpret_cast<float2*>(smem);                  // [H]
   float* winl = smem + 2 * H + 4 * (144 * N1 + 8);               // [N] window, shared by the four waves
+  float* melb = winl + ((p.N + 3) & ~3);                          // filterbank descriptors + compact weights
+  float* dctl = melb + ((p.mel_blob_floats + 3) & ~3);            // [M][C] DCT matrix when it fits
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* buf = smem + 2 * H + wv * (144 * N1 + 8);               // wave-private: 72 N1 complex (padded FFT buffer), later the power row
@@ -175,7 +177,13 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
   const float* __restrict__ w = p.wave + cd.wave_off;
   for (int i = tid; i < H; i += 256) tw[i] = p.tw[i];
   for (int i = tid; i < p.N; i += 256) winl[i] = p.window[i];
+  for (int i = tid; i < p.mel_blob_floats; i += 256) melb[i] = p.mel_blob[i];
+  if (p.dct_in_lds)
+    for (int i = tid; i < p.M * p.C; i += 256) dctl[i] = p.dct[i];
   __syncthreads();
+  const int4* meld = reinterpret_cast<const int4*>(melb);
+  const float* melw = melb + 4 * p.M;
+  const float* __restrict__ dctp = p.dct_in_lds ? dctl : p.dct;
 
   const int N = p.N, K = p.K, M = p.M;
   const int nreg = (N + 63) >> 6;
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
       for (int q = 0; q <= N1; ++q) {
         const int k = lane + 64 * q;
         if (k < K) buf[k] = pw[q];
+        else if (k < K + 3) buf[k] = 0.f;  // the float4 reads of the mel stage run up to 3 entries past the row (zero weights)
       }
     }
     wave_lds_sync();
@@ -283,19 +292,25 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
       }
     } else {
       const int ecol = (p.kind == 2 && use_e) ? 1 : 0;
-      // mel: FOUR lanes per filter (16 consecutive filters per round, similar band widths): lane (jj, sub) sums the
-      // taps t = sub, sub + 4, ... of filter j; two DPP adds combine the quarters.  Serial depth = band / 4.
+      // mel: FOUR lanes per filter (16 consecutive filters per round, similar band widths).  Power row, filter
+      // descriptors and the compact weights are all in LDS; a filter's taps start at a multiple of four bins (zero
+      // weights in front and behind), so lane (jj, sub) takes the float4 groups sub, sub + 4, ... with two 16-byte
+      // LDS reads per four multiply-adds; two DPP adds combine the quarters.
       const int jj = lane >> 2, sub = lane & 3;
       for (int j0m = 0; j0m < M; j0m += 16) {
         const int j = j0m + jj;
         float acc = 0.f;
         if (j < M) {
-          const int2 rg = p.mel_range[j];
-          const int len = rg.y - rg.x;
-          const float* __restrict__ mt = p.mel_t + j;
-          const float* pb = buf + rg.x;
-#pragma unroll 4
-          for (int t = sub; t < len; t += 4) acc = fmaf(pb[t], mt[(size_t)t * M], acc);
+          const int4 dsc = meld[j];
+          const float4* pb4 = reinterpret_cast<const float4*>(buf + dsc.x);
+          const float4* mw4 = reinterpret_cast<const float4*>(melw + dsc.y);
+          for (int g = sub; g < dsc.z; g += 4) {
+            const float4 a = pb4[g], b = mw4[g];
+            acc = fmaf(a.x, b.x, acc);
+            acc = fmaf(a.y, b.y, acc);
+            acc = fmaf(a.z, b.z, acc);
+            acc = fmaf(a.w, b.w, acc);
+          }
         }
         acc += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(acc);
         acc += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(acc);
@@ -316,7 +331,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
           float acc = 0.f;
           if (c < p.C) {
 #pragma unroll 4
-            for (int m = sub; m < M; m += 4) acc = fmaf(lmv[m], p.dct[(size_t)m * p.C + c], acc);
+            for (int m = sub; m < M; m += 4) acc = fmaf(lmv[m], dctp[(size_t)m * p.C + c], acc);
           }
           acc += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(acc);
           acc += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(acc);
