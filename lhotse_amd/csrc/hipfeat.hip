@@ -549,7 +549,7 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
     return HIPFEAT_OK;
   const int H = p->H;
   // H = 128 (fft 256) stays on the radix-2 kernel: measured 0.92 M vs 0.72 M cuts/s there; H = 256: 0.46 vs 0.48 M
-  if (!(H == 256 || H == 512 || H == 1024) || c.frame_length > 64 * kWaveMaxRegs || c.num_filters > 128) return HIPFEAT_OK;
+  if (!(H == 256 || H == 512 || H == 1024) || c.num_filters > 128) return HIPFEAT_OK;
   const bool need_mel = c.kind == HIPFEAT_FBANK || c.kind == HIPFEAT_MFCC || librosa;
   const int M = need_mel ? c.num_filters : 0;
   hipfeat_status st;

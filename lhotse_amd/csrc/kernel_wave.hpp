@@ -82,17 +82,16 @@ __device__ __forceinline__ void small_fft(const v2* x, v2* X) {
 //   pass C  FFT_8  over n3 (item = (k1, k2))
 // While the three passes run, element e = 64 n1 + 8 n2 + n3 lives at e + (e >> 3) = 72 n1 + 9 n2 + n3: with these strides
 // the 8-byte accesses of passes B and C are bank-conflict free (unpadded, eight lanes share a bank pair: measured 45 % of
-// the LDS cycles were conflicts).  The caller stores its input with fft3_pad() and gets natural order back.
+// the LDS cycles were conflicts).  Pass A takes its input from registers (lane l holds the elements l + 64 n1, which is how the
+// front end produces them); the result comes back in natural order in LDS.
 __device__ __forceinline__ int fft3_pad(int e) { return e + (e >> 3); }
 
 template <int N1>
-__device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw, int lane) {
+__device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw, int lane, const v2* x) {  // x[n1] = element lane + 64 n1
   constexpr int H = 64 * N1;
   const int lp = lane + (lane >> 3);  // 9 n2 + n3
   {
-    v2 x[N1], A[N1];
-#pragma unroll
-    for (int n1 = 0; n1 < N1; ++n1) x[n1] = zf[72 * n1 + lp];
+    v2 A[N1];
     small_fft<N1>(x, A);
     const int n2 = lane >> 3;
 #pragma unroll
@@ -146,7 +145,6 @@ __device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw
   wave_lds_sync();
 }
 
-constexpr int kWaveMaxRegs = 32;  // ceil(N / 64) sample registers per lane: N <= 2048
 
 #ifndef HIPFEAT_WAVE_OCC
 #define HIPFEAT_WAVE_OCC 4
@@ -195,17 +193,30 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
     if (f >= cd.num_frames) break;
     const int64_t j0 = (int64_t)f * p.shift - p.npad_left;
 
-    // ---- samples, DC mean, raw log-energy (layers.py:155-162) ------------------------------------------------------
-    constexpr int NREG = 2 * N1 < kWaveMaxRegs ? 2 * N1 : kWaveMaxRegs;  // N <= fft = 128 N1
-    float x[NREG];
+    // ---- samples, DC mean, raw log-energy (layers.py:155-162), in FFT order: lane l holds the sample pairs ----------
+    // (x[2n], x[2n+1]) for n = l + 64 q -- the complex elements z[n] of the half-size FFT, exactly what pass A wants.
+    // Frames that lie inside the cut (almost all) use one 8-byte load per pair; edge frames go sample by sample.
+    v2 xp[N1];
     float s = 0.f;
+    const bool inside = j0 >= 0 && j0 + ((N + 1) & ~1) <= (int64_t)cd.num_samples;
 #pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-      const int m = lane + 64 * r;
-      x[r] = (r < nreg && m < N && !(p.ablate & 8))
-                 ? ((p.flags & F_CENTER) ? load_sample_center(w, j0 + m, cd.num_samples) : load_sample(w, j0 + m, cd.num_samples, cd.padded_len))
-                 : 0.f;
-      s += x[r];
+    for (int q = 0; q < N1; ++q) {
+      const int m0 = 2 * (lane + 64 * q);
+      v2 v = {0.f, 0.f};
+      if (m0 < N && !(p.ablate & 8)) {
+        if (inside) {
+          __builtin_memcpy(&v, w + j0 + m0, sizeof(v2));  // 4-byte aligned 8-byte load
+          if (m0 + 1 >= N) v.y = 0.f;
+        } else if (p.flags & F_CENTER) {
+          v.x = load_sample_center(w, j0 + m0, cd.num_samples);
+          if (m0 + 1 < N) v.y = load_sample_center(w, j0 + m0 + 1, cd.num_samples);
+        } else {
+          v.x = load_sample(w, j0 + m0, cd.num_samples, cd.padded_len);
+          if (m0 + 1 < N) v.y = load_sample(w, j0 + m0 + 1, cd.num_samples, cd.padded_len);
+        }
+      }
+      xp[q] = v;
+      s += v.x + v.y;
     }
     float mean = 0.f;
     if (p.flags & F_REMOVE_DC) mean = wave_sum(s) / (float)N;
@@ -213,69 +224,72 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
     if (use_e && (p.flags & F_RAW_ENERGY)) {
       float e = 0.f;
 #pragma unroll
-      for (int r = 0; r < NREG; ++r) {
-        const int m = lane + 64 * r;
-        const float d = (r < nreg && m < N) ? x[r] - mean : 0.f;
-        e = fmaf(d, d, e);
+      for (int q = 0; q < N1; ++q) {
+        const int m0 = 2 * (lane + 64 * q);
+        const float d0 = m0 < N ? xp[q].x - mean : 0.f, d1 = m0 + 1 < N ? xp[q].y - mean : 0.f;
+        e = fmaf(d0, d0, fmaf(d1, d1, e));
       }
       log_e = fmaxf(logf(wave_sum(e) + 1e-15f), p.log_energy_floor);
     }
-    // d = x - mean into the buffer (as floats), then y[m] = (d[m] - c d[max(m-1, 0)]) w[m], zero padded to 2H
-#pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-      const int m = lane + 64 * r;
-      if (r < nreg && m < N) buf[m] = x[r] - mean;
-    }
-    wave_lds_sync();
+    // y[m] = (d[m] - c d[max(m-1, 0)]) w[m] with d = x - mean, zero padded to 2H; d[2n-1] is the previous lane's second sample
+    v2 y[N1];
     {
-      v2 y[2 * N1];  // z[n] = (y[2n], y[2n+1]) for n = lane + 64 q
       float e = 0.f;
 #pragma unroll
       for (int q = 0; q < N1; ++q) {
-        const int n = lane + 64 * q, m0 = 2 * n;
+        const int m0 = 2 * (lane + 64 * q);
+        const float d0 = xp[q].x - mean, d1 = xp[q].y - mean;
+        // lane l >= 1 wants lane l-1's second sample of this register, lane 0 wants lane 63's of the previous register:
+        // lane 63 offers that one (nobody reads its current one here), so a single wrap-around ds_bpermute serves both
+        const float offer = (q > 0 && lane == 63) ? xp[q > 0 ? q - 1 : 0].y - mean : d1;
+        float dm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * ((lane - 1) & 63), __builtin_bit_cast(int, offer)));
+        if (q == 0 && lane == 0) dm = d0;  // d[max(m - 1, 0)] at the start of the frame
         v2 v = {0.f, 0.f};
         if (m0 < N) {
-          const float d0 = buf[m0], dm = buf[m0 > 0 ? m0 - 1 : 0];
-          v.x = (d0 - p.preemph * dm) * winl[m0];
-          if (m0 + 1 < N) v.y = (buf[m0 + 1] - p.preemph * d0) * winl[m0 + 1];
+          const v2 wn = *reinterpret_cast<const v2*>(winl + m0);
+          v.x = (d0 - p.preemph * dm) * wn.x;
+          if (m0 + 1 < N) v.y = (d1 - p.preemph * d0) * wn.y;
         }
         y[q] = v;
         e = fmaf(v.x, v.x, fmaf(v.y, v.y, e));
       }
       if (use_e && !(p.flags & F_RAW_ENERGY)) log_e = fmaxf(logf(wave_sum(e) + 1e-15f), p.log_energy_floor);  // layers.py:183-185
-      wave_lds_sync();
-#pragma unroll
-      for (int q = 0; q < N1; ++q) zf[fft3_pad(lane + 64 * q)] = y[q];
     }
-    wave_lds_sync();
+    wave_lds_sync();  // the previous frame's readers of this wave's buffer are done
 
     // ---- complex FFT, split step X[k] = E[k] + W_2H^k O[k], power (layers.py:32-42) --------------------------------
-    if (!(p.ablate & 1)) fft3_frame<N1>(zf, tw, lane);
+    if (!(p.ablate & 1)) fft3_frame<N1>(zf, tw, lane, y);
     if (!(p.ablate & 2)) {
-      float pw[N1 + 1];
+      // bins k and H - k come from the same two FFT outputs: with a = Z[k], b = Z[H-k], E = (a + conj b)/2, O = -i (a - conj b)/2,
+      // T = W_2H^k O:  X[k] = E + T and X[H-k] = conj(E - T).  Lane l takes k = l + 64 q <= H/2; k = 0 yields P[0] and P[H].
+      float pa[N1 / 2 + 1], pb[N1 / 2 + 1];
 #pragma unroll
-      for (int q = 0; q <= N1; ++q) {
+      for (int q = 0; q <= N1 / 2; ++q) {
         const int k = lane + 64 * q;
-        pw[q] = 0.f;
-        if (k < K) {
-          const v2 a = zf[k & (H - 1)], b = zf[(H - k) & (H - 1)];
+        pa[q] = pb[q] = 0.f;
+        if (k <= H / 2) {
+          const v2 a = zf[k], b = zf[(H - k) & (H - 1)];
           const float ex = 0.5f * (a.x + b.x), ey = 0.5f * (a.y - b.y);
           const float ox = 0.5f * (a.y + b.y), oy = -0.5f * (a.x - b.x);
-          const float2 wk = (k < H) ? tw[k] : make_float2(-1.f, 0.f);
-          const float xr = ex + (wk.x * ox - wk.y * oy);
-          const float xi = ey + (wk.x * oy + wk.y * ox);
-          float v = xr * xr + xi * xi;
-          if (p.flags & F_FFT_MAG) v = sqrtf(v);
-          pw[q] = v;
+          const float2 wk = tw[k];
+          const float tx = wk.x * ox - wk.y * oy, ty = wk.x * oy + wk.y * ox;
+          const float xr = ex + tx, xi = ey + ty, yr = ex - tx, yi = ey - ty;
+          float v = xr * xr + xi * xi, u = yr * yr + yi * yi;
+          if (p.flags & F_FFT_MAG) { v = sqrtf(v); u = sqrtf(u); }
+          pa[q] = v;
+          pb[q] = u;
         }
       }
       wave_lds_sync();
 #pragma unroll
-      for (int q = 0; q <= N1; ++q) {
+      for (int q = 0; q <= N1 / 2; ++q) {
         const int k = lane + 64 * q;
-        if (k < K) buf[k] = pw[q];
-        else if (k < K + 3) buf[k] = 0.f;  // the float4 reads of the mel stage run up to 3 entries past the row (zero weights)
+        if (k <= H / 2) {
+          buf[k] = pa[q];
+          if (k < H / 2) buf[H - k] = pb[q];
+        }
       }
+      if (lane < 3) buf[K + lane] = 0.f;  // the float4 reads of the mel stage run up to 3 entries past the row (zero weights)
     }
     wave_lds_sync();
 
