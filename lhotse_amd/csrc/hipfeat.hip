@@ -603,7 +603,7 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
   snprintf(nm, sizeof(nm), "wave_kernel<%d> fft=%d lds=%zuB blocks/CU=%d", H / 64, c.fft_length, p->wave_lds_bytes, p->blocks_per_cu);
   p->kernel_name = nm;
   p->variant = 5;
-  p->fpb = 16;  // 4 waves x 4 frames
+  p->fpb = 32;  // 4 waves x 8 frames (the tables copied to LDS per workgroup are ~12 KB)
   if (const char* f = getenv("HIPFEAT_WAVE_FPW")) p->fpb = 4 * std::max(1, atoi(f));  // experiments
   return HIPFEAT_OK;
 }
