@@ -591,8 +591,8 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
   }
   p->wave_dct_in_lds = c.kind == HIPFEAT_MFCC && (size_t)M * c.num_ceps <= 2560;
   auto up4 = [](size_t v) { return (v + 3) & ~(size_t)3; };
-  // twiddles + 4 padded wave buffers + window + filterbank blob (+ DCT matrix)
-  p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)144 * (H / 64) + 8) + up4((size_t)c.frame_length) + up4((size_t)p->wave_blob_floats) +
+  // twiddles W_2H^k + 4 padded wave buffers + window + twiddles W_H^m + filterbank blob (+ DCT matrix)
+  p->wave_lds_bytes = ((size_t)2 * H + 4 * ((size_t)144 * (H / 64) + 8) + up4((size_t)c.frame_length) + (size_t)2 * H + up4((size_t)p->wave_blob_floats) +
                        (p->wave_dct_in_lds ? (size_t)M * c.num_ceps : 0)) * sizeof(float);
   const void* fn = H == 256 ? wave_entry<4>() : (H == 512 ? wave_entry<8>() : wave_entry<16>());
   hipError_t e = ensure_dynamic_lds(fn, p->wave_lds_bytes);

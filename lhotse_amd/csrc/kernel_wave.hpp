@@ -90,7 +90,7 @@ __device__ __forceinline__ void small_fft(const v2* x, v2* X) {
 __device__ __forceinline__ int fft3_pad(int e) { return e + (e >> 3); }
 
 template <int N1>
-__device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw, int lane, const v2* x) {  // x[n1] = element lane + 64 n1
+__device__ __forceinline__ void fft3_frame(v2* zf, const v2* __restrict__ twh, int lane, const v2* x) {  // twh[m] = W_H^m  // x[n1] = element lane + 64 n1
   constexpr int H = 64 * N1;
   const int lp = lane + (lane >> 3);  // 9 n2 + n3
   {
@@ -98,7 +98,7 @@ __device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw
     small_fft<N1>(x, A);
     const int n2 = lane >> 3;
 #pragma unroll
-    for (int k1 = 1; k1 < N1; ++k1) A[k1] = cmul(A[k1], twiddle_h(tw, 8 * n2 * k1, H));
+    for (int k1 = 1; k1 < N1; ++k1) A[k1] = cmul(A[k1], twh[8 * n2 * k1]);
 #pragma unroll
     for (int k1 = 0; k1 < N1; ++k1) zf[72 * k1 + lp] = A[k1];
   }
@@ -115,7 +115,7 @@ __device__ __forceinline__ void fft3_frame(v2* zf, const float2* __restrict__ tw
       fft8(x, B);
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
-        B[k2] = cmul(B[k2], twiddle_h(tw, n3 * (k1 + N1 * k2), H));
+        B[k2] = cmul(B[k2], twh[n3 * (k1 + N1 * k2)]);
         zf[72 * k1 + 9 * k2 + n3] = B[k2];
       }
     }
@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float2* tw = reinterpret_cast<float2*>(smem);                  // [H]
   float* winl = smem + 2 * H + 4 * (144 * N1 + 8);               // [N] window, shared by the four waves
-  float* melb = winl + ((p.N + 3) & ~3);                          // filterbank descriptors + compact weights
+  v2* twh = reinterpret_cast<v2*>(winl + ((p.N + 3) & ~3));       // [H] W_H^m for the FFT passes
+  float* melb = reinterpret_cast<float*>(twh + H);                // filterbank descriptors + compact weights
   float* dctl = melb + ((p.mel_blob_floats + 3) & ~3);            // [M][C] DCT matrix when it fits
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,7 +177,10 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
   }
   const CutDesc cd = p.cuts[cut];
   const float* __restrict__ w = p.wave + cd.wave_off;
-  for (int i = tid; i < H; i += 256) tw[i] = p.tw[i];
+  for (int i = tid; i < H; i += 256) {
+    tw[i] = p.tw[i];
+    twh[i] = twiddle_h(p.tw, i, H);
+  }
   for (int i = tid; i < p.N; i += 256) winl[i] = p.window[i];
   for (int i = tid; i < p.mel_blob_floats; i += 256) melb[i] = p.mel_blob[i];
   if (p.dct_in_lds)
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
     wave_lds_sync();  // the previous frame's readers of this wave's buffer are done
 
     // ---- complex FFT, split step X[k] = E[k] + W_2H^k O[k], power (layers.py:32-42) --------------------------------
-    if (!(p.ablate & 1)) fft3_frame<N1>(zf, tw, lane, y);
+    if (!(p.ablate & 1)) fft3_frame<N1>(zf, twh, lane, y);
     if (!(p.ablate & 2)) {
       // bins k and H - k come from the same two FFT outputs: with a = Z[k], b = Z[H-k], E = (a + conj b)/2, O = -i (a - conj b)/2,
       // T = W_2H^k O:  X[k] = E + T and X[H-k] = conj(E - T).  Lane l takes k = l + 64 q <= H/2; k = 0 yields P[0] and P[H].
@@ -331,11 +335,15 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
         }
         acc += dpp_mov<DPP_QUAD(1, 0, 3, 2)>(acc);
         acc += dpp_mov<DPP_QUAD(2, 3, 0, 1)>(acc);
-        if (j < M && sub == 0) {
-          const float v = (p.flags & F_LOG10) ? log10f(fmaxf(acc, p.mel_floor)) : logf(fmaxf(acc, p.mel_floor));
-          if (p.kind == 2) orow[ecol + j] = v;
-          else buf[2 * H - 120 + j] = v;  // MFCC: log-mel vector stashed behind the power row (K = H + 1 <= 2H - 120, M <= 128)
-        }
+        if (j < M && sub == 0) buf[2 * H - 120 + j] = acc;  // mel energies stashed behind the power row (K + 3 <= 2H - 120, M <= 128)
+      }
+      wave_lds_sync();
+      // one lane per filter for the logarithm, and one coalesced store of the row
+      for (int j = lane; j < M; j += 64) {
+        const float acc = buf[2 * H - 120 + j];
+        const float v = (p.flags & F_LOG10) ? log10f(fmaxf(acc, p.mel_floor)) : logf(fmaxf(acc, p.mel_floor));
+        if (p.kind == 2) orow[ecol + j] = v;
+        else buf[2 * H - 120 + j] = v;  // MFCC: log-mel vector for the DCT
       }
       if (p.kind == 2) {
         if (ecol && lane == 0) orow[0] = log_e;
