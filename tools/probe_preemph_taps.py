@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Impulse probe of the wave kernel's pre-emphasis: for every position p of an impulse inside a frame, where does the -c tap land?"""
+"""Impulse probe of a kernel's pre-emphasis (used while reworking wave_kernel): one impulse per frame at every
+position p of the frame; the autocorrelation of the power spectrum tells at which lag the -c tap landed (must be 1).
+Position 0 is reported by design (y[0] = x[0] - c x[0])."""
 import os, sys, warnings
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
