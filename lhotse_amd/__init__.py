@@ -34,6 +34,8 @@ from .librosa_fbank import HipLibrosaFbank, HipLibrosaFbankConfig  # noqa: F401,
 
 from .signal_transforms import HipGlobalMVN, HipSpecAugment  # noqa: F401,E402
 
+from .layers import HipWav2LogFilterBank, HipWav2LogSpec, HipWav2MFCC, HipWav2Spec  # noqa: F401,E402
+
 from .storage import compute_and_store_features_batch  # noqa: F401,E402
 
 __all__ = [
@@ -41,6 +43,10 @@ __all__ = [
     "HipWhisperFbank",
     "HipLibrosaFbank",
     "HipGlobalMVN",
+    "HipWav2Spec",
+    "HipWav2LogSpec",
+    "HipWav2LogFilterBank",
+    "HipWav2MFCC",
     "HipSpecAugment",
     "HipLibrosaFbankConfig",
     "HipWhisperFbankConfig",

@@ -48,8 +48,10 @@ def lhotse_mod():
         importlib.reload(ins)
         importlib.reload(wh)
         import lhotse_amd.librosa_fbank as lf
+        import lhotse_amd.layers as ly
 
         importlib.reload(lf)
+        importlib.reload(ly)
         import lhotse_amd.storage as st
 
         importlib.reload(st)
@@ -336,3 +338,49 @@ def test_bulk_save_driver_equals_the_reference_driver(tmp_path, cutset, cpu_devi
     mem = LA.compute_and_store_features_batch(cutset, extractor=ex, storage_path=tmp_path / "mem", batch_duration=100.0, num_workers=0,
                                               collate=True, storage_type=NumpyFilesWriter, overwrite=True)
     assert len(list(mem)) == 5 and all(c.has_features for c in mem)
+
+
+LAYER_PAIRS = [("HipWav2Spec", "Wav2Spec"), ("HipWav2LogSpec", "Wav2LogSpec"), ("HipWav2LogFilterBank", "Wav2LogFilterBank"), ("HipWav2MFCC", "Wav2MFCC")]
+
+
+@pytest.mark.parametrize("ours,theirs", LAYER_PAIRS)
+def test_layer_modules_have_the_reference_constructors(lhotse_mod, ours, theirs):
+    import inspect
+
+    import lhotse.features.kaldi.layers as RL
+    import lhotse_amd.layers as HL
+
+    a, b = inspect.signature(getattr(HL, ours).__init__), inspect.signature(getattr(RL, theirs).__init__)
+    assert [(p.name, p.default) for p in a.parameters.values()] == [(p.name, p.default) for p in b.parameters.values()]
+    m = getattr(HL, ours)()
+    r = getattr(RL, theirs)()
+    for attr in ("sampling_rate", "frame_length", "frame_shift", "remove_dc_offset", "preemph_coeff", "window_type", "dither", "snip_edges",
+                 "energy_floor", "raw_energy", "use_energy", "fft_length"):
+        if hasattr(r, attr):
+            assert getattr(m, attr) == getattr(r, attr), attr
+
+
+@pytest.mark.parametrize("ours,theirs,kw", [
+    ("HipWav2LogFilterBank", "Wav2LogFilterBank", {}),
+    ("HipWav2LogFilterBank", "Wav2LogFilterBank", {"use_energy": True, "num_filters": 40, "snip_edges": True}),
+    ("HipWav2MFCC", "Wav2MFCC", {}),
+    ("HipWav2Spec", "Wav2Spec", {}),
+    ("HipWav2LogSpec", "Wav2LogSpec", {"use_energy": False, "sampling_rate": 8000}),
+])
+def test_layer_forward_equals_the_reference_layer(lhotse_mod, cpu_device, ours, theirs, kw):
+    import lhotse.features.kaldi.layers as RL
+    import lhotse_amd.layers as HL
+
+    x = torch.from_numpy((np.random.RandomState(5).rand(3, 4000).astype(np.float32) - 0.5))
+    with torch.no_grad():
+        want = getattr(RL, theirs)(**kw)(x).numpy()
+    layer = getattr(HL, ours)(**kw)
+    got = layer(x).numpy()
+    assert got.shape == want.shape
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-4 * max(1.0, scale)
+    assert layer(x[0]).shape == want.shape[1:]  # (T,) in -> (frames, F) out
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        layer(x.clone().requires_grad_(True))
+    with pytest.raises(TypeError):
+        layer(x.double())
