@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
     } else if (p.kind == 0 || p.kind == 1) {
       for (int k = lane; k < K; k += 64) {
         float v = buf[k];
-        if (p.kind == 1) v = logf(v + p.log_offset);
+        if (p.kind == 1) v = fast_log(v + p.log_offset);
         if (use_e && k == 0) v = log_e;
         orow[k] = v;
       }
@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
       // one lane per filter for the logarithm, and one coalesced store of the row
       for (int j = lane; j < M; j += 64) {
         const float acc = buf[2 * H - 120 + j];
-        const float v = (p.flags & F_LOG10) ? log10f(fmaxf(acc, p.mel_floor)) : logf(fmaxf(acc, p.mel_floor));
+        // v_log_f32 (log2, 1 ulp) times a constant, as in the fft512 kernels: the argument is a normal positive float
+        const float v = __builtin_amdgcn_logf(fmaxf(acc, p.mel_floor)) * ((p.flags & F_LOG10) ? 0.30102999566398120f : 0.69314718055994531f);
         if (p.kind == 2) orow[ecol + j] = v;
         else buf[2 * H - 120 + j] = v;  // MFCC: log-mel vector for the DCT
       }

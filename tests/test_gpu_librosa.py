@@ -54,7 +54,7 @@ def test_hip_librosa_matches_reference_golden(case):
         assert isinstance(got, np.ndarray)
         _close(got, z[f"out{i}"], (name, i, kind), broadband=kind in ("uniform", "gauss", "speechlike"))
         if kind == "zeros":
-            assert np.abs(got + 10.0).max() <= 2e-6  # log10(eps), librosa_fbank.py:127 (the device's log10f(1e-10f) is one ulp off)
+            assert np.abs(got + 10.0).max() <= 5e-6  # log10(eps), librosa_fbank.py:127 (v_log_f32 times log10(2): a couple of ulps)
 
 
 @pytest.mark.parametrize(
