@@ -209,6 +209,8 @@ HIPFEAT_API hipfeat_status hipfeat_global_mvn(const float* d_in, float* d_out, c
  *     axis 1 = frames [begin, end), axis 2 = feature bins [begin, end) (mask_along_axis_optimized, :297-335).
  * The random draws stay with the caller (the host mirror makes them with the reference's RNG calls in the reference's order).
  * Descriptors are host arrays; the call is asynchronous on `stream`.  d_in and d_out must not alias.
+ * Like hipfeat_pcm16_to_float and hipfeat_global_mvn it has no plan: it launches on the calling thread's current device, which must
+ * be the one that owns the buffers and the stream.
  */
 typedef struct hipfeat_warp_segment {
   int32_t sequence, start, num_frames, center, warped;
