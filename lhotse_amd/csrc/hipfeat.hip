@@ -21,6 +21,7 @@
 #include "kernel_resample.hpp"
 #include "kernel_specaug.hpp"
 #include "kernel_whisper.hpp"
+#include "kernel_whisper2.hpp"
 #include "kernel_fft256.hpp"
 #include "kernel_wave.hpp"
 
@@ -117,6 +118,13 @@ struct hipfeat_plan {
   int32_t wh_mt_lo[kWhBinTiles] = {};
   int32_t wh_mt_cnt[kWhBinTiles] = {};
   int wh_mel_tiles = 0;
+  // whisper FFT fast path (variant 6)
+  float* d_wh2_cs = nullptr;
+  float* d_wh2_tw = nullptr;
+  float* d_wh2_mel = nullptr;
+  int32_t* d_wh2_sched = nullptr;
+  int32_t wh2_k0[kW2MaxMelTiles] = {}, wh2_steps[kW2MaxMelTiles] = {}, wh2_off[kW2MaxMelTiles] = {};
+  int32_t wh2_wave_tiles[4][2] = {};
   // transient-layout staging ring (hipfeat_extract)
   mutable std::mutex mu;
   mutable StagingSlot slots[4];
@@ -198,6 +206,10 @@ static void plan_free(hipfeat_plan* p) {
   (void)hipFree(p->d_tw);
   (void)hipFree(p->d_mel);
   (void)hipFree(p->d_mel_range);
+  (void)hipFree(p->d_wh2_cs);
+  (void)hipFree(p->d_wh2_tw);
+  (void)hipFree(p->d_wh2_mel);
+  (void)hipFree(p->d_wh2_sched);
   (void)hipFree(p->d_dct);
   (void)hipFree(p->d_lifter);
   (void)hipFree(p->d_scratch_wave);
@@ -609,6 +621,89 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
 }
 
 // --------------------------------------------------------------------------------------
+// whisper FFT fast path: 400 = 16 x 25 mixed-radix FFT on the vector ALUs + banded mel GEMM (kernel_whisper2.hpp)
+// --------------------------------------------------------------------------------------
+static hipfeat_status setup_whisper2(hipfeat_plan* p, const float* h_mel) {
+  const hipfeat_config& c = p->cfg;
+  if (c.kind != HIPFEAT_WHISPER || c.frame_length != kW2N || c.frame_shift != kW2Shift || c.num_filters > 16 * kW2MaxMelTiles ||
+      getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_WHISPER_V1"))
+    return HIPFEAT_OK;
+  const int M = c.num_filters, nmt = (M + 15) / 16;
+  std::vector<float> cs(288);
+  for (int j = 1; j <= 12; ++j)
+    for (int k = 1; k <= 12; ++k) {
+      const double th = 2.0 * M_PI * (double)((j * k) % 25) / 25.0;
+      cs[(size_t)(j - 1) * 24 + (k - 1)] = (float)std::cos(th);
+      cs[(size_t)(j - 1) * 24 + 12 + (k - 1)] = (float)-std::sin(th);
+    }
+  std::vector<float> tw((size_t)13 * 16 * 2);
+  for (int k2 = 0; k2 < 13; ++k2)
+    for (int l = 0; l < 16; ++l) {
+      const double th = 2.0 * M_PI * (double)((l * k2) % 400) / 400.0;
+      tw[((size_t)k2 * 16 + l) * 2] = (float)std::cos(th);
+      tw[((size_t)k2 * 16 + l) * 2 + 1] = (float)-std::sin(th);
+    }
+  std::vector<float> mel;
+  for (int mt = 0; mt < nmt; ++mt) {
+    int lo = 201, hi = 0;
+    for (int bin = 0; bin <= 200; ++bin)
+      for (int i = 0; i < 16; ++i) {
+        const int m = 16 * mt + i;
+        if (m < M && h_mel[(size_t)bin * M + m] != 0.0f) {
+          lo = std::min(lo, bin);
+          hi = std::max(hi, bin + 1);
+        }
+      }
+    if (hi == 0) lo = 0;
+    const int k0 = lo & ~3, chunks = hi > lo ? (hi - k0 + 15) / 16 : 0;  // chunks of 4 k-steps (16 bins); zero weights pad the band
+    p->wh2_k0[mt] = k0;
+    p->wh2_steps[mt] = chunks;
+    p->wh2_off[mt] = (int32_t)(mel.size() / 256);
+    for (int ch = 0; ch < chunks; ++ch)
+      for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < 4; ++r) {
+          const int bin = k0 + 16 * ch + 4 * r + (l >> 4), m = 16 * mt + (l & 15);
+          mel.push_back((bin <= 200 && m < M) ? h_mel[(size_t)bin * M + m] : 0.0f);
+        }
+  }
+  if (mel.empty()) mel.assign(256, 0.0f);
+  // deal the mel tiles to the four waves: longest first, always to the least loaded wave (at most two tiles each)
+  int load[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+  for (int wv = 0; wv < 4; ++wv) p->wh2_wave_tiles[wv][0] = p->wh2_wave_tiles[wv][1] = -1;
+  std::vector<int> order(nmt);
+  for (int i = 0; i < nmt; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return p->wh2_steps[a] > p->wh2_steps[b]; });
+  for (int mt : order) {
+    int best = -1;
+    for (int wv = 0; wv < 4; ++wv)
+      if (cnt[wv] < 2 && (best < 0 || load[wv] < load[best])) best = wv;
+    p->wh2_wave_tiles[best][cnt[best]++] = mt;
+    load[best] += p->wh2_steps[mt];
+  }
+  hipfeat_status st;
+  if ((st = upload(&p->d_wh2_cs, cs.data(), cs.size())) != HIPFEAT_OK) return st;
+  if ((st = upload(&p->d_wh2_tw, tw.data(), tw.size())) != HIPFEAT_OK) return st;
+  if ((st = upload(&p->d_wh2_mel, mel.data(), mel.size())) != HIPFEAT_OK) return st;
+  std::vector<int32_t> sched(32, 0);
+  for (int wv = 0; wv < 4; ++wv)
+    for (int sl = 0; sl < 2; ++sl) {
+      const int mt = p->wh2_wave_tiles[wv][sl];
+      int32_t* e = &sched[(size_t)(wv * 2 + sl) * 4];
+      e[0] = mt;
+      if (mt >= 0) e[1] = p->wh2_k0[mt], e[2] = p->wh2_steps[mt], e[3] = p->wh2_off[mt];
+    }
+  if ((st = upload(&p->d_wh2_sched, sched.data(), sched.size())) != HIPFEAT_OK) return st;
+  p->variant = 6;
+  p->fpb = 16 * kW2TilesPerBlock;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&whisper2_kernel), 256, 0) == hipSuccess) p->blocks_per_cu = nb;
+  char buf[160];
+  snprintf(buf, sizeof(buf), "whisper_kernel2 fft400=16x25 mel_chunks=%d+%d+%d+%d blocks/CU=%d", load[0], load[1], load[2], load[3], p->blocks_per_cu);
+  p->kernel_name = buf;
+  return HIPFEAT_OK;
+}
+
+// --------------------------------------------------------------------------------------
 // whisper fast path: DFT-400 and mel operands in MFMA lane order (kernel_whisper.hpp)
 // --------------------------------------------------------------------------------------
 static hipfeat_status setup_whisper(hipfeat_plan* p, const float* h_mel) {
@@ -811,7 +906,9 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
 
   st = setup_fft512(p, h_window, h_mel, h_dct, h_lifter);
   if (st != HIPFEAT_OK) return bail(st);
-  st = setup_whisper(p, h_mel);
+  st = setup_whisper2(p, h_mel);
+  if (st != HIPFEAT_OK) return bail(st);
+  if (p->variant == 0) st = setup_whisper(p, h_mel);
   if (st != HIPFEAT_OK) return bail(st);
   st = setup_fft256(p, h_window, h_mel, h_dct, h_lifter);
   if (st != HIPFEAT_OK) return bail(st);
@@ -991,6 +1088,30 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
       case 8: hipLaunchKernelGGL(wave_kernel<8>, grid, block, plan->wave_lds_bytes, stream, wp); break;
       default: hipLaunchKernelGGL(wave_kernel<16>, grid, block, plan->wave_lds_bytes, stream, wp); break;
     }
+    HIP_TRY(hipGetLastError());
+    return HIPFEAT_OK;
+  }
+  if (plan->variant == 6) {
+    Whisper2Params wp{};
+    wp.wave = d_wave;
+    wp.out = d_out;
+    wp.cuts = lay->d_cuts;
+    wp.window = plan->d_window;
+    wp.cs = plan->d_wh2_cs;
+    wp.tw = plan->d_wh2_tw;
+    wp.mel_a = plan->d_wh2_mel;
+    wp.out_stride = lay->out_row_stride;
+    wp.num_cuts = (int32_t)lay->batch;
+    wp.uniform_bpc = lay->uniform_bpc;
+    wp.M = c.num_filters;
+    wp.mel_floor = c.mel_floor;
+    wp.sched = plan->d_wh2_sched;
+    if (const char* ab = getenv("HIPFEAT_W2_ABLATE")) wp.ablate = atoi(ab);
+    DeviceGuard g(plan->device);
+    hipLaunchKernelGGL(whisper2_kernel, dim3((unsigned)lay->total_blocks), dim3(256), 0, stream, wp);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)lay->batch), dim3(1024), 0, stream, lay->d_cuts, d_out, lay->out_row_stride,
+                       (int32_t)c.num_filters, (int32_t)c.frame_shift);
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }
