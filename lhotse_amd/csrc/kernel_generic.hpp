@@ -246,7 +246,23 @@ __global__ __launch_bounds__(1024) void whisper_norm_kernel(const CutDesc* __res
   // dense rows (stride == M) on a 16-byte boundary: one linear float4 sweep per pass
   const bool dense = stride == M && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
   float mx = -INFINITY;
-  if (dense) {
+  // cuts of up to ~12 s (24 float4 per lane) stay in registers between the two passes: one read instead of two
+  constexpr int kKeep = 24;
+  const int64_t n4all = n >> 2;
+  const bool keep = dense && n4all <= (int64_t)kKeep * 1024;
+  float4 held[kKeep];
+  if (keep) {
+    const float4* b4 = reinterpret_cast<const float4*>(base);
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) {
+      const int64_t i = threadIdx.x + 1024 * k;
+      if (i < n4all) {
+        held[k] = b4[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(held[k].x, held[k].y)), fmaxf(held[k].z, held[k].w));
+      }
+    }
+    for (int64_t i = (n4all << 2) + threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, base[i]);
+  } else if (dense) {
     const float4* b4 = reinterpret_cast<const float4*>(base);
     const int64_t n4 = n >> 2;
     for (int64_t i = threadIdx.x; i < n4; i += 1024) {
@@ -268,7 +284,22 @@ __global__ __launch_bounds__(1024) void whisper_norm_kernel(const CutDesc* __res
 #pragma unroll
   for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
   const float lo = mx - 8.0f;
-  if (dense) {
+  if (keep) {
+    float4* b4 = reinterpret_cast<float4*>(base);
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) {
+      const int64_t i = threadIdx.x + 1024 * k;
+      if (i < n4all) {
+        float4 v = held[k];
+        v.x = (fmaxf(v.x, lo) + 4.0f) * 0.25f;
+        v.y = (fmaxf(v.y, lo) + 4.0f) * 0.25f;
+        v.z = (fmaxf(v.z, lo) + 4.0f) * 0.25f;
+        v.w = (fmaxf(v.w, lo) + 4.0f) * 0.25f;
+        b4[i] = v;
+      }
+    }
+    for (int64_t i = (n4all << 2) + threadIdx.x; i < nt; i += 1024) base[i] = (i < n) ? (fmaxf(base[i], lo) + 4.0f) * 0.25f : 0.0f;
+  } else if (dense) {
     float4* b4 = reinterpret_cast<float4*>(base);
     const int64_t n4 = n >> 2;
     for (int64_t i = threadIdx.x; i < n4; i += 1024) {
