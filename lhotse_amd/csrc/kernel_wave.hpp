@@ -90,8 +90,7 @@ __device__ __forceinline__ void small_fft(const v2* x, v2* X) {
 __device__ __forceinline__ int fft3_pad(int e) { return e + (e >> 3); }
 
 template <int N1>
-__device__ __forceinline__ void fft3_frame(v2* zf, const v2* __restrict__ twh, int lane, const v2* x) {  // twh[m] = W_H^m  // x[n1] = element lane + 64 n1
-  constexpr int H = 64 * N1;
+__device__ __forceinline__ void fft3_frame(v2* zf, const v2* __restrict__ twh, int lane, const v2* x) {  // twh[m] = W_H^m, x[n1] = element lane + 64 n1
   const int lp = lane + (lane >> 3);  // 9 n2 + n3
   {
     v2 A[N1];
@@ -191,7 +190,6 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
   const float* __restrict__ dctp = p.dct_in_lds ? dctl : p.dct;
 
   const int N = p.N, K = p.K, M = p.M;
-  const int nreg = (N + 63) >> 6;
   const bool use_e = (p.flags & F_USE_ENERGY) != 0;
   const int fbase = fb * 4 * p.frames_per_wave;
 #pragma unroll 1

@@ -173,7 +173,6 @@ __global__ __launch_bounds__(256, HIPFEAT_W2_OCC) void whisper2_kernel(const Whi
       const f32x4* __restrict__ ma = reinterpret_cast<const f32x4*>(p.mel_a) + (size_t)sc.w * 64 + lane;
       const float* pb = tbuf + q * kW2TFrame + k0 + g;  // B operand: frame q, bin k0 + 4 s + g
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
       for (int i = 0; i < chunks; ++i) {
         const f32x4 a4 = ma[(size_t)i * 64];
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, pb[16 * i], acc0, 0, 0, 0);
