@@ -110,3 +110,25 @@ def test_pipeline_fbank_mvn_specaug_stays_on_the_device():
     seg_rounds, masks = tfm.draw(*feats.shape, None)
     want = R.apply(feats.cpu().numpy(), seg_rounds, masks)
     assert y.is_cuda and np.abs(y.cpu().numpy() - want).max() <= 2e-5
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_forward_with_random_supervision_segments_against_the_oracle(seed):
+    """The full forward (the host's draws + the kernels) on random batches with random, partly overlapping supervision
+    segments: same draws replayed through the numpy oracle."""
+    rng = np.random.RandomState(100 + seed)
+    B, T, F = int(rng.randint(1, 7)), int(rng.randint(120, 900)), int(rng.choice([23, 40, 80]))
+    x = (rng.randn(B, T, F) * 3 - 8).astype(np.float32)
+    sup = []
+    for b in range(B):
+        for _ in range(rng.randint(0, 4)):
+            st = int(rng.randint(0, T - 20))
+            sup.append([b, st, int(rng.randint(10, T))])  # may run past the end of the sequence: sliced like the reference
+    sup = torch.tensor(sup, dtype=torch.int32) if sup else None
+    tfm = LA.HipSpecAugment(time_warp_factor=int(rng.choice([5, 20, 80])), num_frame_masks=int(rng.randint(1, 6)), p=0.8)
+    seed_all(seed)
+    y = tfm(torch.from_numpy(x).cuda(), supervision_segments=sup).cpu().numpy()
+    seed_all(seed)
+    seg_rounds, masks = tfm.draw(B, T, F, sup)
+    want = R.apply(x, seg_rounds, masks)
+    assert np.abs(y - want).max() <= 2e-5, (np.abs(y - want).max(), len(seg_rounds))
