@@ -96,6 +96,7 @@ class HipSpecAugment(torch.nn.Module):
         frames_mask_size: int = 100,
         max_frames_mask_fraction: float = 0.15,
         p=0.9,
+        fast_rng: bool = False,
     ):
         super().__init__()
         assert 0 <= p <= 1
@@ -110,6 +111,39 @@ class HipSpecAugment(torch.nn.Module):
         self.frames_mask_size = frames_mask_size
         self.max_frames_mask_fraction = max_frames_mask_fraction
         self.p = p
+        # extension (not part of the reference's state): draw all random numbers of a batch with a few vectorised numpy calls --
+        # the same distributions, but NOT the reference's random streams; ~20x less host time per batch (0.8 ms -> 0.04 ms at B = 40)
+        self.fast_rng = fast_rng
+
+    def _draw_fast(self, batch: int, num_frames: int, feature_dim: int):
+        """Vectorised equivalent of ``draw`` without supervision segments: same distributions as _forward_single (:217-266)."""
+        rng = np.random.default_rng(np.random.randint(0, 2**31 - 1))  # follows numpy's global seed
+        apply = rng.random(batch) <= self.p
+        segs = []
+        factor = self.time_warp_factor
+        if factor is not None and factor >= 1 and num_frames - factor > factor + 1:
+            center = rng.integers(factor + 1, num_frames - factor, size=batch)
+            warped = rng.integers(center - factor, center + factor + 1)
+            for b in np.nonzero(apply & (warped != center))[0]:
+                segs.append((int(b), 0, num_frames, int(center[b]), int(warped[b])))
+        masks = []
+
+        def add(axis, size, mask_size, times):
+            if times == 0:
+                return
+            values = rng.integers(0, int(mask_size), size=(batch, times))
+            starts = (rng.random((batch, times), dtype=np.float32) * (size - values).astype(np.float32)).astype(np.int64)
+            for b in np.nonzero(apply)[0]:
+                for a, v in zip(starts[b].tolist(), values[b].tolist()):
+                    lo, hi, _ = slice(a, a + v).indices(size)
+                    masks.append((int(b), axis, lo, max(lo, hi)))
+
+        add(2, feature_dim, self.features_mask_size, self.num_feature_masks)
+        max_tot = self.max_frames_mask_fraction * num_frames
+        n_frame_masks = min(self.num_frame_masks, math.ceil(max_tot / self.frames_mask_size))
+        add(1, num_frames, min(self.frames_mask_size, max_tot // n_frame_masks), n_frame_masks)
+        seg_rounds = [np.array(segs, dtype=_lib.WARP_SEGMENT_DTYPE)] if segs else []
+        return seg_rounds, np.array(masks, dtype=_lib.MASK_DTYPE)
 
     # -- the reference's random decisions, call for call -------------------------------------------------------------
     def _draw_warp(self, t: int) -> Optional[Tuple[int, int]]:
@@ -200,7 +234,10 @@ class HipSpecAugment(torch.nn.Module):
         assert len(features.shape) == 3, "SpecAugment only supports batches of single-channel feature matrices."
         x = _require_cuda(features, "HipSpecAugment")
         B, T, F = x.shape
-        seg_rounds, masks = self.draw(B, T, F, supervision_segments)
+        if self.fast_rng and supervision_segments is None:
+            seg_rounds, masks = self._draw_fast(B, T, F)
+        else:
+            seg_rounds, masks = self.draw(B, T, F, supervision_segments)
         return apply_specaug(x, seg_rounds, masks)
 
     def state_dict(self, **kwargs) -> Dict[str, Any]:

@@ -132,3 +132,17 @@ def test_forward_with_random_supervision_segments_against_the_oracle(seed):
     seg_rounds, masks = tfm.draw(B, T, F, sup)
     want = R.apply(x, seg_rounds, masks)
     assert np.abs(y - want).max() <= 2e-5, (np.abs(y - want).max(), len(seg_rounds))
+
+
+def test_fast_rng_mode_runs_and_is_reproducible():
+    x = torch.randn(8, 500, 80, device="cuda") * 3 - 8
+    tfm = LA.HipSpecAugment(time_warp_factor=20, p=1.0, fast_rng=True)
+    np.random.seed(9)
+    a = tfm(x)
+    np.random.seed(9)
+    b = tfm(x)
+    assert torch.equal(a, b) and a.shape == x.shape and not torch.equal(a, x)
+    np.random.seed(9)
+    seg_rounds, masks = tfm._draw_fast(8, 500, 80)
+    want = R.apply(x.cpu().numpy(), seg_rounds, masks)
+    assert np.abs(a.cpu().numpy() - want).max() <= 2e-5

@@ -93,3 +93,28 @@ def test_torch_restatement_used_as_timing_baseline_is_the_reference(case):
     seed_all(seed)
     y = TorchSpecAugment(**kw)(torch.from_numpy(x), None if sup is None else torch.tensor(sup, dtype=torch.int32)).numpy()
     assert np.array_equal(y, np.load(GOLDEN)[name])
+
+
+def test_fast_rng_draws_have_the_reference_distributions():
+    """fast_rng=True is an extension: vectorised numpy draws with the same distributions (not the same streams)."""
+    np.random.seed(3)
+    tfm = LA.HipSpecAugment(time_warp_factor=20, p=0.7, fast_rng=True)
+    assert "fast_rng" not in tfm.state_dict()  # the reference's state only
+    B, T, F = 400, 600, 80
+    seg_rounds, masks = tfm._draw_fast(B, T, F)
+    segs = seg_rounds[0]
+    applied = np.unique(masks["sequence"])
+    assert 0.6 < len(applied) / B < 0.8  # p = 0.7
+    assert set(segs["sequence"]).issubset(set(applied.tolist()))
+    assert np.all(segs["center"] >= 21) and np.all(segs["center"] < T - 20) and np.all(np.abs(segs["warped"] - segs["center"]) <= 20)
+    assert np.all(segs["warped"] != segs["center"])
+    fm, tm = masks[masks["axis"] == 2], masks[masks["axis"] == 1]
+    assert len(fm) == 2 * len(applied) and len(tm) == min(10, int(np.ceil(0.15 * T / 100))) * len(applied)
+    assert np.all(fm["begin"] >= 0) and np.all(fm["end"] <= F) and np.all(fm["end"] - fm["begin"] < 27)
+    assert np.all(tm["begin"] >= 0) and np.all(tm["end"] <= T) and np.all(tm["end"] - tm["begin"] < min(100, 0.15 * T // 1))
+    # reproducible under numpy's global seed
+    np.random.seed(3)
+    again = LA.HipSpecAugment(time_warp_factor=20, p=0.7, fast_rng=True)._draw_fast(B, T, F)
+    assert np.array_equal(again[1], masks) and np.array_equal(again[0][0], segs)
+    # the exact mode is what a default-constructed transform uses
+    assert LA.HipSpecAugment().fast_rng is False
