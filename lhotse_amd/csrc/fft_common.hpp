@@ -51,6 +51,15 @@ __device__ __forceinline__ v2 cmul(v2 a, v2 w) {  // a * w, only w itself availa
   return a * v2{w.x, w.x} + swap2(a * HF_CJ) * v2{w.y, w.y};
 }
 
+// a * w in two packed instructions from w alone: (a.x, a.y) * w.x, then (-a.y, a.x) * w.y added -- the half-negation
+// rides on the neg_lo modifier of VOP3P, which hipcc does not form from source-level negations.
+__device__ __forceinline__ v2 cmul2(v2 a, v2 w) {
+  v2 t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+
 // 16-point complex FFT in registers (radix-4 x radix-4, natural order in and out)
 __device__ __forceinline__ void fft16(const v2 (&x)[16], v2 (&X)[16]) {
   constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;

@@ -18,6 +18,8 @@
 #include "kernel_generic.hpp"
 #include "kernel_fft512.hpp"
 #include "kernel_fft512b.hpp"
+#include "kernel_fft512c.hpp"
+#include "mel4_schedule.hpp"
 #include "kernel_resample.hpp"
 #include "kernel_specaug.hpp"
 #include "kernel_whisper.hpp"
@@ -106,6 +108,9 @@ struct hipfeat_plan {
   float* d_lds_consts = nullptr;
   float* d_mel_a = nullptr;
   WaveWork* d_work = nullptr;
+  // fft512 wave-autonomous fbank kernel (variant 7)
+  float* d_c_shared = nullptr;  // LDS image: FFT constants | 4x4-block filterbank weights | lane tables
+  int c_shared_floats = 0, c_wtab_off = 0, c_ltab_off = 0, c_xs_floats = 0, c_rounds = 0;
   // wave-per-frame kernel (variant 5)
   float* d_mel_t = nullptr;  // filterbank blob (descriptors + compact weights)
   int mel_maxband = 0;
@@ -220,6 +225,7 @@ static void plan_free(hipfeat_plan* p) {
   (void)hipFree(p->d_mel_a);
   (void)hipFree(p->d_work);
   (void)hipFree(p->d_mel_t);
+  (void)hipFree(p->d_c_shared);
   (void)hipFree(p->d_wh_dft);
   (void)hipFree(p->d_wh_mel);
   for (auto& s : p->slots) {
@@ -334,6 +340,86 @@ static std::vector<float> build_dct_operands(const hipfeat_config& c, const floa
   return da;
 }
 
+// --------------------------------------------------------------------------------------
+// fft512 wave-autonomous fbank kernel (kernel_fft512c.hpp); its filterbank schedule is built in mel4_schedule.hpp
+// --------------------------------------------------------------------------------------
+template <int NROWS>
+static const void* fft512c_entry() {
+  return reinterpret_cast<const void*>(&fft512c_kernel<NROWS>);
+}
+
+// Returns HIPFEAT_OK with p->variant == 7 when the configuration takes the wave-autonomous kernel, HIPFEAT_OK with the
+// variant untouched when it does not (the caller then sets up kernel "b").
+static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, const float* h_mel, int nrows) {
+  const hipfeat_config& c = p->cfg;
+  const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
+  Mel4Schedule sch;
+  if (!build_mel4_schedule(h_mel, M, p->K, kCPRowStride, kCMaxSets, kCMaxSteps, sch)) return HIPFEAT_OK;
+  // LDS image: window/2 as (even, odd) sample pairs per (row n1, lane q); pass twiddles W_256^(q k1) per (row k1, lane q);
+  // split-step twiddles -i W_512^(q + 16 k2) per (row k2 < 8, lane q); then the filterbank tables
+  std::vector<float> img((size_t)(nrows * 16 + 256 + 128) * 2, 0.0f);
+  for (int n1 = 0; n1 < nrows; ++n1)
+    for (int q = 0; q < 16; ++q)
+      for (int e = 0; e < 2; ++e) {
+        const int i = 32 * n1 + 2 * q + e;
+        img[2 * (n1 * 16 + q) + e] = i < N ? 0.5f * h_window[i] : 0.0f;
+      }
+  float* twp = img.data() + 2 * nrows * 16;
+  float* tws = twp + 512;
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int q = 0; q < 16; ++q) {
+      const double a = -2.0 * M_PI * (double)(q * k1) / 256.0;
+      twp[2 * (k1 * 16 + q)] = (float)std::cos(a);
+      twp[2 * (k1 * 16 + q) + 1] = (float)std::sin(a);
+    }
+  for (int k2 = 0; k2 < 8; ++k2)
+    for (int q = 0; q < 16; ++q) {  // w = -i * W_512^k = (sin(a), -cos(a)) with a = -2 pi k / 512
+      const double a = -2.0 * M_PI * (double)(q + 16 * k2) / 512.0;
+      tws[2 * (k2 * 16 + q)] = (float)std::sin(a);
+      tws[2 * (k2 * 16 + q) + 1] = (float)(-std::cos(a));
+    }
+  // the kernel runs kCMaxSets sets of kCMaxSteps steps unconditionally: pad the tables (weights 0, no output column)
+  p->c_wtab_off = (int)img.size();
+  img.resize(img.size() + (size_t)kCMaxSets * kCMaxSteps * 64, 0.0f);
+  for (int s2 = 0; s2 < sch.nsets; ++s2)
+    std::memcpy(img.data() + p->c_wtab_off + (size_t)s2 * kCMaxSteps * 64, sch.wtab.data() + (size_t)sch.step0[s2] * 64, (size_t)sch.steps[s2] * 64 * sizeof(float));
+  p->c_ltab_off = (int)img.size();
+  img.resize(img.size() + (size_t)kCMaxSets * 256, 0.0f);
+  {
+    const int none = -1;
+    for (int s2 = 0; s2 < kCMaxSets; ++s2)
+      for (int lane = 0; lane < 64; ++lane) {
+        float* lt = img.data() + p->c_ltab_off + ((size_t)s2 * 64 + lane) * 4;
+        if (s2 < sch.nsets) std::memcpy(lt, sch.ltab.data() + ((size_t)s2 * 64 + lane) * 4, 4 * sizeof(float));
+        else std::memcpy(lt + 1, &none, 4);
+      }
+  }
+  while (img.size() % 64) img.push_back(0.0f);
+  p->c_shared_floats = (int)img.size();
+  p->c_xs_floats = (3 * shift + 32 * nrows + 3) & ~3;
+  const size_t lds = ((size_t)p->c_shared_floats + (size_t)kCWaves * (p->c_xs_floats + kCRegion)) * sizeof(float);
+  if (lds > 80 * 1024) return HIPFEAT_OK;  // two workgroups of 8 waves per CU or nothing
+  const void* fn = nrows == 10 ? fft512c_entry<10>() : (nrows == 13 ? fft512c_entry<13>() : fft512c_entry<16>());
+  hipError_t e = ensure_dynamic_lds(fn, lds);
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft512c) failed: %s", hipGetErrorName(e));
+  hipfeat_status st;
+  if ((st = upload(&p->d_c_shared, img.data(), img.size())) != HIPFEAT_OK) return st;
+  p->nrows = nrows;
+  p->c_rounds = 8;  // 8 waves x 8 rounds x 4 frames = 256 frames per workgroup
+  if (const char* rd = getenv("HIPFEAT_C_ROUNDS")) p->c_rounds = std::max(1, atoi(rd));  // experiments
+  p->fpb = kCWaves * p->c_rounds * 4;
+  p->fast_lds_bytes = lds;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kCWaves, lds) == hipSuccess) p->blocks_per_cu = nb;
+  int total_steps = 0;
+  for (int s2 = 0; s2 < sch.nsets; ++s2) total_steps += sch.steps[s2];
+  char nm[128];
+  snprintf(nm, sizeof(nm), "fft512c_kernel<%d> fbank lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, lds, p->blocks_per_cu, sch.nsets, total_steps);
+  p->kernel_name = nm;
+  p->variant = 7;
+  return HIPFEAT_OK;
+}
+
 static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const float* h_mel, const float* h_dct,
                                    const float* h_lifter) {
   const hipfeat_config& c = p->cfg;
@@ -350,6 +436,13 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   const int ntiles = spec ? 0 : (M + 15) / 16;
   if (ntiles > 8) return HIPFEAT_OK;
 
+  if (!mfcc && !spec) {  // log-mel filterbank: the wave-autonomous kernel, unless the schedule or the LDS budget says no
+    const char* var = getenv("HIPFEAT_FFT512_VARIANT");
+    if (!(var && (var[0] == 'a' || var[0] == 'b'))) {
+      hipfeat_status stc = setup_fft512c(p, h_window, h_mel, nrows);
+      if (stc != HIPFEAT_OK || p->variant == 7) return stc;
+    }
+  }
   WaveWork work[4];
   std::vector<float> mel_a;
   if (!build_mel_schedule(h_mel, M, p->K, kPRowStride, ntiles, work, mel_a)) return HIPFEAT_OK;  // -> generic kernel
@@ -1141,6 +1234,36 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)lay->batch), dim3(1024), 0, stream, lay->d_cuts, d_out, lay->out_row_stride,
                        (int32_t)c.num_filters, (int32_t)c.frame_shift);
+    HIP_TRY(hipGetLastError());
+    return HIPFEAT_OK;
+  }
+  if (plan->variant == 7) {
+    Fft512cParams fp{};
+    fp.wave = d_wave;
+    fp.out = d_out;
+    fp.cuts = lay->d_cuts;
+    fp.shared_consts = plan->d_c_shared;
+    fp.out_stride = lay->out_row_stride;
+    fp.num_cuts = (int32_t)lay->batch;
+    fp.uniform_bpc = lay->uniform_bpc;
+    fp.frames_per_block = plan->fpb;
+    fp.rounds = plan->c_rounds;
+    fp.N = c.frame_length;
+    fp.shift = c.frame_shift;
+    fp.npad_left = plan->npad_left;
+    fp.M = c.num_filters;
+    fp.flags = c.remove_dc_offset ? F_REMOVE_DC : 0;
+    fp.preemph = c.preemph_coeff;
+    fp.mel_floor = c.mel_floor;
+    fp.shared_floats = plan->c_shared_floats;
+    fp.wtab_off = plan->c_wtab_off;
+    fp.ltab_off = plan->c_ltab_off;
+    fp.xs_floats = plan->c_xs_floats;
+    DeviceGuard g(plan->device);
+    const dim3 grid((unsigned)lay->total_blocks), block(64 * kCWaves);
+    if (plan->nrows == 10) hipLaunchKernelGGL(fft512c_kernel<10>, grid, block, plan->fast_lds_bytes, stream, fp);
+    else if (plan->nrows == 13) hipLaunchKernelGGL(fft512c_kernel<13>, grid, block, plan->fast_lds_bytes, stream, fp);
+    else hipLaunchKernelGGL(fft512c_kernel<16>, grid, block, plan->fast_lds_bytes, stream, fp);
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }

@@ -41,7 +41,11 @@ constexpr int kWaveRegion = HIPFEAT_EXPERIMENT_REGION;
 constexpr int kWaveRegion = 4 * kExFrameStride + 16;  // 2192 dwords per wave (== 16 mod 64)
 #endif
 constexpr int kPRowStride = 260;                      // dwords per power row (== 4 mod 64)
-constexpr int kMaxGroups0 = 20;                       // 8-bin MFMA groups of a wave's first / second mel tile
+#ifdef HF_X_MAXG0
+constexpr int kMaxGroups0 = HF_X_MAXG0;
+#else
+constexpr int kMaxGroups0 = 20;
+#endif                       // 8-bin MFMA groups of a wave's first / second mel tile
 constexpr int kMaxGroups1 = 4;
 constexpr int kMelARegs = 2 * (kMaxGroups0 + kMaxGroups1);
 constexpr int kPrefetch = 3;                          // float4 per lane per tile (256 * 3 * 4 >= span)

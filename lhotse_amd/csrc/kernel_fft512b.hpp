@@ -42,7 +42,20 @@ constexpr int kBMelVec = kMelARegs / 4;                  // 16-byte loads of fil
 #define HIPFEAT_FFT512B_WAVES_PER_SIMD 4
 #endif
 
-constexpr int kMaxDctGroups = 10;  // 8-mel groups of the DCT GEMM (num_filters <= 80)
+constexpr int kMaxDctGroups = 10;
+#ifdef HF_X_LDS1
+#define HF_SEP() asm volatile("")
+#else
+#define HF_SEP()
+#endif
+#ifndef HF_X_ABL
+#define HF_X_ABL 0
+#endif
+#ifdef HF_X_CMUL
+#define HF_CMUL cmul2
+#else
+#define HF_CMUL cmul
+#endif  // 8-mel groups of the DCT GEMM (num_filters <= 80)
 
 // OUT = 0: log-mel filterbank (Wav2LogFilterBank).  OUT = 1: MFCC -- the log-mel tile goes to LDS instead of
 // HBM and a second (dense, tiny) MFMA GEMM applies the DCT (layers.py:716), then the lifter (:717-718).
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
     float* myreg = regions + wv * kBWaveRegion;
 
     // ---- S3 ---------------------------------------------------------------------------------
-#if defined(HIPFEAT_ABLATE) && (HIPFEAT_ABLATE & 2)
+#if (defined(HIPFEAT_ABLATE) && (HIPFEAT_ABLATE & 2)) || (HF_X_ABL & 2)
     if (p.N < 0)  // experiment builds only: the phase is compiled but skipped at run time
 #endif
     {
@@ -143,9 +156,9 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
       v2 win[NROWS];
       v2 sum2 = {0.f, 0.f};
 #pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) z[n1] = *reinterpret_cast<const v2*>(x + 32 * n1);
+      for (int n1 = 0; n1 < NROWS; ++n1) { z[n1] = *reinterpret_cast<const v2*>(x + 32 * n1); HF_SEP(); }
 #pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) win[n1] = cwin[n1 * 16 + q];
+      for (int n1 = 0; n1 < NROWS; ++n1) { win[n1] = cwin[n1 * 16 + q]; HF_SEP(); }
       // samples at or beyond N (the frame length) are not part of the frame: the template instance may carry up to three
       // rows more than ceil(N / 32), so every row is checked (uniform test per row, lane mask only in the boundary rows)
 #pragma unroll
@@ -156,6 +169,10 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
           if (m0 + 1 >= N) z[n1].y = 0.f;
         }
       }
+#if HF_X_ABL & 4
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) z[n1] = z[n1] * win[n1];
+#else
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) sum2 += z[n1];
       float mu = 0.f;
@@ -182,18 +199,24 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         z[n1] = (d - v2{c, c} * v2{dp, d.x}) * win[n1];
       }
 #endif
+#endif
 #pragma unroll
       for (int n1 = NROWS; n1 < 16; ++n1) z[n1] = v2{0.f, 0.f};
       v2 a[16];
+#if HF_X_ABL & 32
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a[i] = z[i];
+#else
       fft16(z, a);
+#endif
       // pass twiddles W_256^(q k1): fetched from LDS in two bursts of 8 (one latency exposure each)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         v2 tw[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) tw[r] = ctwp[(8 * h + r) * 16 + q];
+        for (int r = 0; r < 8; ++r) { tw[r] = ctwp[(8 * h + r) * 16 + q]; HF_SEP(); }
 #pragma unroll
-        for (int r = (h == 0 ? 1 : 0); r < 8; ++r) a[8 * h + r] = cmul(a[8 * h + r], tw[r]);
+        for (int r = (h == 0 ? 1 : 0); r < 8; ++r) a[8 * h + r] = HF_CMUL(a[8 * h + r], tw[r]);
       }
 
       // exchange in two halves: rows k1 = 8h .. 8h+7 go through an 8-row block; lanes with
@@ -201,6 +224,11 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
       float* exf = myreg + g * kBExFrameStride;
       v2 b[16];
       constexpr int RPP = 16 / kBExParts;  // rows per part
+#if HF_X_ABL & 16
+#pragma unroll
+      for (int i = 0; i < 16; ++i) b[i] = a[i];
+      if (p.N < 0)
+#endif
 #pragma unroll
       for (int h = 0; h < kBExParts; ++h) {
 #pragma unroll
@@ -210,18 +238,31 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (q / RPP == h) {
 #pragma unroll
-          for (int n2 = 0; n2 < 16; ++n2) b[n2] = *reinterpret_cast<const v2*>(exf + (q % RPP) * kBExRowStride + 2 * n2);
+          for (int n2 = 0; n2 < 16; ++n2) { b[n2] = *reinterpret_cast<const v2*>(exf + (q % RPP) * kBExRowStride + 2 * n2); HF_SEP(); }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
       v2 Z[16];
+#if HF_X_ABL & 64
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Z[i] = b[i];
+#else
       fft16(b, Z);
+#endif
 
       float* prow = myreg + g * kPRowStride;
       float* pown = prow + q;
       float* ppar = prow + ((16 - q) & 15) + (q == 0 ? 16 : 0);
       if (q < 3) prow[257 + q] = 0.f;
+#if HF_X_ABL & 8
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        pown[16 * k2] = Z[k2].x * Z[k2].x + Z[k2].y * Z[k2].y;
+        ppar[16 * (15 - k2)] = Z[15 - k2].x * Z[15 - k2].x + Z[15 - k2].y * Z[15 - k2].y;
+      }
+      if (p.N < 0) {
+#endif
 #if !HIPFEAT_B5
       float t1[16];
 #pragma unroll
@@ -243,10 +284,14 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           tw[r] = ctws[(4 * h + r) * 16 + q];
-#if HIPFEAT_B5
+          HF_SEP();
+#if defined(HF_X_CMUL)
+          twq[r] = tw[r];
+#elif HIPFEAT_B5
           twq[r] = swap2(tw[r] * HF_CJ);  // (-w.y, w.x)
 #else
           twq[r] = ctwsp[(4 * h + r) * 16 + q];
+          HF_SEP();
 #endif
         }
 #pragma unroll
@@ -260,12 +305,19 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
 #endif
           const v2 sp = m * HF_CJ + Z[k2];
           const v2 dm = m * HF_NCJ + Z[k2];
+#ifdef HF_X_CMUL
+          const v2 tt = cmul2(dm, tw[r]);
+#else
           const v2 tt = cmulc(dm, tw[r], twq[r]);
+#endif
           const v2 xp = sp + tt, xm = sp - tt;
           pown[16 * k2] = xp.x * xp.x + xp.y * xp.y;
           ppar[16 * (15 - k2)] = xm.x * xm.x + xm.y * xm.y;
         }
       }
+#if HF_X_ABL & 8
+      }
+#endif
       if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
     }
     // the filter weights of this wave's band: requested now (the FFT registers are dead), so the L2
@@ -314,9 +366,17 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
       v2 pv[NCH][CH];
       auto load_chunk = [&](int ci) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) pv[ci][i] = *reinterpret_cast<const v2*>(pb + min(ww.bin0 + 8 * (ci * CH + i), kPRowStride - 8));
+        for (int i = 0; i < CH; ++i) { pv[ci][i] = *reinterpret_cast<const v2*>(pb + min(ww.bin0 + 8 * (ci * CH + i), kPRowStride - 8)); HF_SEP(); }
       };
+#ifdef HF_X_ALLP
+#pragma unroll
+      for (int ci = 0; ci < NCH; ++ci) load_chunk(ci);
+      v2 pv1[kMaxGroups1];
+#pragma unroll
+      for (int gi = 0; gi < kMaxGroups1; ++gi) { pv1[gi] = *reinterpret_cast<const v2*>(pb + min(ww.bin1 + 8 * gi, kPRowStride - 8)); HF_SEP(); }
+#else
       load_chunk(0);
+#endif
       // gfx950 has ONE in-order counter for all vector-memory operations: take delivery of the weights
       // (requested before the barrier) BEFORE the span DMA is issued, otherwise their first use would
       // have to wait for the much slower HBM transfer queued behind them.
@@ -354,15 +414,17 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         }
       };
       auto wgt = [&](int step) -> float { return ma[step >> 2][step & 3]; };
-#if defined(HIPFEAT_ABLATE) && (HIPFEAT_ABLATE & 1)
-      if (false) {
+#if (defined(HIPFEAT_ABLATE) && (HIPFEAT_ABLATE & 1)) || (HF_X_ABL & 1)
+      if (p.N < 0) {
 #else
       if (ww.ngroups0 > 0) {
 #endif
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ci = 0; ci < NCH; ++ci) {
+#ifndef HF_X_ALLP
           if (ci + 1 < NCH) load_chunk(ci + 1);
+#endif
           if (ci * CH < ww.ngroups0) {
 #pragma unroll
             for (int i = 0; i < CH; ++i)
@@ -379,10 +441,14 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
 #endif
         epilogue(acc + acc2, ww.tile0);
       }
-      if (ww.ngroups1 > 0) {
+      if (ww.ngroups1 > 0 && !((HF_X_ABL & 1) && p.N >= 0)) {
+#ifdef HF_X_ALLP
+        v2 (&pv)[kMaxGroups1] = pv1;
+#else
         v2 pv[kMaxGroups1];
 #pragma unroll
         for (int gi = 0; gi < kMaxGroups1; ++gi) pv[gi] = *reinterpret_cast<const v2*>(pb + min(ww.bin1 + 8 * gi, kPRowStride - 8));
+#endif
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int gi = 0; gi < kMaxGroups1; ++gi) {

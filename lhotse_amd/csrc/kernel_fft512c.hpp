@@ -1,0 +1,307 @@
+// fft512 fast path, wave-autonomous variant ("c"): log-mel filterbank (Wav2LogFilterBank, layers.py:565-578) for
+// fft 512 with NO workgroup barrier in the steady state.
+//
+// The "b" kernel couples the four waves of a workgroup twice per 16-frame tile: the 16x16x4 matrix-core GEMM of the
+// mel stage needs the power rows of all 16 frames, i.e. of all four waves (barrier), and the shared sample span may only
+// be overwritten once everybody has framed it (barrier).  Measured on MI355X (phase timers, round 2): of 13.9 k clk per
+// wave-tile 3.3 k were the mel stage (five dependent LDS round trips + the re-fetch of 48 KB of filter weights per tile
+// from L2) and 1.3 k barrier waits, while VALU, LDS and matrix pipes each sat half idle.
+//
+// Here a wave owns its four frames from the samples to the stored log-mel rows:
+//   * its own sample span (3 shift + N floats) comes by LDS-DMA into a wave-private buffer, requested one round ahead
+//     (as soon as the current round's samples sit in registers);
+//   * S3 (framing, DC, pre-emphasis, window, 512-point real FFT on 16 lanes per frame, |X|^2) is the "b" kernel's, with
+//     single ds_read_b64 (hipcc's merged ds_read2_b64 runs at half the LDS rate on gfx950: tools/ubench/lds_rate.hip)
+//     and two-instruction complex multiplies;
+//   * the mel filterbank runs on the matrix cores with v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 blocks per
+//     instruction, block = (4 frames of THIS wave) x (4 consecutive mel filters) x (1 bin), so a block "slot" walks the
+//     band of its filter group one bin per instruction.  Wide bands are split over 2 or 4 adjacent slots (summed with
+//     two row_shr DPP multiply-adds), which levels the 298 (group, bin) pairs of the 80-filter bank to ~10 steps on each
+//     of 2 accumulator sets.  A operand = one power value per lane (ds_read_b32 from the wave's own rows), B operand =
+//     one weight per lane from a 5 KB table in LDS: no vector-memory traffic for weights at all;
+//   * log and store straight from the accumulators (lane = 4 slot + filter, register = frame).
+// One __syncthreads() at kernel start (constant tables), none afterwards.
+#pragma once
+#include "common.hpp"
+#include "fft_common.hpp"
+
+namespace hipfeat {
+
+constexpr int kCExRowStride = 34;                          // dwords per exchange row (16 complex + 2 pad)
+constexpr int kCExFrameStride = 8 * kCExRowStride + 16;    // 288 (== 32 mod 64): 8 rows per half
+constexpr int kCPRowStride = 272;                          // dwords per power row (== 16 mod 64: the 4 frames of a slot hit disjoint bank quads)
+constexpr int kCRegion = 4 * kCExFrameStride + 16;         // 1168 dwords per wave; the 4 power rows (1088) alias it
+constexpr int kCMaxSets = 2;                               // accumulator sets (16 slots each)
+constexpr int kCMaxSteps = 16;                             // MFMA steps per set
+constexpr int kCWaves = 8;                                 // waves per workgroup
+
+struct Fft512cParams {
+  const float* wave;
+  float* out;
+  const CutDesc* cuts;
+  // shared LDS image, copied once per workgroup: [nrows][16] v2 window/2 | [16][16] v2 W_256^(q k1) | [8][16] v2 -i W_512^(q+16 k2)
+  // | weight table [2 sets][16 steps / 4][64 lanes][4 steps] (zero beyond a set's steps) | lane table [2 sets][64 lanes][4]
+  // (power-row offset (int), output column (int, -1 = none), m4, m8)
+  const float* shared_consts;
+  int64_t out_stride;
+  int32_t num_cuts, uniform_bpc;
+  int32_t frames_per_block, rounds;  // rounds of 4 frames per wave; frames_per_block = 8 waves * rounds * 4
+  int32_t N, shift, npad_left, M, flags;
+  float preemph, mel_floor;
+  int32_t shared_floats;  // floats of the shared image
+  int32_t wtab_off, ltab_off;  // float offsets of the weight / lane tables inside the image
+  int32_t xs_floats;      // floats of one wave's sample-span buffer (multiple of 4)
+};
+
+#define HFC_SEP() asm volatile("")  // keeps hipcc from merging two ds_read_b64 into one (half-rate) ds_read2_b64
+
+template <int NROWS>
+__global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const v2* cwin = reinterpret_cast<const v2*>(smem);  // [NROWS][16]
+  const v2* ctwp = cwin + NROWS * 16;                  // [16][16] row k1, column q
+  const v2* ctws = ctwp + 256;                         // [8][16] w = -i W_512^(q+16 k2)
+  const float* wtab = smem + p.wtab_off;
+  const float* ltab = smem + p.ltab_off;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int blk = blockIdx.x;
+  int cut, fb;
+  if (p.uniform_bpc > 0) {
+    cut = blk / p.uniform_bpc;
+    fb = blk - cut * p.uniform_bpc;
+  } else {
+    cut = find_cut(p.cuts, p.num_cuts, blk);
+    fb = blk - p.cuts[cut].first_block;
+  }
+  const CutDesc cd = p.cuts[cut];
+  const float* __restrict__ w = p.wave + cd.wave_off;
+  const int N = p.N, shift = p.shift;
+  const int span = 3 * shift + N;
+
+  for (int i = tid; i < p.shared_floats; i += 64 * kCWaves) smem[i] = p.shared_consts[i];
+  float* xs = smem + p.shared_floats + wv * (p.xs_floats + kCRegion);
+  float* myreg = xs + p.xs_floats;
+  const bool dc = (p.flags & F_REMOVE_DC) != 0;
+  const float inv_n = 1.0f / (float)N;
+  const float c = p.preemph;
+  const int nchunks = (p.xs_floats + 255) >> 8;  // 1 KiB LDS-DMA pieces covering the span buffer
+
+  // Stage the span of the four frames starting at f0 into this wave's buffer.  Interior rounds: LDS-DMA (lane i supplies
+  // the global address of its 16 bytes, the hardware writes piece base + 16 i).  Rounds touching a cut edge (reflection,
+  // zero padding of a batch row): per-lane loads through the edge rule.
+  auto stage_span = [&](int f0, unsigned lane4) {
+    const int64_t j0 = (int64_t)f0 * shift - p.npad_left;
+    if (j0 >= 0 && j0 + p.xs_floats <= cd.num_samples) {
+      const char* src = reinterpret_cast<const char*>(w + j0);  // uniform
+      for (int ch = 0; ch < nchunks; ++ch)
+        if ((unsigned)ch * 256u + lane4 < (unsigned)p.xs_floats)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)ch * 1024u + 4u * lane4)),
+                                           (__attribute__((address_space(3))) void*)(xs + ch * 256), 16, 0, 0);
+    } else {
+      for (int i = (int)(lane4 >> 2); i < span; i += 64) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
+    }
+  };
+
+  const int first_frame = fb * p.frames_per_block + wv * p.rounds * 4;
+  __syncthreads();  // the constant tables are in place (the only workgroup barrier of the kernel)
+  if (first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
+
+  for (int r = 0; r < p.rounds; ++r) {
+    const int f0 = first_frame + 4 * r;
+    if (f0 >= cd.num_frames) break;
+    const int nf = min(4, cd.num_frames - f0);
+
+    // this round's span was requested a round ago by this very wave: its own vmcnt covers the LDS-DMA, the in-order LDS
+    // queue covers the per-lane stores of an edge round
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    // Re-derive every per-lane address inside the loop from an opaque copy of the lane id (LICM would otherwise pin ~25
+    // loop-invariant addresses in VGPRs for the whole kernel and cost a wave of occupancy).
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int q = lane_o & 15, g = lane_o >> 4;
+
+    v2 Z[16];
+    {
+      const float* x = xs + g * shift + 2 * q;
+      v2 z[16];
+      v2 win[NROWS];
+      v2 sum2 = {0.f, 0.f};
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        z[n1] = *reinterpret_cast<const v2*>(x + 32 * n1);
+        HFC_SEP();
+      }
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        win[n1] = cwin[n1 * 16 + q];
+        HFC_SEP();
+      }
+      // the samples are in flight to registers; once they have arrived the buffer is free for the next round's span
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (r + 1 < p.rounds && f0 + 4 < cd.num_frames) stage_span(f0 + 4, (unsigned)lane_o * 4u);
+
+      // samples at or beyond N (the frame length) are not part of the frame (uniform test per row, lane mask only in
+      // the boundary rows)
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        if (32 * (n1 + 1) > N) {
+          const int m0 = 32 * n1 + 2 * q;
+          if (m0 >= N) z[n1].x = 0.f;
+          if (m0 + 1 >= N) z[n1].y = 0.f;
+        }
+      }
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) sum2 += z[n1];
+      float mu = 0.f;
+      if (dc) mu = row16_sum(sum2.x + sum2.y) * inv_n;
+      // previous sample of the first element of each pair: lane q-1's second element; for lane 0 it is lane 15's second
+      // element of the previous row (fetched one row earlier with row_ror:1), and the very first sample of the frame
+      // replicates itself (layers.py:166)
+      float wrap = 0.f;
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) {
+        const v2 d = z[n1] - v2{mu, mu};
+        const float dp = dpp_shr1_keep(n1 == 0 ? d.x : wrap, d.y);
+        if (n1 + 1 < NROWS) wrap = dpp_mov<DPP_ROW_ROR1>(d.y);
+        z[n1] = (d - v2{c, c} * v2{dp, d.x}) * win[n1];
+      }
+#pragma unroll
+      for (int n1 = NROWS; n1 < 16; ++n1) z[n1] = v2{0.f, 0.f};
+      v2 a[16];
+      fft16(z, a);
+      // pass twiddles W_256^(q k1): fetched from LDS in two bursts of 8 (one latency exposure each)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        v2 tw[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          tw[rr] = ctwp[(8 * h + rr) * 16 + q];
+          HFC_SEP();
+        }
+#pragma unroll
+        for (int rr = (h == 0 ? 1 : 0); rr < 8; ++rr) a[8 * h + rr] = cmul2(a[8 * h + rr], tw[rr]);
+      }
+
+      // exchange in two halves: rows k1 = 8h .. 8h+7 go through an 8-row block; lanes with (q >> 3) == h then read
+      // "their" row (all n2) back
+      float* exf = myreg + g * kCExFrameStride;
+      v2 b[16];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) *reinterpret_cast<v2*>(exf + rr * kCExRowStride + 2 * q) = a[8 * h + rr];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (q / 8 == h) {
+#pragma unroll
+          for (int n2 = 0; n2 < 16; ++n2) {
+            b[n2] = *reinterpret_cast<const v2*>(exf + (q % 8) * kCExRowStride + 2 * n2);
+            HFC_SEP();
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      fft16(b, Z);
+    }
+
+    {
+      float* prow = myreg + g * kCPRowStride;
+      float* pown = prow + q;
+      float* ppar = prow + ((16 - q) & 15) + (q == 0 ? 16 : 0);
+      if (q < kCPRowStride - 257) prow[257 + q] = 0.f;  // the padding a slot may read past bin 256 (weight 0) must be finite
+      float t1[16];
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        t1[2 * k2] = dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].x);
+        t1[2 * k2 + 1] = dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].y);
+      }
+      // second half of the lane map l -> (16 - l) % 16: shift right by one; lane 0 has no source and keeps its own
+      // register (16 - k2) % 16 instead (its mirror partner is itself)
+#pragma unroll
+      for (int k2 = 0; k2 < 8; ++k2) {
+        t1[2 * k2] = dpp_shr1_keep(Z[(16 - k2) & 15].x, t1[2 * k2]);
+        t1[2 * k2 + 1] = dpp_shr1_keep(Z[(16 - k2) & 15].y, t1[2 * k2 + 1]);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        v2 tw[4];  // split-step twiddles of 4 bin pairs per burst
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          tw[rr] = ctws[(4 * h + rr) * 16 + q];
+          HFC_SEP();
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int k2 = 4 * h + rr;
+          const v2 m = v2{t1[2 * k2], t1[2 * k2 + 1]};
+          const v2 sp = m * HF_CJ + Z[k2];
+          const v2 dm = m * HF_NCJ + Z[k2];
+          const v2 tt = cmul2(dm, tw[rr]);
+          const v2 xp = sp + tt, xm = sp - tt;
+          pown[16 * k2] = xp.x * xp.x + xp.y * xp.y;
+          ppar[16 * (15 - k2)] = xm.x * xm.x + xm.y * xm.y;
+        }
+      }
+      if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
+    }
+    // the wave's four power rows are complete once its own (in-order) LDS queue has drained
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- mel filterbank on the matrix cores, 4 frames x 4 filters x 1 bin per block, 16 blocks per instruction ----
+    // All operands of the phase are requested before the first MFMA (one LDS round trip; the FFT registers are dead):
+    // A = four consecutive power values per 16-byte read (lane = slot b, frame i: P[i][bin0(b) + 4 c ..]), B = four
+    // consecutive steps of the weight table per 16-byte read (lane = slot b, filter j).
+    float* orow = p.out + (cd.out_row + f0) * p.out_stride;
+    int lt_poff[kCMaxSets], lt_col[kCMaxSets];
+    float lt_m4[kCMaxSets], lt_m8[kCMaxSets];
+#pragma unroll
+    for (int s = 0; s < kCMaxSets; ++s) {
+      const float* lt = ltab + s * 256 + 4 * lane_o;
+      lt_poff[s] = __builtin_bit_cast(int, lt[0]);
+      lt_col[s] = __builtin_bit_cast(int, lt[1]);
+      lt_m4[s] = lt[2];
+      lt_m8[s] = lt[3];
+    }
+    f32x4 av[kCMaxSets][kCMaxSteps / 4], bv[kCMaxSets][kCMaxSteps / 4];
+#pragma unroll
+    for (int s = 0; s < kCMaxSets; ++s) {
+      const float* pa = myreg + lt_poff[s];
+      const float* wb = wtab + s * (kCMaxSteps * 64) + 4 * lane_o;
+#pragma unroll
+      for (int c4 = 0; c4 < kCMaxSteps / 4; ++c4) {
+        av[s][c4] = *reinterpret_cast<const f32x4*>(pa + 4 * c4);
+        bv[s][c4] = *reinterpret_cast<const f32x4*>(wb + c4 * 256);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < kCMaxSets; ++s) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c4 = 0; c4 < kCMaxSteps / 4; ++c4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s][c4][i], bv[s][c4][i], acc, 0, 0, 0);
+      }
+      const int col = lt_col[s];
+      const float m4 = lt_m4[s], m8 = lt_m8[s];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[i];
+        v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4 -- the odd slot of a pair takes its left neighbour's partial sum
+        v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8 -- the last slot of a group of 3 or 4 takes the first slot(s)'
+        v = fast_log(fmaxf(v, p.mel_floor));
+        if (col >= 0 && i < nf) orow[i * p.out_stride + col] = v;
+      }
+    }
+    // the next round's exchange writes follow this round's power-row reads in the wave's own LDS queue (in order)
+  }
+}
+
+}  // namespace hipfeat
