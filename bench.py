@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="host processes of the CPU baseline (default min(cores, 128))")
+    ap.add_argument("--input", default="uniform", choices=["uniform", "zeros", "sine"], help="synthetic input (the metric is defined on `uniform`; the others exist to expose power/DVFS effects)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (self-test of the N>1 path on one GPU)")
     args = ap.parse_args()
 
@@ -250,6 +251,11 @@ def main():
     chunk = 500
     for i in range(0, C, chunk):
         wave[i : i + chunk].uniform_(-0.5, 0.5, generator=g)
+    if args.input == "zeros":
+        wave.zero_()
+    elif args.input == "sine":
+        t = torch.arange(SAMPLES_PER_CUT, device=dev, dtype=torch.float32)
+        wave[:] = 0.4 * torch.sin(2 * 3.14159265 * 440.0 / 16000.0 * t)
     out = torch.empty((C * FRAMES_PER_CUT, NUM_MELS), dtype=torch.float32, device=dev)
     offs = np.arange(C, dtype=np.int64) * SAMPLES_PER_CUT
     lens = np.full(C, SAMPLES_PER_CUT, dtype=np.int64)

@@ -5,6 +5,26 @@
 
 namespace hipfeat {
 
+// Experiment builds (-DHIPFEAT_LDS_POISON): every feature kernel fills its dynamic LDS with NaN before it starts, so that
+// a read of a location the kernel never wrote (harmless-looking when it meets a zero weight and the leftover bits of the
+// previous kernel happen to be finite) shows up as NaN in the GPU tests.  tools/lds_poison.sh runs the suite on such a build.
+#ifdef HIPFEAT_LDS_POISON
+__device__ int g_lds_poison_floats;
+#define HF_POISON_LDS(smem_)                                                                                           \
+  do {                                                                                                                 \
+    for (int i_ = threadIdx.x; i_ < g_lds_poison_floats; i_ += blockDim.x) (smem_)[i_] = __builtin_nanf("");            \
+    __syncthreads();                                                                                                   \
+  } while (0)
+#define HF_POISON_ARRAY(arr_, n_)                                                                                      \
+  do {                                                                                                                 \
+    for (int i_ = threadIdx.x; i_ < (int)(n_); i_ += blockDim.x) (arr_)[i_] = __builtin_nanf("");                       \
+    __syncthreads();                                                                                                   \
+  } while (0)
+#else
+#define HF_POISON_LDS(smem_)
+#define HF_POISON_ARRAY(arr_, n_)
+#endif
+
 // One cut of a batch, as the kernels see it (32 bytes, device resident).
 struct CutDesc {
   int64_t wave_off;     // first sample of the cut in the waveform buffer (elements)

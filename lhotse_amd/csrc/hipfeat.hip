@@ -16,13 +16,12 @@
 
 #include "common.hpp"
 #include "kernel_generic.hpp"
-#include "kernel_fft512.hpp"
+#include "fft512_common.hpp"
 #include "kernel_fft512b.hpp"
 #include "kernel_fft512c.hpp"
 #include "mel4_schedule.hpp"
 #include "kernel_resample.hpp"
 #include "kernel_specaug.hpp"
-#include "kernel_whisper.hpp"
 #include "kernel_whisper2.hpp"
 #include "kernel_fft256.hpp"
 #include "kernel_wave.hpp"
@@ -94,7 +93,7 @@ struct hipfeat_plan {
   int span = 0, off_z = 0, off_p = 0, off_tw = 0, off_stat = 0, off_mel = 0;
   size_t lds_bytes = 0;
   // fft512 fast path
-  int variant = 0;  // 0 generic, 1 fft512 fbank (register-resident weights), 2 fft512 fbank "b" (4 workgroups/CU)
+  int variant = 0;  // 0 generic, 2 fft512 "b" (16-frame tiles), 4 fft256, 5 wave-per-frame, 6 whisper, 7 fft512 "c" (wave-autonomous fbank)
   float* d_mel_a4 = nullptr;
   float* d_dct_consts = nullptr;
   bool fast_mfcc = false;
@@ -117,12 +116,6 @@ struct hipfeat_plan {
   int wave_blob_floats = 0;
   bool wave_dct_in_lds = false;
   size_t wave_lds_bytes = 0;
-  // whisper fast path (variant 3)
-  float* d_wh_dft = nullptr;
-  float* d_wh_mel = nullptr;
-  int32_t wh_mt_lo[kWhBinTiles] = {};
-  int32_t wh_mt_cnt[kWhBinTiles] = {};
-  int wh_mel_tiles = 0;
   // whisper FFT fast path (variant 6)
   float* d_wh2_cs = nullptr;
   float* d_wh2_tw = nullptr;
@@ -226,8 +219,6 @@ static void plan_free(hipfeat_plan* p) {
   (void)hipFree(p->d_work);
   (void)hipFree(p->d_mel_t);
   (void)hipFree(p->d_c_shared);
-  (void)hipFree(p->d_wh_dft);
-  (void)hipFree(p->d_wh_mel);
   for (auto& s : p->slots) {
     if (s.h) (void)hipHostFree(s.h);
     if (s.d) (void)hipFree(s.d);
@@ -239,10 +230,6 @@ static void plan_free(hipfeat_plan* p) {
 // --------------------------------------------------------------------------------------
 // fft512 fast path: eligibility, constants, mel work split
 // --------------------------------------------------------------------------------------
-template <int NROWS>
-static const void* fft512_entry() {
-  return reinterpret_cast<const void*>(&fft512_fbank_kernel<NROWS>);
-}
 template <int NROWS, int OUT>
 static const void* fft512b_entry() {
   return reinterpret_cast<const void*>(&fft512b_kernel<NROWS, OUT>);
@@ -250,6 +237,15 @@ static const void* fft512b_entry() {
 
 // The dynamic-LDS limit of a kernel is a property of the FUNCTION, shared by every plan of the process: it is only ever
 // raised (per device), so that a later plan with a smaller footprint cannot lower it under an earlier plan's launches.
+#ifdef HIPFEAT_LDS_POISON
+static void set_lds_poison(size_t bytes) {
+  const int n = (int)(bytes / sizeof(float));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(hipfeat::g_lds_poison_floats), &n, sizeof(n));
+}
+#else
+static inline void set_lds_poison(size_t) {}
+#endif
+
 static hipError_t ensure_dynamic_lds(const void* fn, size_t bytes) {
   static std::mutex mu;
   static std::map<std::pair<const void*, int>, size_t> high;
@@ -386,7 +382,7 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
   p->c_ltab_off = (int)img.size();
   img.resize(img.size() + (size_t)kCMaxSets * 256, 0.0f);
   {
-    const int none = -1;
+    const int none = kMel4NoColumn;
     for (int s2 = 0; s2 < kCMaxSets; ++s2)
       for (int lane = 0; lane < 64; ++lane) {
         float* lt = img.data() + p->c_ltab_off + ((size_t)s2 * 64 + lane) * 4;
@@ -398,7 +394,7 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
   p->c_shared_floats = (int)img.size();
   p->c_xs_floats = (3 * shift + 32 * nrows + 3) & ~3;
   const size_t lds = ((size_t)p->c_shared_floats + (size_t)kCWaves * (p->c_xs_floats + kCRegion)) * sizeof(float);
-  if (lds > 80 * 1024) return HIPFEAT_OK;  // two workgroups of 8 waves per CU or nothing
+  if (lds > 80 * 1024 || (p->c_xs_floats >> 8) > 6) return HIPFEAT_OK;  // two workgroups of 8 waves per CU or nothing
   const void* fn = nrows == 10 ? fft512c_entry<10>() : (nrows == 13 ? fft512c_entry<13>() : fft512c_entry<16>());
   hipError_t e = ensure_dynamic_lds(fn, lds);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft512c) failed: %s", hipGetErrorName(e));
@@ -406,7 +402,6 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
   if ((st = upload(&p->d_c_shared, img.data(), img.size())) != HIPFEAT_OK) return st;
   p->nrows = nrows;
   p->c_rounds = 8;  // 8 waves x 8 rounds x 4 frames = 256 frames per workgroup
-  if (const char* rd = getenv("HIPFEAT_C_ROUNDS")) p->c_rounds = std::max(1, atoi(rd));  // experiments
   p->fpb = kCWaves * p->c_rounds * 4;
   p->fast_lds_bytes = lds;
   int nb = 0;
@@ -428,7 +423,7 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
   const bool mfcc = c.kind == HIPFEAT_MFCC;
   const bool spec = c.kind == HIPFEAT_SPECTROGRAM || c.kind == HIPFEAT_LOG_SPECTROGRAM;
-  if (c.kind > HIPFEAT_MFCC || c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || (!spec && c.use_fft_mag) || getenv("HIPFEAT_NO_FAST"))
+  if (c.kind > HIPFEAT_MFCC || c.fft_length != 512 || (shift & 1) || N < 32 || c.use_energy || (!spec && c.use_fft_mag))
     return HIPFEAT_OK;
   if (mfcc && (M > 8 * kMaxDctGroups || c.num_ceps > 64)) return HIPFEAT_OK;
   const int need = (N + 31) / 32;
@@ -438,7 +433,7 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
 
   if (!mfcc && !spec) {  // log-mel filterbank: the wave-autonomous kernel, unless the schedule or the LDS budget says no
     const char* var = getenv("HIPFEAT_FFT512_VARIANT");
-    if (!(var && (var[0] == 'a' || var[0] == 'b'))) {
+    if (!(var && var[0] == 'b')) {  // HIPFEAT_FFT512_VARIANT=b: the 16-frame-tile kernel for log-mel too (tests compare the two)
       hipfeat_status stc = setup_fft512c(p, h_window, h_mel, nrows);
       if (stc != HIPFEAT_OK || p->variant == 7) return stc;
     }
@@ -450,8 +445,7 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   // W_256^(q k1) per (row k1, lane q); split-step twiddles -i W_512^(q + 16 k2) per (row k2, lane q)
   std::vector<float> wh(512, 0.0f);
   for (int i = 0; i < N; ++i) wh[i] = 0.5f * h_window[i];
-  const int const_floats_full = (nrows * 16 + 512) * 2;
-  std::vector<float> lc((size_t)const_floats_full, 0.0f);
+  std::vector<float> lc((size_t)(nrows * 16 + 256 + 128) * 2, 0.0f);
   for (int n1 = 0; n1 < nrows; ++n1)
     for (int q = 0; q < 16; ++q) {
       lc[2 * (n1 * 16 + q)] = wh[32 * n1 + 2 * q];
@@ -465,15 +459,11 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
       twp[2 * (k1 * 16 + q)] = (float)std::cos(a);
       twp[2 * (k1 * 16 + q) + 1] = (float)std::sin(a);
     }
-  float* twsp = tws + 256;
   for (int k2 = 0; k2 < 8; ++k2)
-    for (int q = 0; q < 16; ++q) {  // w = -i * W_512^k = (sin(a), -cos(a)) with a = -2 pi k / 512; wp = (-w.y, w.x)
+    for (int q = 0; q < 16; ++q) {  // w = -i * W_512^k = (sin(a), -cos(a)) with a = -2 pi k / 512
       const double a = -2.0 * M_PI * (double)(q + 16 * k2) / 512.0;
-      const float wx = (float)std::sin(a), wy = (float)(-std::cos(a));
-      tws[2 * (k2 * 16 + q)] = wx;
-      tws[2 * (k2 * 16 + q) + 1] = wy;
-      twsp[2 * (k2 * 16 + q)] = -wy;
-      twsp[2 * (k2 * 16 + q) + 1] = wx;
+      tws[2 * (k2 * 16 + q)] = (float)std::sin(a);
+      tws[2 * (k2 * 16 + q) + 1] = (float)(-std::cos(a));
     }
   hipfeat_status st;
   if ((st = upload(&p->d_lds_consts, lc.data(), lc.size())) != HIPFEAT_OK) return st;
@@ -483,14 +473,10 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   // 16 tiles (256 frames) per workgroup: the constant-table load and the first, un-overlapped span
   // fetch are paid once per workgroup (measured on MI355X: 4 -> 1.98 M, 8 -> 2.11 M, 16 -> 2.16 M cuts/s)
   p->tiles_per_block = 16;
-  if (const char* tpb = getenv("HIPFEAT_TILES_PER_BLOCK")) p->tiles_per_block = std::max(1, atoi(tpb));
-  const char* var = getenv("HIPFEAT_FFT512_VARIANT");
-  const bool use_b = mfcc || spec || !(var && var[0] == 'a');
-  // the twsp table (last 256 floats) is only copied to LDS by the kernels that read it
-  const int const_floats = const_floats_full - (use_b ? 256 - kBTwspFloats : 0);
+  const int const_floats = (int)lc.size();
   p->const_floats = const_floats;
   const void* fn;
-  if (use_b) {
+  {
     // weights as 16-byte vectors: [wave][step / 4][lane][step % 4]
     std::vector<float> mel_a4(mel_a.size());
     for (int w = 0; w < 4; ++w)
@@ -517,10 +503,6 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
       fn = nrows == 10 ? fft512b_entry<10, 2>() : (nrows == 13 ? fft512b_entry<13, 2>() : fft512b_entry<16, 2>());
     else
       fn = nrows == 10 ? fft512b_entry<10, 0>() : (nrows == 13 ? fft512b_entry<13, 0>() : fft512b_entry<16, 0>());
-  } else {
-    p->xs_floats = (15 * shift + 32 * nrows + 3) & ~3;
-    p->fast_lds_bytes = (size_t)(p->xs_floats + const_floats + 4 * kWaveRegion) * sizeof(float);
-    fn = nrows == 10 ? fft512_entry<10>() : (nrows == 13 ? fft512_entry<13>() : fft512_entry<16>());
   }
   if (p->fast_lds_bytes > 160 * 1024) return HIPFEAT_OK;
   hipError_t e = ensure_dynamic_lds(fn, p->fast_lds_bytes);
@@ -529,13 +511,10 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, p->fast_lds_bytes) == hipSuccess) p->blocks_per_cu = nb;
   char nm[96];
   // same spelling as the device symbol rocprofv3 reports (modulo the space after the comma)
-  if (use_b)
-    snprintf(nm, sizeof(nm), "fft512b_kernel<%d,%d> %s lds=%zuB blocks/CU=%d", nrows, p->fast_out,
-             mfcc ? "mfcc" : (spec ? "spectrogram" : "fbank"), p->fast_lds_bytes, p->blocks_per_cu);
-  else
-    snprintf(nm, sizeof(nm), "fft512_fbank_kernel<%d> fbank lds=%zuB blocks/CU=%d", nrows, p->fast_lds_bytes, p->blocks_per_cu);
+  snprintf(nm, sizeof(nm), "fft512b_kernel<%d,%d> %s lds=%zuB blocks/CU=%d", nrows, p->fast_out,
+           mfcc ? "mfcc" : (spec ? "spectrogram" : "fbank"), p->fast_lds_bytes, p->blocks_per_cu);
   p->kernel_name = nm;
-  p->variant = use_b ? 2 : 1;
+  p->variant = 2;
   p->fpb = kTileFrames * p->tiles_per_block;
   return HIPFEAT_OK;
 }
@@ -554,7 +533,7 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
   const bool mfcc = c.kind == HIPFEAT_MFCC;
   const bool spec = c.kind == HIPFEAT_SPECTROGRAM || c.kind == HIPFEAT_LOG_SPECTROGRAM;
   if (c.kind > HIPFEAT_MFCC || c.fft_length != 256 || (shift & 1) || N < 16 || c.use_energy || (!spec && c.use_fft_mag) ||
-      getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_FAST"))
+      getenv("HIPFEAT_FORCE_GENERIC"))
     return HIPFEAT_OK;
   if (mfcc && (M > 8 * kMaxDctGroups || c.num_ceps > 64)) return HIPFEAT_OK;
   const int need = (N + 15) / 16;
@@ -605,7 +584,6 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
   if ((st = upload(&p->d_mel_a4, mel_a4.data(), mel_a4.size())) != HIPFEAT_OK) return st;
   p->nrows = nrows;
   p->tiles_per_block = 16;  // 512 frames per workgroup (measured: 8 -> 3.84 M, 16 -> 3.99 M, 32 -> 3.93 M cuts/s at 8 kHz fbank-80)
-  if (const char* tpb = getenv("HIPFEAT_TILES_PER_BLOCK")) p->tiles_per_block = std::max(1, atoi(tpb));
   p->const_floats = const_floats;
   p->xs_floats = ((k256TileFrames - 1) * shift + 16 * nrows + 255) & ~255;  // whole 1 KiB LDS-DMA chunks
   size_t lds_floats = (size_t)p->xs_floats + const_floats + 4 * k256WaveRegion;
@@ -619,7 +597,6 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
     p->fast_mfcc = true;
   }
   p->fast_lds_bytes = lds_floats * sizeof(float);
-  if (const char* pad = getenv("HIPFEAT_LDS_PAD")) p->fast_lds_bytes += (size_t)atoi(pad);  // occupancy experiments
   p->fast_out = mfcc ? 1 : (spec ? 2 : 0);
   if (p->fast_lds_bytes > 64 * 1024) return HIPFEAT_OK;  // keep at least two workgroups per CU; otherwise the generic kernel
   const void* fn;
@@ -709,7 +686,6 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
   p->kernel_name = nm;
   p->variant = 5;
   p->fpb = 32;  // 4 waves x 8 frames (the tables copied to LDS per workgroup are ~12 KB)
-  if (const char* f = getenv("HIPFEAT_WAVE_FPW")) p->fpb = 4 * std::max(1, atoi(f));  // experiments
   return HIPFEAT_OK;
 }
 
@@ -719,7 +695,7 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
 static hipfeat_status setup_whisper2(hipfeat_plan* p, const float* h_mel) {
   const hipfeat_config& c = p->cfg;
   if (c.kind != HIPFEAT_WHISPER || c.frame_length != kW2N || c.frame_shift != kW2Shift || c.num_filters > 16 * kW2MaxMelTiles ||
-      getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_WHISPER_V1"))
+      getenv("HIPFEAT_FORCE_GENERIC"))
     return HIPFEAT_OK;
   const int M = c.num_filters, nmt = (M + 15) / 16;
   std::vector<float> cs(288);
@@ -792,86 +768,6 @@ static hipfeat_status setup_whisper2(hipfeat_plan* p, const float* h_mel) {
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&whisper2_kernel), 256, 0) == hipSuccess) p->blocks_per_cu = nb;
   char buf[160];
   snprintf(buf, sizeof(buf), "whisper_kernel2 fft400=16x25 mel_chunks=%d+%d+%d+%d blocks/CU=%d", load[0], load[1], load[2], load[3], p->blocks_per_cu);
-  p->kernel_name = buf;
-  return HIPFEAT_OK;
-}
-
-// --------------------------------------------------------------------------------------
-// whisper fast path: DFT-400 and mel operands in MFMA lane order (kernel_whisper.hpp)
-// --------------------------------------------------------------------------------------
-static hipfeat_status setup_whisper(hipfeat_plan* p, const float* h_mel) {
-  const hipfeat_config& c = p->cfg;
-  if (c.kind != HIPFEAT_WHISPER || c.frame_length != kWhN || c.frame_shift != kWhShift || c.num_filters > 16 * kWhMaxMelTiles ||
-      getenv("HIPFEAT_FORCE_GENERIC"))
-    return HIPFEAT_OK;
-  const int M = c.num_filters;
-  const int nmt = (M + 15) / 16;
-  // DFT operands: tile bt < 7: even bins 2m, m = 16 bt + i; bt >= 7: odd bins 2m + 1, m = 16 (bt - 7) + i
-  std::vector<float> dft((size_t)kWhBinTiles * kWhChunks * 256, 0.f);  // [bt][chunk][lane][step & 3]
-  for (int bt = 0; bt < kWhBinTiles; ++bt) {
-    const bool odd = bt >= 7;
-    for (int s = 0; s < kWhSteps; ++s)
-      for (int l = 0; l < 64; ++l) {
-        const int i = l & 15, g = l >> 4;
-        const int m = 16 * (odd ? bt - 7 : bt) + i;
-        if (m > (odd ? 99 : 100)) continue;
-        const bool sine = s >= kWhCosSteps;
-        const int kk = 4 * (sine ? s - kWhCosSteps : s) + g;
-        const int n = sine ? kk + 1 : kk;
-        double v = 0.0;
-        if (!odd) {
-          const double th = 2.0 * M_PI * (double)((int64_t)m * n % 200) / 200.0;
-          if (!sine && kk <= 100) v = std::cos(th);
-          if (sine && n <= 99) v = -std::sin(th);
-        } else {
-          const double th = 2.0 * M_PI * (double)((int64_t)n * (2 * m + 1) % 400) / 400.0;
-          if (!sine && kk <= 99) v = std::cos(th);
-          if (sine && n <= 100) v = -std::sin(th);
-        }
-        dft[(((size_t)bt * kWhChunks + (s >> 2)) * 64 + l) * 4 + (s & 3)] = (float)v;
-      }
-  }
-  // mel operands for the (bin tile, mel tile) pairs with non-zero weights; k-step r covers accumulator rows 4 g + r
-  auto bin_of = [](int bt, int j) { return bt < 7 ? 2 * (16 * bt + j) : 2 * (16 * (bt - 7) + j) + 1; };
-  std::vector<float> mel((size_t)kWhBinTiles * kWhSlots * 256, 0.f);
-  int pairs = 0;
-  for (int bt = 0; bt < kWhBinTiles; ++bt) {
-    int lo = nmt, hi = -1;
-    for (int mt = 0; mt < nmt; ++mt) {
-      bool any = false;
-      for (int j = 0; j < 16 && !any; ++j)
-        for (int i = 0; i < 16 && !any; ++i) {
-          const int bin = bin_of(bt, j), m = 16 * mt + i;
-          any = bin <= 200 && m < M && h_mel[(size_t)bin * M + m] != 0.0f;
-        }
-      if (any) {
-        lo = std::min(lo, mt);
-        hi = std::max(hi, mt);
-      }
-    }
-    if (hi < 0) lo = 0;
-    const int cnt = hi < 0 ? 0 : hi - lo + 1;
-    if (cnt > kWhSlots) return HIPFEAT_OK;  // filterbank too dense for the static schedule: generic kernel
-    p->wh_mt_lo[bt] = lo;
-    p->wh_mt_cnt[bt] = cnt;
-    pairs += cnt;
-    for (int sl = 0; sl < cnt; ++sl)
-      for (int r = 0; r < 4; ++r)
-        for (int l = 0; l < 64; ++l) {
-          const int i = l & 15, g = l >> 4;
-          const int bin = bin_of(bt, 4 * g + r), m = 16 * (lo + sl) + i;
-          mel[(((size_t)bt * kWhSlots + sl) * 64 + l) * 4 + r] = (bin <= 200 && m < M) ? h_mel[(size_t)bin * M + m] : 0.f;
-        }
-  }
-  hipfeat_status st;
-  if ((st = upload(&p->d_wh_dft, dft.data(), dft.size())) != HIPFEAT_OK) return st;
-  if ((st = upload(&p->d_wh_mel, mel.data(), mel.size())) != HIPFEAT_OK) return st;
-  p->wh_mel_tiles = nmt <= 5 ? 5 : 8;
-  p->variant = 3;
-  p->fpb = 16 * kWhTilesPerBlock;
-  char buf[160];
-  snprintf(buf, sizeof(buf), "whisper_kernel<%d> dft400-as-mfma-gemm lds=%dB mel_pairs=%d", p->wh_mel_tiles,
-           (int)((16 * kWhRowStride + kWhSpanChunks * 256) * sizeof(float)), pairs);
   p->kernel_name = buf;
   return HIPFEAT_OK;
 }
@@ -986,7 +882,6 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   };
   {
     size_t cap = 21 * 1024;
-    if (const char* kb = getenv("HIPFEAT_GENERIC_LDS_KB")) cap = (size_t)std::max(8, atoi(kb)) * 1024;  // experiments
     int pick = 0;
     for (int fpb = 8; fpb >= 2 && !pick; fpb >>= 1)
       if (carve(fpb) <= cap) pick = fpb;
@@ -1000,8 +895,6 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   st = setup_fft512(p, h_window, h_mel, h_dct, h_lifter);
   if (st != HIPFEAT_OK) return bail(st);
   st = setup_whisper2(p, h_mel);
-  if (st != HIPFEAT_OK) return bail(st);
-  if (p->variant == 0) st = setup_whisper(p, h_mel);
   if (st != HIPFEAT_OK) return bail(st);
   st = setup_fft256(p, h_window, h_mel, h_dct, h_lifter);
   if (st != HIPFEAT_OK) return bail(st);
@@ -1173,9 +1066,9 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     wp.log_energy_floor = c.energy_floor > 0.0f ? logf(c.energy_floor) : -INFINITY;
     wp.mel_floor = c.mel_floor;
     wp.log_offset = c.log_offset;
-    if (const char* ab = getenv("HIPFEAT_WAVE_ABLATE")) wp.ablate = atoi(ab);
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(256);
+    set_lds_poison(plan->wave_lds_bytes);
     switch (plan->H >> 6) {
       case 4: hipLaunchKernelGGL(wave_kernel<4>, grid, block, plan->wave_lds_bytes, stream, wp); break;
       case 8: hipLaunchKernelGGL(wave_kernel<8>, grid, block, plan->wave_lds_bytes, stream, wp); break;
@@ -1199,38 +1092,8 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     wp.M = c.num_filters;
     wp.mel_floor = c.mel_floor;
     wp.sched = plan->d_wh2_sched;
-    if (const char* ab = getenv("HIPFEAT_W2_ABLATE")) wp.ablate = atoi(ab);
     DeviceGuard g(plan->device);
     hipLaunchKernelGGL(whisper2_kernel, dim3((unsigned)lay->total_blocks), dim3(256), 0, stream, wp);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)lay->batch), dim3(1024), 0, stream, lay->d_cuts, d_out, lay->out_row_stride,
-                       (int32_t)c.num_filters, (int32_t)c.frame_shift);
-    HIP_TRY(hipGetLastError());
-    return HIPFEAT_OK;
-  }
-  if (plan->variant == 3) {
-    WhisperParams wp{};
-    wp.wave = d_wave;
-    wp.out = d_out;
-    wp.cuts = lay->d_cuts;
-    wp.window = plan->d_window;
-    wp.dft_a = plan->d_wh_dft;
-    wp.mel_a = plan->d_wh_mel;
-    wp.out_stride = lay->out_row_stride;
-    wp.num_cuts = (int32_t)lay->batch;
-    wp.uniform_bpc = lay->uniform_bpc;
-    wp.shift = c.frame_shift;
-    wp.M = c.num_filters;
-    wp.mel_floor = c.mel_floor;
-    if (const char* ab = getenv("HIPFEAT_WH_ABLATE")) wp.ablate = atoi(ab);
-    for (int i = 0; i < kWhBinTiles; ++i) {
-      wp.mt_lo[i] = plan->wh_mt_lo[i];
-      wp.mt_cnt[i] = plan->wh_mt_cnt[i];
-    }
-    DeviceGuard g(plan->device);
-    const dim3 grid((unsigned)lay->total_blocks), block(128);
-    if (plan->wh_mel_tiles == 5) hipLaunchKernelGGL(whisper_kernel<5>, grid, block, 0, stream, wp);
-    else hipLaunchKernelGGL(whisper_kernel<8>, grid, block, 0, stream, wp);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)lay->batch), dim3(1024), 0, stream, lay->d_cuts, d_out, lay->out_row_stride,
                        (int32_t)c.num_filters, (int32_t)c.frame_shift);
@@ -1261,19 +1124,20 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.xs_floats = plan->c_xs_floats;
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(64 * kCWaves);
+    set_lds_poison(plan->fast_lds_bytes);
     if (plan->nrows == 10) hipLaunchKernelGGL(fft512c_kernel<10>, grid, block, plan->fast_lds_bytes, stream, fp);
     else if (plan->nrows == 13) hipLaunchKernelGGL(fft512c_kernel<13>, grid, block, plan->fast_lds_bytes, stream, fp);
     else hipLaunchKernelGGL(fft512c_kernel<16>, grid, block, plan->fast_lds_bytes, stream, fp);
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }
-  if (plan->variant == 1 || plan->variant == 2 || plan->variant == 4) {
+  if (plan->variant == 2 || plan->variant == 4) {
     Fft512Params fp{};
     fp.wave = d_wave;
     fp.out = d_out;
     fp.cuts = lay->d_cuts;
     fp.lds_consts = plan->d_lds_consts;
-    fp.mel_a = plan->variant == 1 ? plan->d_mel_a : plan->d_mel_a4;
+    fp.mel_a = plan->d_mel_a4;
     fp.work = plan->d_work;
     fp.out_stride = lay->out_row_stride;
     fp.num_cuts = (int32_t)lay->batch;
@@ -1296,6 +1160,7 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.dct_floats = plan->dct_floats;
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(256);
+    set_lds_poison(plan->fast_lds_bytes);
     if (plan->variant == 4) {
 #define HF_LAUNCH_256(NR, OUT) hipLaunchKernelGGL((fft256_kernel<NR, OUT>), grid, block, plan->fast_lds_bytes, stream, fp)
       if (plan->nrows == 13) {
@@ -1321,12 +1186,7 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
       else HF_LAUNCH_NR(0);
 #undef HF_LAUNCH_NR
 #undef HF_LAUNCH_B
-    } else if (plan->nrows == 10)
-      hipLaunchKernelGGL(fft512_fbank_kernel<10>, grid, block, plan->fast_lds_bytes, stream, fp);
-    else if (plan->nrows == 13)
-      hipLaunchKernelGGL(fft512_fbank_kernel<13>, grid, block, plan->fast_lds_bytes, stream, fp);
-    else
-      hipLaunchKernelGGL(fft512_fbank_kernel<16>, grid, block, plan->fast_lds_bytes, stream, fp);
+    }
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }
@@ -1368,6 +1228,7 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
   gp.off_stat = plan->off_stat;
   gp.off_mel = plan->off_mel;
   DeviceGuard g(plan->device);
+  set_lds_poison(plan->lds_bytes);
   hipLaunchKernelGGL(generic_kernel, dim3((unsigned)lay->total_blocks), dim3(256), plan->lds_bytes, stream, gp);
   HIP_TRY(hipGetLastError());
   if (whisper) {
@@ -1643,7 +1504,6 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_specaug(const float* d_in, float* 
     }
   }
   int tile_elems = 8192;
-  if (const char* t = getenv("HIPFEAT_SPECAUG_TILE")) tile_elems = std::max(256, atoi(t));  // experiments
   const int rows_per_tile = std::max(1, std::min(T, tile_elems / std::max(F, 1)));
   const int tiles = (T + rows_per_tile - 1) / rows_per_tile;
   auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };

@@ -16,7 +16,7 @@
 #pragma once
 #include "common.hpp"
 #include "fft_common.hpp"
-#include "kernel_fft512.hpp"   // Fft512Params, WaveWork, kMaxGroups*, kMelARegs
+#include "fft512_common.hpp"   // Fft512Params, WaveWork, kMaxGroups*, kMelARegs
 #include "kernel_fft512b.hpp"  // kBMelVec, kMaxDctGroups
 
 namespace hipfeat {
@@ -46,6 +46,7 @@ template <int NROWS, int OUT>
 __global__ __launch_bounds__(256, 5) void fft256_kernel(const Fft512Params p) {
   constexpr bool MFCC = OUT == 1, SPEC = OUT == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  HF_POISON_LDS(smem);
   float* xs = smem;
   const v2* cwin = reinterpret_cast<const v2*>(smem + p.xs_floats);  // [NROWS][8]
   const v2* ctwp = cwin + NROWS * 8;                                 // [16][8] row k1, column q: W_128^(q k1)

@@ -1,75 +1,46 @@
-// fft512 fast path, occupancy-oriented variant ("b"): same arithmetic as kernel_fft512.hpp, organised so
-// that FOUR workgroups (16 waves) fit a CU.  Measured on MI355X (tools/ubench): one wave can issue a VALU
-// instruction only every ~5 clk while the SIMD accepts one every 2-3 clk, so the f32 FFT work needs >= 2
-// waves per SIMD inside their arithmetic phase at any time; the cheapest way there is more resident waves.
-//
-// What changes against kernel_fft512.hpp
-//   * nothing persistent in VGPRs besides addresses: the mel filter weights (MFMA A operands) are
-//     re-fetched from L2 with 9 x 16-byte loads per wave at the start of every S5 (they are only live
-//     there, where the FFT registers are dead);
-//   * the next tile's sample span is written straight into LDS by global_load_lds_dwordx4 (LDS-DMA)
-//     during S5, when the span buffer is dead -- no prefetch registers, no second buffer;
-//   * the FFT exchange runs in two halves (rows 0-7, then 8-15) through a 4.6 KB wave region;
-//   => <= 128 VGPRs and 35.8 KB LDS per workgroup.
+// fft512 fast path with 16-frame tiles ("b"): MFCC (DCT as a second matrix-core GEMM), (log-)spectrogram, and log-mel
+// filterbanks outside the static schedule of the wave-autonomous kernel (kernel_fft512c.hpp).  Workgroup = 4 waves, tile = 16
+// consecutive frames of one cut, FOUR workgroups (16 waves) per CU:
+//   S1  the tile's sample span (15 shift + N floats) goes HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), requested one phase
+//       ahead (during S5 of the previous tile, when the span buffer is dead); tiles touching a cut edge use per-lane loads
+//       through the reflect / zero-pad rule;
+//   S3  one frame per 16-lane group: DC removal, pre-emphasis, window, real FFT(512) = complex FFT(256) = 16 x 16 in registers
+//       (packed (re, im) VGPR pairs), exchange in two halves through a 4.6 KB wave-private LDS region, split step on bin pairs
+//       with the mirror operand fetched by DPP, |X|^2 -> LDS power tile P[16][260];
+//   S5  mel = banded f32 GEMM on the matrix cores (v_mfma_f32_16x16x4_f32) over each 16-mel tile's non-zero band only; the
+//       wave's filter weights (A operands) are re-fetched from L2 before the barrier; log epilogue, 16-byte stores;
+//   S6  (MFCC) cepstra = DCT^T x log-mel as a second, dense but tiny MFMA GEMM from LDS, lifter, stores.
+// <= 128 VGPRs and 34.7 KB LDS per workgroup.
 #pragma once
 #include "common.hpp"
 #include "fft_common.hpp"
-#include "kernel_fft512.hpp"  // Fft512Params, WaveWork, tile constants
+#include "fft512_common.hpp"  // Fft512Params, WaveWork, tile constants
 
 namespace hipfeat {
 
-#ifndef HIPFEAT_B5
-#define HIPFEAT_B5 0  // experiment: 32.6 KB / <= 96 VGPRs -> FIVE workgroups per CU (exchange in quarters, no twsp table)
-#endif
 constexpr int kBExRowStride = 34;                        // dwords per exchange row (16 complex + 2 pad)
-#if HIPFEAT_B5
-constexpr int kBExParts = 4;                             // the exchange runs in quarters (4 rows at a time)
-constexpr int kBExFrameStride = 4 * kBExRowStride + 8;   // 144 (== 16 mod 64)
-constexpr int kBWaveRegion = 4 * kPRowStride;            // 1040 dwords per wave: the power rows; 4 x 144 exchange fits inside
-constexpr int kBTwspFloats = 0;                          // (-w.y, w.x) is derived from w with one packed multiply
-#else
 constexpr int kBExParts = 2;
 constexpr int kBExFrameStride = 8 * kBExRowStride + 16;  // 288 (== 32 mod 64): 8 rows per half
 constexpr int kBWaveRegion = 4 * kBExFrameStride + 16;   // 1168 dwords per wave (== 16 mod 64)
-constexpr int kBTwspFloats = 256;
-#endif
 constexpr int kBMelVec = kMelARegs / 4;                  // 16-byte loads of filter weights per lane per tile
 
-#ifndef HIPFEAT_S5_PRIO
-#define HIPFEAT_S5_PRIO 1  // waves in the short MFMA/epilogue phase go first: +1.4 % (measured)
-#endif
-#ifndef HIPFEAT_FFT512B_WAVES_PER_SIMD
-#define HIPFEAT_FFT512B_WAVES_PER_SIMD 4
-#endif
 
 constexpr int kMaxDctGroups = 10;
-#ifdef HF_X_LDS1
-#define HF_SEP() asm volatile("")
-#else
-#define HF_SEP()
-#endif
-#ifndef HF_X_ABL
-#define HF_X_ABL 0
-#endif
-#ifdef HF_X_CMUL
-#define HF_CMUL cmul2
-#else
-#define HF_CMUL cmul
-#endif  // 8-mel groups of the DCT GEMM (num_filters <= 80)
+#define HF_SEP() asm volatile("")  // keeps hipcc from merging two ds_read_b64 into one half-rate ds_read2_b64 (tools/ubench/lds_rate.hip)
 
 // OUT = 0: log-mel filterbank (Wav2LogFilterBank).  OUT = 1: MFCC -- the log-mel tile goes to LDS instead of
 // HBM and a second (dense, tiny) MFMA GEMM applies the DCT (layers.py:716), then the lifter (:717-718).
 // OUT = 2: (log-)spectrogram (Wav2Spec / Wav2LogSpec, layers.py:392-402, :461-473) -- every wave streams the
 // power rows of its own four frames from LDS to HBM; no matrix-core stage.
 template <int NROWS, int OUT>
-__global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_kernel(const Fft512Params p) {
+__global__ __launch_bounds__(256, 4) void fft512b_kernel(const Fft512Params p) {
   constexpr bool MFCC = OUT == 1, SPEC = OUT == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  HF_POISON_LDS(smem);
   float* xs = smem;
   const v2* cwin = reinterpret_cast<const v2*>(smem + p.xs_floats);  // [NROWS][16]
   const v2* ctwp = cwin + NROWS * 16;                                // [16][16] row k1, column q
   const v2* ctws = ctwp + 256;                                       // [8][16] w = -i W_512^(q+16 k2)
-  const v2* ctwsp = ctws + 128;                                      // [8][16] (-w.y, w.x)
   float* regions = smem + p.xs_floats + p.const_floats;
 
   const int tid = threadIdx.x;
@@ -147,9 +118,6 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
     float* myreg = regions + wv * kBWaveRegion;
 
     // ---- S3 ---------------------------------------------------------------------------------
-#if (defined(HIPFEAT_ABLATE) && (HIPFEAT_ABLATE & 2)) || (HF_X_ABL & 2)
-    if (p.N < 0)  // experiment builds only: the phase is compiled but skipped at run time
-#endif
     {
       const float* x = xs + (4 * wv + g) * shift + 2 * q;
       v2 z[16];
@@ -169,24 +137,10 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
           if (m0 + 1 >= N) z[n1].y = 0.f;
         }
       }
-#if HF_X_ABL & 4
-#pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) z[n1] = z[n1] * win[n1];
-#else
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) sum2 += z[n1];
       float mu = 0.f;
       if (dc) mu = row16_sum(sum2.x + sum2.y) * inv_n;
-#if HIPFEAT_B5
-      // previous sample of the first element of each pair, read from the span (the very first sample of the frame
-      // replicates itself, layers.py:166): no cross-lane chain, fewer live registers
-#pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) {
-        const float pvs = n1 == 0 ? x[q == 0 ? 0 : -1] : x[32 * n1 - 1];
-        const v2 d = z[n1] - v2{mu, mu};
-        z[n1] = (d - v2{c, c} * v2{pvs - mu, d.x}) * win[n1];
-      }
-#else
       // previous sample of the first element of each pair: lane q-1's second element; for lane 0 it is
       // lane 15's second element of the previous row (fetched one row earlier with row_ror:1), and the
       // very first sample of the frame replicates itself (layers.py:166)
@@ -198,17 +152,10 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         if (n1 + 1 < NROWS) wrap = dpp_mov<DPP_ROW_ROR1>(d.y);
         z[n1] = (d - v2{c, c} * v2{dp, d.x}) * win[n1];
       }
-#endif
-#endif
 #pragma unroll
       for (int n1 = NROWS; n1 < 16; ++n1) z[n1] = v2{0.f, 0.f};
       v2 a[16];
-#if HF_X_ABL & 32
-#pragma unroll
-      for (int i = 0; i < 16; ++i) a[i] = z[i];
-#else
       fft16(z, a);
-#endif
       // pass twiddles W_256^(q k1): fetched from LDS in two bursts of 8 (one latency exposure each)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -216,7 +163,7 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
 #pragma unroll
         for (int r = 0; r < 8; ++r) { tw[r] = ctwp[(8 * h + r) * 16 + q]; HF_SEP(); }
 #pragma unroll
-        for (int r = (h == 0 ? 1 : 0); r < 8; ++r) a[8 * h + r] = HF_CMUL(a[8 * h + r], tw[r]);
+        for (int r = (h == 0 ? 1 : 0); r < 8; ++r) a[8 * h + r] = cmul2(a[8 * h + r], tw[r]);
       }
 
       // exchange in two halves: rows k1 = 8h .. 8h+7 go through an 8-row block; lanes with
@@ -224,11 +171,6 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
       float* exf = myreg + g * kBExFrameStride;
       v2 b[16];
       constexpr int RPP = 16 / kBExParts;  // rows per part
-#if HF_X_ABL & 16
-#pragma unroll
-      for (int i = 0; i < 16; ++i) b[i] = a[i];
-      if (p.N < 0)
-#endif
 #pragma unroll
       for (int h = 0; h < kBExParts; ++h) {
 #pragma unroll
@@ -244,26 +186,12 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         __builtin_amdgcn_wave_barrier();
       }
       v2 Z[16];
-#if HF_X_ABL & 64
-#pragma unroll
-      for (int i = 0; i < 16; ++i) Z[i] = b[i];
-#else
       fft16(b, Z);
-#endif
 
       float* prow = myreg + g * kPRowStride;
       float* pown = prow + q;
       float* ppar = prow + ((16 - q) & 15) + (q == 0 ? 16 : 0);
       if (q < 3) prow[257 + q] = 0.f;
-#if HF_X_ABL & 8
-#pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) {
-        pown[16 * k2] = Z[k2].x * Z[k2].x + Z[k2].y * Z[k2].y;
-        ppar[16 * (15 - k2)] = Z[15 - k2].x * Z[15 - k2].x + Z[15 - k2].y * Z[15 - k2].y;
-      }
-      if (p.N < 0) {
-#endif
-#if !HIPFEAT_B5
       float t1[16];
 #pragma unroll
       for (int k2 = 0; k2 < 8; ++k2) {
@@ -277,47 +205,26 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         t1[2 * k2] = dpp_shr1_keep(Z[(16 - k2) & 15].x, t1[2 * k2]);
         t1[2 * k2 + 1] = dpp_shr1_keep(Z[(16 - k2) & 15].y, t1[2 * k2 + 1]);
       }
-#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        v2 tw[4], twq[4];  // split-step twiddles of 4 bin pairs per burst
+        v2 tw[4];  // split-step twiddles of 4 bin pairs per burst
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           tw[r] = ctws[(4 * h + r) * 16 + q];
           HF_SEP();
-#if defined(HF_X_CMUL)
-          twq[r] = tw[r];
-#elif HIPFEAT_B5
-          twq[r] = swap2(tw[r] * HF_CJ);  // (-w.y, w.x)
-#else
-          twq[r] = ctwsp[(4 * h + r) * 16 + q];
-          HF_SEP();
-#endif
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k2 = 4 * h + r;
-#if HIPFEAT_B5
-          const v2 m = v2{dpp_shr1_keep(Z[(16 - k2) & 15].x, dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].x)),
-                          dpp_shr1_keep(Z[(16 - k2) & 15].y, dpp_mov<DPP_ROW_MIRROR>(Z[15 - k2].y))};
-#else
           const v2 m = v2{t1[2 * k2], t1[2 * k2 + 1]};
-#endif
           const v2 sp = m * HF_CJ + Z[k2];
           const v2 dm = m * HF_NCJ + Z[k2];
-#ifdef HF_X_CMUL
           const v2 tt = cmul2(dm, tw[r]);
-#else
-          const v2 tt = cmulc(dm, tw[r], twq[r]);
-#endif
           const v2 xp = sp + tt, xm = sp - tt;
           pown[16 * k2] = xp.x * xp.x + xp.y * xp.y;
           ppar[16 * (15 - k2)] = xm.x * xm.x + xm.y * xm.y;
         }
       }
-#if HF_X_ABL & 8
-      }
-#endif
       if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
     }
     // the filter weights of this wave's band: requested now (the FFT registers are dead), so the L2
@@ -332,9 +239,7 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
     HF_T(4);
 
     // ---- S5 ---------------------------------------------------------------------------------
-#ifdef HIPFEAT_S5_PRIO
-    __builtin_amdgcn_s_setprio(HIPFEAT_S5_PRIO);
-#endif
+    __builtin_amdgcn_s_setprio(1);  // waves in the short MFMA/epilogue phase go first: +1.4 % (measured)
     if (SPEC) {
       {
         const int fn = f0 + kTileFrames;
@@ -368,24 +273,12 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
 #pragma unroll
         for (int i = 0; i < CH; ++i) { pv[ci][i] = *reinterpret_cast<const v2*>(pb + min(ww.bin0 + 8 * (ci * CH + i), kPRowStride - 8)); HF_SEP(); }
       };
-#ifdef HF_X_ALLP
-#pragma unroll
-      for (int ci = 0; ci < NCH; ++ci) load_chunk(ci);
-      v2 pv1[kMaxGroups1];
-#pragma unroll
-      for (int gi = 0; gi < kMaxGroups1; ++gi) { pv1[gi] = *reinterpret_cast<const v2*>(pb + min(ww.bin1 + 8 * gi, kPRowStride - 8)); HF_SEP(); }
-#else
       load_chunk(0);
-#endif
       // gfx950 has ONE in-order counter for all vector-memory operations: take delivery of the weights
       // (requested before the barrier) BEFORE the span DMA is issued, otherwise their first use would
       // have to wait for the much slower HBM transfer queued behind them.
 #pragma unroll
       for (int i = 0; i < kBMelVec; ++i) asm volatile("" : "+v"(ma[i]));
-#ifdef HIPFEAT_PHASE_TIMERS3
-      const unsigned long long v0 = __builtin_readcyclecounter();
-      hf_acc[6] += v0 - t4;  // weights wait
-#endif
       // xs is dead until the next tile: stage the next span now (lands during the mel GEMM)
       {
         const int fn = f0 + kTileFrames;
@@ -414,17 +307,11 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         }
       };
       auto wgt = [&](int step) -> float { return ma[step >> 2][step & 3]; };
-#if (defined(HIPFEAT_ABLATE) && (HIPFEAT_ABLATE & 1)) || (HF_X_ABL & 1)
-      if (p.N < 0) {
-#else
       if (ww.ngroups0 > 0) {
-#endif
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ci = 0; ci < NCH; ++ci) {
-#ifndef HF_X_ALLP
           if (ci + 1 < NCH) load_chunk(ci + 1);
-#endif
           if (ci * CH < ww.ngroups0) {
 #pragma unroll
             for (int i = 0; i < CH; ++i)
@@ -434,21 +321,12 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
               }
           }
         }
-#ifdef HIPFEAT_PHASE_TIMERS3
-        asm volatile("" : "+v"(acc), "+v"(acc2));
-        const unsigned long long v1 = __builtin_readcyclecounter();
-        hf_acc[7] += v1 - v0;  // DMA issue + P reads + MFMA chain of segment 0
-#endif
         epilogue(acc + acc2, ww.tile0);
       }
-      if (ww.ngroups1 > 0 && !((HF_X_ABL & 1) && p.N >= 0)) {
-#ifdef HF_X_ALLP
-        v2 (&pv)[kMaxGroups1] = pv1;
-#else
+      if (ww.ngroups1 > 0) {
         v2 pv[kMaxGroups1];
 #pragma unroll
         for (int gi = 0; gi < kMaxGroups1; ++gi) pv[gi] = *reinterpret_cast<const v2*>(pb + min(ww.bin1 + 8 * gi, kPRowStride - 8));
-#endif
         f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int gi = 0; gi < kMaxGroups1; ++gi) {
@@ -493,9 +371,7 @@ __global__ __launch_bounds__(256, HIPFEAT_FFT512B_WAVES_PER_SIMD) void fft512b_k
         }
       }
     }
-#ifdef HIPFEAT_S5_PRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
     HF_T(5);
     HF_ACC(0, t0, t1);  // wait for DMA / stores (vmcnt)
     HF_ACC(1, t1, t2);  // barrier 1

@@ -41,7 +41,7 @@ struct Fft512cParams {
   const CutDesc* cuts;
   // shared LDS image, copied once per workgroup: [nrows][16] v2 window/2 | [16][16] v2 W_256^(q k1) | [8][16] v2 -i W_512^(q+16 k2)
   // | weight table [2 sets][16 steps / 4][64 lanes][4 steps] (zero beyond a set's steps) | lane table [2 sets][64 lanes][4]
-  // (power-row offset (int), output column (int, -1 = none), m4, m8)
+  // (power-row offset (int), output column (int, >= M = none), m4, m8)
   const float* shared_consts;
   int64_t out_stride;
   int32_t num_cuts, uniform_bpc;
@@ -53,11 +53,19 @@ struct Fft512cParams {
   int32_t xs_floats;      // floats of one wave's sample-span buffer (multiple of 4)
 };
 
-#define HFC_SEP() asm volatile("")  // keeps hipcc from merging two ds_read_b64 into one (half-rate) ds_read2_b64
+#ifdef HIPFEAT_PHASE_TIMERS
+#define HFC_T(i) { const unsigned long long tt_ = __builtin_readcyclecounter(); hfc_acc[i] += tt_ - hfc_last; hfc_last = tt_; }
+#else
+#define HFC_T(i)
+#endif
+#define HFC_SEP() asm volatile("")
+// lane-index multiplies: v_mul_u32_u24 issues at the full VALU rate, v_mul_lo_u32 at a quarter of it
+__device__ __forceinline__ int mul24(int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); }
 
 template <int NROWS>
 __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  HF_POISON_LDS(smem);
   const v2* cwin = reinterpret_cast<const v2*>(smem);  // [NROWS][16]
   const v2* ctwp = cwin + NROWS * 16;                  // [16][16] row k1, column q
   const v2* ctws = ctwp + 256;                         // [8][16] w = -i W_512^(q+16 k2)
@@ -88,7 +96,6 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
   const bool dc = (p.flags & F_REMOVE_DC) != 0;
   const float inv_n = 1.0f / (float)N;
   const float c = p.preemph;
-  const int nchunks = (p.xs_floats + 255) >> 8;  // 1 KiB LDS-DMA pieces covering the span buffer
 
   // Stage the span of the four frames starting at f0 into this wave's buffer.  Interior rounds: LDS-DMA (lane i supplies
   // the global address of its 16 bytes, the hardware writes piece base + 16 i).  Rounds touching a cut edge (reflection,
@@ -97,27 +104,40 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
     const int64_t j0 = (int64_t)f0 * shift - p.npad_left;
     if (j0 >= 0 && j0 + p.xs_floats <= cd.num_samples) {
       const char* src = reinterpret_cast<const char*>(w + j0);  // uniform
-      for (int ch = 0; ch < nchunks; ++ch)
-        if ((unsigned)ch * 256u + lane4 < (unsigned)p.xs_floats)
+      // whole 1 KiB pieces without a lane mask, then the (shorter) last piece: straight-line code, one exec mask
+      const int nfull = p.xs_floats >> 8;
+#pragma unroll
+      for (int ch = 0; ch < 6; ++ch) {
+        if (ch < nfull)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)ch * 1024u + 4u * lane4)),
                                            (__attribute__((address_space(3))) void*)(xs + ch * 256), 16, 0, 0);
+      }
+      if ((unsigned)nfull * 256u + lane4 < (unsigned)p.xs_floats)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)nfull * 1024u + 4u * lane4)),
+                                         (__attribute__((address_space(3))) void*)(xs + nfull * 256), 16, 0, 0);
     } else {
       for (int i = (int)(lane4 >> 2); i < span; i += 64) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
     }
   };
 
-  const int first_frame = fb * p.frames_per_block + wv * p.rounds * 4;
+  // the waves of a workgroup take the frame quads round-robin, so that a short cut still spreads over all of them
+  const int first_frame = fb * p.frames_per_block + 4 * wv;
   __syncthreads();  // the constant tables are in place (the only workgroup barrier of the kernel)
   if (first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
 
+#ifdef HIPFEAT_PHASE_TIMERS
+  unsigned long long hfc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hfc_last = __builtin_readcyclecounter();
+#endif
   for (int r = 0; r < p.rounds; ++r) {
-    const int f0 = first_frame + 4 * r;
+    const int f0 = first_frame + 4 * kCWaves * r;
     if (f0 >= cd.num_frames) break;
     const int nf = min(4, cd.num_frames - f0);
 
     // this round's span was requested a round ago by this very wave: its own vmcnt covers the LDS-DMA, the in-order LDS
     // queue covers the per-lane stores of an edge round
+    if (r == 0)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    HFC_T(0);  // wait for the span
     // Re-derive every per-lane address inside the loop from an opaque copy of the lane id (LICM would otherwise pin ~25
     // loop-invariant addresses in VGPRs for the whole kernel and cost a wave of occupancy).
     int lane_o = lane;
@@ -126,7 +146,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
 
     v2 Z[16];
     {
-      const float* x = xs + g * shift + 2 * q;
+      const float* x = xs + mul24(g, shift) + 2 * q;
       v2 z[16];
       v2 win[NROWS];
       v2 sum2 = {0.f, 0.f};
@@ -140,9 +160,13 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         win[n1] = cwin[n1 * 16 + q];
         HFC_SEP();
       }
+      float pv[NROWS];  // left neighbour of each pair's first sample (the frame's first sample replicates itself)
+#pragma unroll
+      for (int n1 = 0; n1 < NROWS; ++n1) pv[n1] = n1 == 0 ? x[q == 0 ? 0 : -1] : x[32 * n1 - 1];
       // the samples are in flight to registers; once they have arrived the buffer is free for the next round's span
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (r + 1 < p.rounds && f0 + 4 < cd.num_frames) stage_span(f0 + 4, (unsigned)lane_o * 4u);
+      HFC_T(1);  // sample + window reads
+      if (r + 1 < p.rounds && f0 + 4 * kCWaves < cd.num_frames) stage_span(f0 + 4 * kCWaves, (unsigned)lane_o * 4u);
 
       // samples at or beyond N (the frame length) are not part of the frame (uniform test per row, lane mask only in
       // the boundary rows)
@@ -154,20 +178,31 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
           if (m0 + 1 >= N) z[n1].y = 0.f;
         }
       }
+      {  // four partial sums: the dependent chain is 4 + 2 adds instead of NROWS
+        v2 sa = z[0], sb = z[1], sc = z[2], sd = z[3];
 #pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) sum2 += z[n1];
+        for (int n1 = 4; n1 < NROWS; ++n1) {
+          if ((n1 & 3) == 0) sa += z[n1];
+          if ((n1 & 3) == 1) sb += z[n1];
+          if ((n1 & 3) == 2) sc += z[n1];
+          if ((n1 & 3) == 3) sd += z[n1];
+        }
+        sum2 = (sa + sb) + (sc + sd);
+      }
       float mu = 0.f;
       if (dc) mu = row16_sum(sum2.x + sum2.y) * inv_n;
-      // previous sample of the first element of each pair: lane q-1's second element; for lane 0 it is lane 15's second
-      // element of the previous row (fetched one row earlier with row_ror:1), and the very first sample of the frame
-      // replicates itself (layers.py:166)
-      float wrap = 0.f;
+      // pre-emphasis on the DC-free frame: y[n] = (x[n] - mu) - c (x[n-1] - mu) = x[n] - c x[n-1] - (1 - c) mu, the very first
+      // sample of the frame replicating itself (layers.py:166).  The left neighbour of a pair's first element comes from the
+      // span (one ds_read_b32 per row) instead of a cross-lane DPP chain.
+      {
+        const float nc = -c, mu1 = (1.0f - c) * mu;
 #pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) {
-        const v2 d = z[n1] - v2{mu, mu};
-        const float dp = dpp_shr1_keep(n1 == 0 ? d.x : wrap, d.y);
-        if (n1 + 1 < NROWS) wrap = dpp_mov<DPP_ROW_ROR1>(d.y);
-        z[n1] = (d - v2{c, c} * v2{dp, d.x}) * win[n1];
+        for (int n1 = 0; n1 < NROWS; ++n1) {
+          v2 t;
+          t.x = fmaf(nc, pv[n1], z[n1].x);
+          t.y = fmaf(nc, z[n1].x, z[n1].y);
+          z[n1] = (t - v2{mu1, mu1}) * win[n1];
+        }
       }
 #pragma unroll
       for (int n1 = NROWS; n1 < 16; ++n1) z[n1] = v2{0.f, 0.f};
@@ -186,9 +221,10 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         for (int rr = (h == 0 ? 1 : 0); rr < 8; ++rr) a[8 * h + rr] = cmul2(a[8 * h + rr], tw[rr]);
       }
 
+      HFC_T(2);  // DMA issue, prolog, pass 1, twiddles
       // exchange in two halves: rows k1 = 8h .. 8h+7 go through an 8-row block; lanes with (q >> 3) == h then read
       // "their" row (all n2) back
-      float* exf = myreg + g * kCExFrameStride;
+      float* exf = myreg + mul24(g, kCExFrameStride);
       v2 b[16];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -207,11 +243,12 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
+      HFC_T(3);  // exchange
       fft16(b, Z);
     }
 
     {
-      float* prow = myreg + g * kCPRowStride;
+      float* prow = myreg + mul24(g, kCPRowStride);
       float* pown = prow + q;
       float* ppar = prow + ((16 - q) & 15) + (q == 0 ? 16 : 0);
       if (q < kCPRowStride - 257) prow[257 + q] = 0.f;  // the padding a slot may read past bin 256 (weight 0) must be finite
@@ -250,6 +287,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
       }
       if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
     }
+    HFC_T(4);  // pass 2, split step, power rows
     // the wave's four power rows are complete once its own (in-order) LDS queue has drained
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -259,6 +297,9 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
     // All operands of the phase are requested before the first MFMA (one LDS round trip; the FFT registers are dead):
     // A = four consecutive power values per 16-byte read (lane = slot b, frame i: P[i][bin0(b) + 4 c ..]), B = four
     // consecutive steps of the weight table per 16-byte read (lane = slot b, filter j).
+    // the next round's span (requested at the start of this round) must have landed before this round's stores join the
+    // same in-order vmcnt queue: waiting here instead of at the top of the next round never waits for the stores
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     float* orow = p.out + (cd.out_row + f0) * p.out_stride;
     int lt_poff[kCMaxSets], lt_col[kCMaxSets];
     float lt_m4[kCMaxSets], lt_m8[kCMaxSets];
@@ -281,6 +322,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         bv[s][c4] = *reinterpret_cast<const f32x4*>(wb + c4 * 256);
       }
     }
+    HFC_T(5);  // operand reads of the mel phase issued (not yet waited for)
 #pragma unroll
     for (int s = 0; s < kCMaxSets; ++s) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -297,11 +339,21 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4 -- the odd slot of a pair takes its left neighbour's partial sum
         v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8 -- the last slot of a group of 3 or 4 takes the first slot(s)'
         v = fast_log(fmaxf(v, p.mel_floor));
-        if (col >= 0 && i < nf) orow[i * p.out_stride + col] = v;
+        if (col < p.M && i < nf) orow[i * p.out_stride + col] = v;
       }
     }
+    HFC_T(6);  // MFMAs, reduction, log, stores
+#ifdef HIPFEAT_PHASE_TIMERS
+    hfc_acc[7] += 1;
+#endif
     // the next round's exchange writes follow this round's power-row reads in the wave's own LDS queue (in order)
   }
+#ifdef HIPFEAT_PHASE_TIMERS
+  if (lane == 0 && g_phase_buf) {
+    unsigned long long* o = g_phase_buf + ((size_t)blockIdx.x * kCWaves + wv) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = hfc_acc[i];
+  }
+#endif
 }
 
 }  // namespace hipfeat

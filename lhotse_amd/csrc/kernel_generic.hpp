@@ -30,6 +30,7 @@ __device__ __forceinline__ float group32_sum(float v) {
 
 __global__ __launch_bounds__(256) void generic_kernel(const GenericParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  HF_POISON_LDS(smem);
   float* xs = smem;
   float2* z = reinterpret_cast<float2*>(smem + p.off_z);
   float* zr = smem + p.off_z;

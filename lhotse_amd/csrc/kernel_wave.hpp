@@ -33,7 +33,6 @@ struct WaveParams {
   int32_t N, shift, H, K, M, C, mel_blob_floats, dct_in_lds;
   int32_t kind, flags, npad_left;
   float preemph, log_energy_floor, mel_floor, log_offset;
-  int32_t ablate;  // experiments (HIPFEAT_WAVE_ABLATE): 1 no FFT, 2 no split/power, 4 no epilogue, 8 no sample loads
 };
 
 __device__ __forceinline__ v2 twiddle_h(const float2* __restrict__ tw, int m, int H) {  // W_H^m, 0 <= m < H, from W_2H^k (k < H)
@@ -155,6 +154,7 @@ template <int N1>
 __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_kernel(const WaveParams p) {
   constexpr int H = 64 * N1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  HF_POISON_LDS(smem);
   float2* tw = reinterpret_cast<float2*>(smem);                  // [H]
   float* winl = smem + 2 * H + 4 * (144 * N1 + 8);               // [N] window, shared by the four waves
   v2* twh = reinterpret_cast<v2*>(winl + ((p.N + 3) & ~3));       // [H] W_H^m for the FFT passes
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
     for (int q = 0; q < N1; ++q) {
       const int m0 = 2 * (lane + 64 * q);
       v2 v = {0.f, 0.f};
-      if (m0 < N && !(p.ablate & 8)) {
+      if (m0 < N) {
         if (inside) {
           __builtin_memcpy(&v, w + j0 + m0, sizeof(v2));  // 4-byte aligned 8-byte load
           if (m0 + 1 >= N) v.y = 0.f;
@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
     wave_lds_sync();  // the previous frame's readers of this wave's buffer are done
 
     // ---- complex FFT, split step X[k] = E[k] + W_2H^k O[k], power (layers.py:32-42) --------------------------------
-    if (!(p.ablate & 1)) fft3_frame<N1>(zf, twh, lane, y);
-    if (!(p.ablate & 2)) {
+    fft3_frame<N1>(zf, twh, lane, y);
+    {
       // bins k and H - k come from the same two FFT outputs: with a = Z[k], b = Z[H-k], E = (a + conj b)/2, O = -i (a - conj b)/2,
       // T = W_2H^k O:  X[k] = E + T and X[H-k] = conj(E - T).  Lane l takes k = l + 64 q <= H/2; k = 0 yields P[0] and P[H].
       float pa[N1 / 2 + 1], pb[N1 / 2 + 1];
@@ -300,9 +300,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     float* __restrict__ orow = p.out + (cd.out_row + f) * p.out_stride;
-    if (p.ablate & 4) {
-      if (lane < M) orow[lane] = buf[lane];
-    } else if (p.kind == 0 || p.kind == 1) {
+    if (p.kind == 0 || p.kind == 1) {
       for (int k = lane; k < K; k += 64) {
         float v = buf[k];
         if (p.kind == 1) v = fast_log(v + p.log_offset);

@@ -44,7 +44,6 @@ struct Whisper2Params {
   int32_t num_cuts, uniform_bpc, M;
   float mel_floor;
   const int32_t* sched;  // [4 waves][2 slots][4]: mel tile (-1: none), first bin (multiple of 4), chunks of 4 k-steps, offset (in chunks)
-  int32_t ablate;            // experiments (HIPFEAT_W2_ABLATE): 1 no 25-point DFT, 2 no fft16, 4 no mel GEMM, 8 no sample loads
 };
 
 #ifndef HIPFEAT_W2_OCC
@@ -54,6 +53,7 @@ __global__ __launch_bounds__(256, HIPFEAT_W2_OCC) void whisper2_kernel(const Whi
   // transpose buffer [16 frames][13][34]; once a group has read its frame back, the same region receives the frame's power row
   // (row stride 442 == 26 mod 32: the B-operand reads of the mel GEMM hit every bank exactly twice)
   __shared__ __attribute__((aligned(16))) float tbuf[16 * kW2TFrame + 24];
+  HF_POISON_ARRAY(tbuf, 16 * kW2TFrame + 24);
   __shared__ __attribute__((aligned(16))) float winl[kW2N];
   __shared__ __attribute__((aligned(16))) v2 twl[13 * 16];
   const int tid = threadIdx.x;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, HIPFEAT_W2_OCC) void whisper2_kernel(const Whi
     float s[25];
     {
       const int64_t j0 = (int64_t)(f0 + fi) * kW2Shift - kW2N / 2;
-      const bool live = fi < nf && !(p.ablate & 8);
+      const bool live = fi < nf;
       const bool inside = j0 >= 0 && j0 + kW2N <= (int64_t)S;
 #pragma unroll
       for (int j = 0; j < 25; ++j) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, HIPFEAT_W2_OCC) void whisper2_kernel(const Whi
       float re[12], im[12];
 #pragma unroll
       for (int k = 0; k < 12; ++k) re[k] = s[0], im[k] = 0.f;
-      if (!(p.ablate & 1)) {
+      {
 #pragma unroll
         for (int j = 1; j <= 12; ++j) {
           // constant address space: the loads stay scalar (s_load) after the opaque copy
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, HIPFEAT_W2_OCC) void whisper2_kernel(const Whi
       for (int l = 0; l < 16; ++l) xin[l] = *reinterpret_cast<const v2*>(src + 2 * l);
     }
     // ---- 4. 16-point FFT over l, power, scatter into the power tile ---------------------------------------------------------
-    if (!(p.ablate & 2)) fft16(xin, X);
+    fft16(xin, X);
     if (q == 0) {
 #pragma unroll
       for (int k1 = 0; k1 <= 8; ++k1) prow[25 * k1] = X[k1].x * X[k1].x + X[k1].y * X[k1].y;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, HIPFEAT_W2_OCC) void whisper2_kernel(const Whi
     for (int slot = 0; slot < 2; ++slot) {
       const int4 sc = *reinterpret_cast<const int4*>(p.sched + (wv * 2 + slot) * 4);  // uniform: one scalar load
       const int mt = sc.x;
-      if (mt < 0 || (p.ablate & 4)) continue;
+      if (mt < 0) continue;
       const int k0 = sc.y, chunks = sc.z;
       const f32x4* __restrict__ ma = reinterpret_cast<const f32x4*>(p.mel_a) + (size_t)sc.w * 64 + lane;
       const float* pb = tbuf + q * kW2TFrame + k0 + g;  // B operand: frame q, bin k0 + 4 s + g

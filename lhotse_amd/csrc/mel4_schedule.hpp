@@ -19,12 +19,16 @@
 
 namespace hipfeat {
 
+// "no output from this lane": a column no filterbank has.  (Not -1: the integer tables live in LDS as float words, and
+// 0xFFFFFFFF is a NaN that a later kernel could pick up from never-written LDS padding.)
+constexpr int kMel4NoColumn = 1 << 20;
+
 struct Mel4Schedule {
   int nsets = 0;
   int steps[4] = {0, 0, 0, 0};  // MFMA steps per set (multiples of 4)
   int step0[4] = {0, 0, 0, 0};  // first step of the set in the weight table
   std::vector<float> wtab;      // [total steps / 4][64 lanes][4 steps]: B operands
-  std::vector<float> ltab;      // [nsets][64 lanes][4]: power-row offset (int bits), output column (int bits, -1 = none), m4, m8
+  std::vector<float> ltab;      // [nsets][64 lanes][4]: power-row offset (int bits), output column (int bits, kMel4NoColumn = none), m4, m8
 };
 
 // h_mel: [K][M] row-major filterbank (bin x filter).  prow_stride: floats between the power rows of consecutive frames.
@@ -131,7 +135,7 @@ inline bool build_mel4_schedule(const float* h_mel, int M, int K, int prow_strid
     for (int lane = 0; lane < 64; ++lane) {  // unused slots: offset 0, no output
       float* lt = out.ltab.data() + ((size_t)s * 64 + lane) * 4;
       lt[0] = bits((lane & 3) * prow_stride);
-      lt[1] = bits(-1);
+      lt[1] = bits(kMel4NoColumn);
     }
   for (int g = 0; g < ng; ++g) {
     const Place& pl = best.place[g];
@@ -157,7 +161,7 @@ inline bool build_mel4_schedule(const float* h_mel, int M, int K, int prow_strid
       for (int i = 0; i < 4; ++i) {
         float* lt = out.ltab.data() + ((size_t)pl.set * 64 + 4 * b + i) * 4;
         lt[0] = bits(i * prow_stride + bin0);
-        lt[1] = bits(last && 4 * g + i < M ? 4 * g + i : -1);
+        lt[1] = bits(last && 4 * g + i < M ? 4 * g + i : kMel4NoColumn);
         lt[2] = m4;
         lt[3] = m8;
       }

@@ -157,7 +157,7 @@ def test_dither_is_gaussian_noise_on_the_waveform():
 
     x = torch.zeros(160000, device="cuda")
     ex = make_hip("fbank", {"dither": 0.01})
-    assert ex.kernel_name.startswith("fft512b_kernel")
+    assert ex.kernel_name.startswith("fft512c_kernel")
     torch.manual_seed(3)
     a = ex.extract(x, 16000)
     torch.manual_seed(3)
@@ -291,24 +291,25 @@ def test_one_very_long_cut_and_many_short_ones():
 
 
 def test_generic_and_fast_kernels_agree(monkeypatch):
-    """The specialised fft512 kernels and the generic kernel are two implementations of the same
-    arithmetic; HIPFEAT_FORCE_GENERIC / HIPFEAT_FFT512_VARIANT select them at plan creation."""
+    """The wave-autonomous fft512 kernel (default for log-mel), the 16-frame-tile fft512 kernel (HIPFEAT_FFT512_VARIANT=b; the
+    default for MFCC / spectrograms) and the generic kernel (HIPFEAT_FORCE_GENERIC=1) are three implementations of the same
+    arithmetic."""
     from _hip import make_hip
 
     rs = np.random.RandomState(11)
     waves = [(rs.rand(n).astype(np.float32) - 0.5) for n in (16000, 4000, 160000, 12345)]
     outs = {}
-    for name, env in [("fast_b", {}), ("fast_a", {"HIPFEAT_FFT512_VARIANT": "a"}), ("generic", {"HIPFEAT_FORCE_GENERIC": "1"})]:
+    for name, env in [("fast_c", {}), ("fast_b", {"HIPFEAT_FFT512_VARIANT": "b"}), ("generic", {"HIPFEAT_FORCE_GENERIC": "1"})]:
         for k in ("HIPFEAT_FFT512_VARIANT", "HIPFEAT_FORCE_GENERIC"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ex = make_hip("fbank", {})
         outs[name] = (ex.kernel_name, ex.extract_batch(waves, 16000))
-    assert outs["fast_b"][0].startswith("fft512b_kernel") and outs["fast_a"][0].startswith("fft512_fbank_kernel") and outs["generic"][0] == "generic"
-    for a, b in zip(outs["fast_b"][1], outs["generic"][1]):
+    assert outs["fast_c"][0].startswith("fft512c_kernel") and outs["fast_b"][0].startswith("fft512b_kernel") and outs["generic"][0] == "generic"
+    for a, b in zip(outs["fast_c"][1], outs["generic"][1]):
         assert err_stats(a, b)["rel_l2"] < 2e-6
-    for a, b in zip(outs["fast_b"][1], outs["fast_a"][1]):
+    for a, b in zip(outs["fast_c"][1], outs["fast_b"][1]):
         assert err_stats(a, b)["rel_l2"] < 2e-6
 
 
@@ -393,7 +394,7 @@ def test_fbank_fast_path_other_filterbanks(cfg):
     from _hip import make_hip
 
     ex = make_hip("fbank", cfg)
-    assert ex.kernel_name.startswith("fft512b_kernel"), ex.kernel_name
+    assert ex.kernel_name.startswith("fft512"), ex.kernel_name  # "c" when the filterbank fits its static schedule, else "b"
     rs = np.random.RandomState(41)
     waves = [(rs.rand(n).astype(np.float32) - 0.5) for n in (16000, 600, 31999)]
     outs = ex.extract_batch(waves, 16000)

@@ -113,26 +113,3 @@ def test_mfma_dft_kernel_agrees_with_the_generic_direct_dft(n_mels, monkeypatch)
         truth = W.log_mel_spectrogram(x, filters, dtype=np.float64)
         assert a.shape == b.shape == truth.shape
         assert np.abs(a - truth).max() <= 2e-4 and np.abs(b - truth).max() <= 2e-4, (len(x), np.abs(a - truth).max(), np.abs(b - truth).max())
-
-
-def test_both_fast_paths_agree(monkeypatch):
-    """whisper_kernel2 (16 x 25 FFT on the vector ALUs, the default) and whisper_kernel (DFT-400 as matrix-core GEMMs,
-    HIPFEAT_WHISPER_V1=1) against the float64 oracle and against each other, 80 and 128 filters, ragged lengths."""
-    rng = np.random.RandomState(7)
-    xs = [(rng.rand(n).astype(np.float32) - 0.5) * s for n, s in [(16000, 1.0), (48123, 0.2), (201, 1.0), (160000, 0.7), (3359, 0.05)]]
-    for n_mels in (80, 128):
-        filters = W.slaney_mel_filters(16000, 400, n_mels)
-        new = LA.HipWhisperFbank(LA.HipWhisperFbankConfig(num_filters=n_mels))
-        assert "whisper_kernel2" in new.kernel_name
-        a = new.extract_batch(xs, 16000)
-        monkeypatch.setenv("HIPFEAT_WHISPER_V1", "1")
-        old = LA.HipWhisperFbank(LA.HipWhisperFbankConfig(num_filters=n_mels))
-        assert "whisper_kernel<" in old.kernel_name
-        b = old.extract_batch(xs, 16000)
-        monkeypatch.delenv("HIPFEAT_WHISPER_V1")
-        for x, ya, yb in zip(xs, a, b):
-            truth = W.log_mel_spectrogram(x, filters, dtype=np.float64)
-            ref32 = W.log_mel_spectrogram(x, filters, dtype=np.float32)
-            _close(ya, ref32, truth, ("v2", n_mels, len(x)))
-            _close(yb, ref32, truth, ("v1", n_mels, len(x)))
-            assert np.abs(ya - yb).max() <= 2e-4

@@ -65,7 +65,7 @@ def emulate(sched, P, M):
                 sh[l] = v[l - 8] if (l & 15) >= 8 else 0.0
             v = v + sh * m8
             for l in range(64):
-                if col[l] >= 0:
+                if col[l] < M:
                     out[i, col[l]] = v[l]
                     seen[i, col[l]] += 1
     return out, seen
