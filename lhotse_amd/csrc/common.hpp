@@ -9,10 +9,15 @@ namespace hipfeat {
 // a read of a location the kernel never wrote (harmless-looking when it meets a zero weight and the leftover bits of the
 // previous kernel happen to be finite) shows up as NaN in the GPU tests.  tools/lds_poison.sh runs the suite on such a build.
 #ifdef HIPFEAT_LDS_POISON
+#ifndef HIPFEAT_LDS_POISON_FROM
+#define HIPFEAT_LDS_POISON_FROM 0  // bisecting aid: poison only [FROM, TO) floats
+#define HIPFEAT_LDS_POISON_TO (1 << 30)
+#endif
 __device__ int g_lds_poison_floats;
 #define HF_POISON_LDS(smem_)                                                                                           \
   do {                                                                                                                 \
-    for (int i_ = threadIdx.x; i_ < g_lds_poison_floats; i_ += blockDim.x) (smem_)[i_] = __builtin_nanf("");            \
+    for (int i_ = threadIdx.x + HIPFEAT_LDS_POISON_FROM; i_ < min(g_lds_poison_floats, HIPFEAT_LDS_POISON_TO); i_ += blockDim.x)   \
+      (smem_)[i_] = __builtin_nanf("");                                                                                \
     __syncthreads();                                                                                                   \
   } while (0)
 #define HF_POISON_ARRAY(arr_, n_)                                                                                      \

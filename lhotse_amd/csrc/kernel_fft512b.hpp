@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 4) void fft512b_kernel(const Fft512Params p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)ch * 1024u + lane16)),
                                          (__attribute__((address_space(3))) void*)(xs + ch * 256), 16, 0, 0);
     } else {
-      for (int i = tid; i < span; i += 256) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
+      for (int i = tid; i < p.xs_floats; i += 256) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);  // the whole buffer: rows past N are read (and masked) too
     }
   };
 

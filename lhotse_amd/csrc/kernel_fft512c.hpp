@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)nfull * 1024u + 4u * lane4)),
                                          (__attribute__((address_space(3))) void*)(xs + nfull * 256), 16, 0, 0);
     } else {
-      for (int i = (int)(lane4 >> 2); i < span; i += 64) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
+      for (int i = (int)(lane4 >> 2); i < p.xs_floats; i += 64) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);  // the whole buffer: rows past N are read (and met by a zero window) too
     }
   };
 

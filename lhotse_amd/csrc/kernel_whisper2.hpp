@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256, HIPFEAT_W2_OCC) void whisper2_kernel(const Whi
     }
     // ---- 4. 16-point FFT over l, power, scatter into the power tile ---------------------------------------------------------
     fft16(xin, X);
+    prow[201 + q] = 0.f;  // the last 16-bin chunk of a band may reach up to 15 entries past bin 200 (zero weights): keep them finite
     if (q == 0) {
 #pragma unroll
       for (int k1 = 0; k1 <= 8; ++k1) prow[25 * k1] = X[k1].x * X[k1].x + X[k1].y * X[k1].y;
