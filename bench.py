@@ -71,18 +71,10 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(seconds: float = 12.0, procs: int = 0):
-    """Time lhotse's CPU Fbank path on this host.  /root/reference does not exist on the GPU box, so the path is
-    restated in oracle/kaldi_torch.py with the reference's own sequence of torch (ATen) calls -- as_strided framing,
-    rfft, matmul, log -- bit-identical to the reference on the golden vectors (tests/test_oracle.py).
-    B (`value`): one cut per call as in CutSet.compute_and_store_features, `procs` single-threaded processes in
-    parallel, mirroring `num_jobs=procs` with torch.set_num_threads(1) (lhotse/bin/modes/features.py:25-32).
-    A (`batched`): batches of 60 cuts (600 s, the batch driver's default) through the batched forward with torch's
-    default intra-op threads, as Fbank.extract_batch runs it.  Workers are plain subprocesses with a hard timeout."""
+def _cpu_run(seconds: float, procs: int):
+    """`procs` single-threaded worker processes for `seconds`; returns (cuts/s summed over workers, cuts, workers that answered)."""
     import subprocess
 
-    ncpu = os.cpu_count() or 1
-    procs = procs or min(ncpu, 128)
     worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
     ps = [subprocess.Popen([sys.executable, worker, str(seconds), str(100 * i)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
           for i in range(procs)]
@@ -95,24 +87,51 @@ def cpu_baseline(seconds: float = 12.0, procs: int = 0):
             res.append((int(n), float(dt)))
         except Exception:
             p.kill()
-    if not res:
+    return sum(n / dt for n, dt in res), sum(n for n, _ in res), len(res)
+
+
+def cpu_baseline(seconds: float = 12.0, procs: int = 0):
+    """Time lhotse's CPU Fbank path on this host.  /root/reference does not exist on the GPU box, so the path is
+    restated in oracle/kaldi_torch.py with the reference's own sequence of torch (ATen) calls -- as_strided framing,
+    rfft, matmul, log -- bit-identical to the reference on the golden vectors (tests/test_oracle.py).
+    B (`value`): one cut per call as in CutSet.compute_and_store_features, N single-threaded processes in parallel,
+    mirroring `num_jobs=N` with torch.set_num_threads(1) (lhotse/bin/modes/features.py:25-32).  The path is memory-bound
+    on the host (each cut streams ~10 MB of intermediates), so more processes are not always faster: a short sweep over
+    N = cores/8 .. cores/2 (or --cpu-procs) is timed and the BEST total is reported, with the whole sweep alongside.
+    A (`batched`): batches of 60 cuts (600 s, the batch driver's default) through the batched forward with torch's
+    default intra-op threads, as Fbank.extract_batch runs it.  Workers are plain subprocesses with a hard timeout."""
+    import subprocess
+
+    ncpu = os.cpu_count() or 1
+    if procs:
+        sweep = [procs]
+    else:
+        sweep = sorted({max(1, min(ncpu, n)) for n in (ncpu // 8, ncpu // 4, ncpu // 2)})
+    per = max(4.0, seconds / len(sweep))
+    runs = []
+    for n in sweep:
+        rate, cuts, ok = _cpu_run(per, n)
+        if ok:
+            runs.append({"processes": ok, "cuts_per_s": round(rate, 1), "cuts": cuts, "seconds": per})
+    if not runs:
         return {"value": None, "unit": "cuts/s", "cores": 0, "kind": "port", "sample": "CPU baseline workers failed"}
-    rate = sum(n / dt for n, dt in res)
-    total = sum(n for n, _ in res)
+    best = max(runs, key=lambda r: r["cuts_per_s"])
     out = {
-        "value": round(rate, 1),
+        "value": best["cuts_per_s"],
         "unit": "cuts/s",
-        "cores": len(res),
+        "cores": best["processes"],
         "kind": "port",
         "cpu_model": cpu_model(),
         "logical_cores": ncpu,
-        "sample": f"{total} x 10 s cuts in {seconds:.0f} s wall: {len(res)} single-threaded processes of the reference's torch CPU Fbank "
-        f"call sequence (oracle/kaldi_torch.py, bit-identical to the reference on the goldens; {rate / len(res):.0f} cuts/s per process); "
-        f"host has {ncpu} logical cores ({cpu_model()})",
+        "sweep": runs,
+        "sample": f"{best['cuts']} x 10 s cuts in {best['seconds']:.0f} s wall: {best['processes']} single-threaded processes of the reference's torch CPU Fbank "
+        f"call sequence (oracle/kaldi_torch.py, bit-identical to the reference on the goldens; {best['cuts_per_s'] / best['processes']:.0f} cuts/s per process), "
+        f"best of a sweep over {[r['processes'] for r in runs]} processes; host has {ncpu} logical cores ({cpu_model()})",
     }
     # baseline A: batched, default intra-op threads
+    worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
     try:
-        p = subprocess.run([sys.executable, worker, str(min(seconds, 8.0)), "7", "batched"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+        p = subprocess.run([sys.executable, worker, str(min(seconds, 6.0)), "7", "batched"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                            text=True, timeout=seconds + 120)
         n, dt, threads = p.stdout.split()
         out["batched"] = {"value": round(int(n) / float(dt), 1), "unit": "cuts/s", "threads": int(threads),
@@ -204,8 +223,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--cpu-procs", type=int, default=0, help="host processes of the CPU baseline (default min(cores, 128))")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="host processes of the CPU baseline (default: best of a sweep over cores/8, cores/4, cores/2)")
     ap.add_argument("--input", default="uniform", choices=["uniform", "zeros", "sine"], help="synthetic input (the metric is defined on `uniform`; the others exist to expose power/DVFS effects)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (self-test of the N>1 path on one GPU)")
     args = ap.parse_args()

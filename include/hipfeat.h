@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HIPFEAT_ABI_VERSION 1
+#define HIPFEAT_ABI_VERSION 2
 
 #if defined(HIPFEAT_BUILD)
 #define HIPFEAT_API __attribute__((visibility("default")))
@@ -94,7 +94,12 @@ typedef struct hipfeat_config {
   float energy_floor;       /* log-energy floored at log(energy_floor) if >0 layers.py:864     */
   float mel_floor;          /* eps of max(mel, eps).log() = 1.1920929e-07    layers.py:536,572 */
   float log_offset;         /* 1e-15 added before log in Wav2LogSpec         layers.py:467     */
-  float dither;             /* must be 0 in ABI v1 (layers.py:191-193 draws torch.randn)        */
+  float dither;             /* must be 0 (layers.py:191-193 draws torch.randn: the host adds it)  */
+  int32_t batch_hop;        /* round(frame_shift_s * sampling_rate): the hop with which
+                               compute_num_frames_from_samples (lhotse/utils.py:424-434) counts the rows
+                               item b keeps of a zero-padded batch row (padded_len given); differs from
+                               frame_shift for fractional hops (12.5 ms @ 22.05 kHz: 276 vs 275).
+                               0 = frame_shift                                                   */
 } hipfeat_config;
 
 typedef struct hipfeat_plan hipfeat_plan;     /* constants + kernel selection, per (device, config) */

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import build as _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> (return C type, [argument C types]) ; mirrors include/hipfeat.h one to one.
 _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
@@ -93,6 +93,7 @@ CONFIG_DTYPE = np.dtype(
         ("mel_floor", "<f4"),
         ("log_offset", "<f4"),
         ("dither", "<f4"),
+        ("batch_hop", "<i4"),
     ],
     align=True,
 )

@@ -141,7 +141,7 @@ class HipResampleTensor:
         x = waveform.reshape(rows, T).to(self.device).contiguous()
         out, _, out_lens = self.run(x.view(-1), np.arange(rows, dtype=np.int64) * T, np.full(rows, T, dtype=np.int64), align=False)
         y = out.view(shape[:-1] + (int(out_lens[0]) if rows else 0,))
-        return y if waveform.is_cuda else y.cpu()
+        return y.to(waveform.device)  # the input's device, whichever GPU (or the host) that is
 
     forward = __call__
 

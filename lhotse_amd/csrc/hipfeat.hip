@@ -789,7 +789,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
     return fail(HIPFEAT_ERR_UNSUPPORTED, "frame_shift (%d) > frame_length (%d) is not supported", shift, N);
   if (!h_window) return fail(HIPFEAT_ERR_INVALID, "window is NULL");
   if (cfg->dither != 0.0f)
-    return fail(HIPFEAT_ERR_UNSUPPORTED, "dither != 0 is not supported in ABI v%d", HIPFEAT_ABI_VERSION);
+    return fail(HIPFEAT_ERR_UNSUPPORTED, "dither != 0 is not supported by the library (ABI v%d): the host adds it to the samples", HIPFEAT_ABI_VERSION);
   const bool whisper = cfg->kind == HIPFEAT_WHISPER;
   if (whisper && (fft != N || cfg->snip_edges || cfg->use_energy || cfg->use_fft_mag || cfg->remove_dc_offset || cfg->preemph_coeff != 0.0f))
     return fail(HIPFEAT_ERR_INVALID, "whisper: needs fft_length == frame_length and no snip_edges / energy / magnitude / DC removal / pre-emphasis");
@@ -943,8 +943,8 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
       // _extract_batch (extractors.py:499-537): the padded row of P samples is framed as a whole and
       // item b keeps the first compute_num_frames_from_samples(S) rows (lhotse/utils.py:424-434) --
       // with snip_edges that is NOT the snip_edges count, and it is capped by what the row yields.
-      T = std::min<int64_t>((S + c.frame_shift / 2) / c.frame_shift,
-                            hipfeat_num_frames(P, c.frame_length, c.frame_shift, c.snip_edges));
+      const int64_t hop = c.batch_hop > 0 ? c.batch_hop : c.frame_shift;
+      T = std::min<int64_t>((S + hop / 2) / hop, hipfeat_num_frames(P, c.frame_length, c.frame_shift, c.snip_edges));
     }
     if (!c.snip_edges && T > 0 && c.kind != HIPFEAT_WHISPER && c.kind != HIPFEAT_LIBROSA_FBANK) {
       hipfeat_status st = hipfeat_check_length(P, c.frame_length, c.frame_shift, 0);
@@ -1385,8 +1385,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_extract_host(const hipfeat_plan* p
   for (int64_t b = 0, row = 0; b < batch; ++b) {
     const hipfeat_config& c = plan->cfg;
     int64_t T = hipfeat_num_frames(h_num_samples[b], c.frame_length, c.frame_shift, c.snip_edges);
-    if (h_padded_len) T = std::min<int64_t>((h_num_samples[b] + c.frame_shift / 2) / c.frame_shift,
-                                            hipfeat_num_frames(h_padded_len[b], c.frame_length, c.frame_shift, c.snip_edges));
+    if (h_padded_len) {
+      const int64_t hop = c.batch_hop > 0 ? c.batch_hop : c.frame_shift;
+      T = std::min<int64_t>((h_num_samples[b] + hop / 2) / hop, hipfeat_num_frames(h_padded_len[b], c.frame_length, c.frame_shift, c.snip_edges));
+    }
     const int64_t r0 = h_out_rows ? h_out_rows[b] : row;
     if (r0 < 0 || (T > 0 && ((r0 + T - 1) * out_row_stride + plan->feature_dim) > out_elems))
       return fail(HIPFEAT_ERR_INVALID, "cut %lld: output rows lie outside the output buffer", (long long)b);

@@ -230,6 +230,10 @@ class _Plan:
         # reference does, layers.py:189-193); the library itself takes the (dithered) samples
         self.dither = float(cfg.dither)
         c["dither"] = 0.0
+        # rows an item keeps of a zero-padded batch row: compute_num_frames_from_samples counts with round(), the framing
+        # itself with floor() (lhotse/utils.py:424-434 vs layers.py:116)
+        self.batch_hop = int(round(cfg.frame_shift * cfg.sampling_rate)) if hasattr(cfg, "frame_shift") and hasattr(cfg, "sampling_rate") else shift
+        c["batch_hop"] = self.batch_hop
         cbuf = np.ascontiguousarray(c).reshape(1)
         out = np.zeros(1, dtype=np.uint64)
         self.lib.check(
@@ -277,7 +281,7 @@ class _Plan:
             frames = self.num_frames_many(lengths)
         else:
             padded = _lib.i64(padded)
-            own = (lengths + shift // 2) // shift
+            own = (lengths + self.batch_hop // 2) // self.batch_hop
             frames = np.minimum(own, self.num_frames_many(padded))
         total = int(frames.sum())
         with torch.cuda.device(self.device):
@@ -308,7 +312,7 @@ class _Plan:
         frames = self.num_frames_many(lengths)
         if padded is not None:
             padded = _lib.i64(padded)
-            frames = np.minimum((lengths + shift // 2) // shift, self.num_frames_many(padded))
+            frames = np.minimum((lengths + self.batch_hop // 2) // self.batch_hop, self.num_frames_many(padded))
         tmax = int(frames.max(initial=0))
         got = np.zeros(len(lengths), dtype=np.int64)
         with torch.cuda.device(self.device):
@@ -492,6 +496,7 @@ class _HipExtractor(FeatureExtractor):
         st = dict(self.__dict__)
         st["_plan"] = None  # the device handle is per process
         st["_staging"] = None
+        st.pop("_lock", None)
         return st
 
     def _drop_plan(self):
@@ -502,8 +507,16 @@ class _HipExtractor(FeatureExtractor):
     @property
     def plan(self) -> _Plan:
         if self._plan is None:
-            self._plan = _Plan(self._plan_config(), self.kind, torch.device(self.config.device), mel_floor=self._plan_mel_floor())
+            with self._lazy_lock():  # extractors may be shared between reader threads: build the plan once
+                if self._plan is None:
+                    self._plan = _Plan(self._plan_config(), self.kind, torch.device(self.config.device), mel_floor=self._plan_mel_floor())
         return self._plan
+
+    def _lazy_lock(self):
+        lock = self.__dict__.get("_lock")
+        if lock is None:  # created on first use so that pickled / copied extractors get their own
+            lock = self.__dict__.setdefault("_lock", threading.Lock())
+        return lock
 
     def _plan_config(self):
         return self.config
@@ -525,7 +538,9 @@ class _HipExtractor(FeatureExtractor):
     # -- device plumbing --------------------------------------------------------------------
     def _stage(self) -> _HostStaging:
         if self._staging is None:
-            self._staging = _HostStaging()
+            with self._lazy_lock():
+                if self._staging is None:
+                    self._staging = _HostStaging()
         return self._staging
 
     def _to_host(self, dev_tensor: torch.Tensor) -> torch.Tensor:

@@ -5,14 +5,18 @@
 Loops the CPU Fbank path (oracle/kaldi_torch.py: the reference's own sequence of torch calls, bit-identical to the
 reference on the goldens; one 10 s cut per call with torch.set_num_threads(1), as CutSet.compute_and_store_features /
 `lhotse feat extract` run the reference extractor) for <seconds> and prints "<cuts> <elapsed>".
-`numpy` as third argument times the numpy restatement (oracle/kaldi_ref.py) instead.
+`numpy` as third argument times the numpy restatement (oracle/kaldi_ref.py) instead; `batched` times the batched forward on
+batches of 60 cuts with torch's DEFAULT intra-op threads, as Fbank.extract_batch runs it (lhotse/features/kaldi/extractors.py:485-554),
+and prints "<cuts> <elapsed> <threads>".
 """
 import os
 import sys
 import time
 
-for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-    os.environ[k] = "1"
+BATCHED = len(sys.argv) > 3 and sys.argv[3] == "batched"
+if not BATCHED:
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import numpy as np  # noqa: E402
@@ -23,6 +27,20 @@ from oracle.signals import make_signal  # noqa: E402
 
 def main():
     seconds, seed = float(sys.argv[1]), int(sys.argv[2])
+    if BATCHED:
+        import torch
+
+        from oracle.kaldi_torch import TorchFbank
+
+        ex = TorchFbank()
+        x = torch.from_numpy(np.stack([make_signal("uniform", 160000, seed + s) for s in range(60)]))
+        ex.forward_batch(x)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            ex.forward_batch(x)
+            n += 60
+        print(n, time.perf_counter() - t0, torch.get_num_threads(), flush=True)
+        return
     if len(sys.argv) > 3 and sys.argv[3] == "numpy":
         ex = RefExtractor(RefConfig(kind="fbank"), np.float32)
     else:

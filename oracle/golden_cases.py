@@ -86,6 +86,10 @@ CASES: List[Dict[str, Any]] = [
     _c("batch_equal", "fbank", {}, [(U, 8000, 94), (U, 8000, 95), (U, 8000, 96)], mode="batch"),
     _c("batch_lengths", "mfcc", {"num_filters": 40, "num_ceps": 40}, [(U, 9000, 97), (U, 4000, 98), (U, 8880, 99)], mode="batch_lengths"),
     _c("batch_single", "fbank", {}, [(U, 5000, 100)], mode="batch"),
+    # fractional hop: 12.5 ms @ 22.05 kHz frames with floor() = 275 samples, but compute_num_frames_from_samples slices the
+    # items of a zero-padded batch with round() = 276 (lhotse/utils.py:424-434): 9213 and 15264 samples give one row less
+    _c("batch_fractional_hop", "fbank", {"sampling_rate": 22050, "frame_shift": 0.0125, "num_filters": 40},
+       [(U, 22050, 101), (U, 9213, 102), (U, 15264, 103)], mode="batch"),
 ]
 
 

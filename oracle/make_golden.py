@@ -82,7 +82,13 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     index = {}
     total = 0
+    only = set(sys.argv[1:])  # optional: regenerate just the named cases (the index keeps the others' entries)
+    if only and os.path.exists(os.path.join(out_dir, "index.json")):
+        with open(os.path.join(out_dir, "index.json")) as f:
+            index = json.load(f)["cases"]
     for case in CASES:
+        if only and case["name"] not in only:
+            continue
         ex = build(ex_mod, case["kind"], case["cfg"])
         sr = ex.config.sampling_rate
         waves = [make_signal(k, n, seed, sr) for k, n, seed in case["inputs"]]

@@ -51,3 +51,32 @@ def err_stats(got: np.ndarray, want: np.ndarray) -> Dict[str, float]:
         "rel_l2": float(np.linalg.norm(d) / den) if den > 0 else float(np.linalg.norm(d)),
         "frac_within": float(np.mean(np.abs(d) <= 1e-3 + 1e-4 * np.abs(want))) if d.size else 1.0,
     }
+
+
+# ---- parity log: every GPU comparison that goes through record_parity() ends up in gpurun_out/parity_report.json
+# (written by conftest.pytest_sessionfinish; copied to profiles/rNN_parity.json per round) --------------------------------
+PARITY_LOG = []
+
+
+def record_parity(suite: str, case, kernel: str, got, want, truth, rel_tol: float = 1e-4, abs_tol: float = 2e-3) -> Dict[str, float]:
+    """Error of the HIP output against the reference arithmetic (`want`, float32) next to the reference's own float32-vs-
+    float64 floor; `clause_*` say whether the 3 x floor escape clause of the assertion was needed for this entry."""
+    s = err_stats(got, want)
+    floor = err_stats(want, truth)
+    own = err_stats(got, truth)
+    rec = {
+        "suite": suite,
+        "case": str(case),
+        "kernel": kernel.split(" ")[0] if kernel else "",
+        "rel_l2": s["rel_l2"],
+        "max_abs": s["max_abs"],
+        "frac_within_rtol1e-4_atol1e-3": s["frac_within"],
+        "floor_rel_l2": floor["rel_l2"],
+        "floor_max_abs": floor["max_abs"],
+        "rel_l2_vs_float64": own["rel_l2"],
+        "clause_needed_rel": bool(s["rel_l2"] > rel_tol),
+        "clause_needed_abs": bool(s["max_abs"] > abs_tol),
+        "n_values": int(np.asarray(got).size),
+    }
+    PARITY_LOG.append(rec)
+    return rec

@@ -23,18 +23,23 @@ def make_hip(kind: str, cfg: dict, **extra):
         return cls(ccls(**cfg, **extra))
 
 
-def run_case(case, waves):
+def run_case(case, waves, want_kernel=False):
     """Run the HIP path through the same entry point the reference was run through."""
+    outs, ex = _run_case(case, waves)
+    return (outs, ex.kernel_name) if want_kernel else outs
+
+
+def _run_case(case, waves):
     sr = case["cfg"].get("sampling_rate", 16000)
     if case["mode"] == "extract":
         ex = make_hip(case["kind"], case["cfg"])
-        return [ex.extract(w, sr) for w in waves]
+        return [ex.extract(w, sr) for w in waves], ex
     ex = make_hip(case["kind"], case["cfg"], edge_rule="batch_zero_pad")
     if case["mode"] == "batch":
         res = ex.extract_batch(list(waves), sr)
-        return list(res) if not (isinstance(res, np.ndarray) and res.ndim == 2) else [res]
+        return (list(res) if not (isinstance(res, np.ndarray) and res.ndim == 2) else [res]), ex
     lens = torch.tensor([len(w) for w in waves], dtype=torch.int32)
     padded = torch.zeros(len(waves), int(lens.max()))
     for i, w in enumerate(waves):
         padded[i, : len(w)] = torch.from_numpy(w)
-    return list(ex.extract_batch(padded, sr, lengths=lens))
+    return list(ex.extract_batch(padded, sr, lengths=lens)), ex

@@ -3,17 +3,19 @@ GPU parity tests (run on a real MI355X): the HIP path, called through the Hip* e
 and the C ABI, against
   (1) the committed golden vectors produced by the reference itself,
   (2) the oracle (CPU restatement) on fresh seeded inputs,
-both judged relative to float64 arithmetic: the tolerance north_star states is 1e-4
-relative; log features of near-silent bins carry the reference's own float32 noise
-(SURVEY section 7 "parity metric"), so the bar is
-     rel_l2(hip, ref)  <= max(1e-4, 3 * rel_l2(ref, float64 truth))
-     max_abs(hip, ref) <= max(2e-3, 3 * max_abs(ref, float64 truth)).
+both judged relative to float64 arithmetic.  The bar is the one north_star states, without escape clause:
+     rel_l2(hip, ref) <= 1e-4        max_abs(hip, ref) <= 2e-3
+for every filterbank / MFCC / spectrogram comparison.  Two families carry the reference's own float32 noise beyond that
+(profiles/r02_parity.json records, per comparison, the achieved error, the reference's float32-vs-float64 floor and
+whether a clause was needed): the LOG of single near-silent FFT bins (log-spectrogram: both clauses, `kind` says so) and
+the element-wise bound of MFCCs of pure tones (a DCT row sums 23-40 such logs: abs clause only):
+     rel_l2 <= max(1e-4, 3 * rel_l2(ref, float64))      max_abs <= max(2e-3, 3 * max_abs(ref, float64)).
 """
 import numpy as np
 import pytest
 import torch
 
-from _golden import CASES, err_stats, golden_rows, load_case, ref_config
+from _golden import CASES, err_stats, golden_rows, load_case, record_parity, ref_config
 from oracle.kaldi_ref import RefConfig, RefExtractor
 
 pytestmark = pytest.mark.gpu
@@ -23,13 +25,17 @@ REL_TOL = 1e-4
 ABS_TOL = 2e-3
 
 
-def assert_parity(got, want, truth, ctx, abs_tol=ABS_TOL):
+def assert_parity(got, want, truth, ctx, abs_tol=ABS_TOL, suite="misc", kernel="", kind="fbank"):
+    """No escape clause unless `kind` is one of the two families the module docstring names."""
     s = err_stats(got, want)
     floor = err_stats(want, truth)
     own = err_stats(got, truth)
+    record_parity(suite, ctx, kernel, got, want, truth, REL_TOL, abs_tol)
     assert np.isfinite(np.asarray(got)).all(), ctx
-    assert s["rel_l2"] <= max(REL_TOL, 3 * floor["rel_l2"]), (ctx, s, floor, own)
-    assert s["max_abs"] <= max(abs_tol, 3 * floor["max_abs"]), (ctx, s, floor, own)
+    rel_bar = max(REL_TOL, 3 * floor["rel_l2"]) if kind == "log-spectrogram" else REL_TOL
+    abs_bar = max(abs_tol, 3 * floor["max_abs"]) if kind in ("log-spectrogram", "mfcc") else abs_tol
+    assert s["rel_l2"] <= rel_bar, (ctx, s, floor, own)
+    assert s["max_abs"] <= abs_bar, (ctx, s, floor, own)
 
 
 # log of a single near-silent FFT bin: both float32 implementations are dominated by rounding there
@@ -44,7 +50,7 @@ def test_hip_matches_reference_golden(name):
     from _hip import run_case
 
     case, waves, z = load_case(name)
-    outs = run_case(case, waves)
+    outs, kernel = run_case(case, waves, want_kernel=True)
     ex64 = RefExtractor(ref_config(case), np.float64)
     truth = [ex64.extract(w) for w in waves] if case["mode"] == "extract" else ex64.extract_batch(waves, "batch_zero_pad")
     assert len(outs) == len(waves)
@@ -53,7 +59,7 @@ def test_hip_matches_reference_golden(name):
         assert o.dtype == np.float32
         got, want = golden_rows(z, i, o)
         tr, _ = golden_rows(z, i, truth[i])
-        assert_parity(got, want, tr, (name, i))
+        assert_parity(got, want, tr, (name, i), suite="golden", kernel=kernel, kind=case["kind"])
 
 
 @pytest.mark.parametrize("kind,cfg", [("fbank", {}), ("mfcc", {"num_filters": 40, "num_ceps": 40}), ("spectrogram", {}), ("log-spectrogram", {})])
@@ -73,7 +79,7 @@ def test_hip_matches_oracle_ragged_batch(kind, cfg):
     for w, o in zip(waves, outs):
         want, truth = o32.extract(w), o64.extract(w)
         assert o.shape == want.shape
-        assert_parity(o, want, truth, (kind, len(w)))
+        assert_parity(o, want, truth, (kind, len(w)), suite="ragged_batch", kernel=ex.kernel_name, kind=kind)
         # batch result == single-item result, bit for bit (same kernel, same arithmetic)
         np.testing.assert_array_equal(o, ex.extract(w, 16000))
 
@@ -105,12 +111,13 @@ def test_full_size_properties():
     a = 0.25
     ya = ex.extract(x[1] * a, 16000)
     assert torch.allclose(ya, y[1] + 2 * np.log(a), atol=2e-4, rtol=0)
-    # sampled oracle parity on a few full-size cuts
+    # oracle parity on ALL 64 full-size cuts of the headline configuration, without the escape clause on the norm-wise bar
     o32 = RefExtractor(RefConfig(kind="fbank"), np.float32)
     o64 = RefExtractor(RefConfig(kind="fbank"), np.float64)
-    for b in (0, 31, 63):
+    yc = y.cpu().numpy()
+    for b in range(B):
         w = x[b].numpy()
-        assert_parity(y[b].cpu().numpy(), o32.extract(w), o64.extract(w), ("full", b))
+        assert_parity(yc[b], o32.extract(w), o64.extract(w), ("full", b), suite="headline_10s_x64", kernel=ex.kernel_name)
 
 
 def test_too_short_and_errors():
@@ -331,7 +338,7 @@ def test_mfcc_fast_path(cfg, fast):
     o32 = RefExtractor(RefConfig(kind="mfcc", **rc), np.float32)
     o64 = RefExtractor(RefConfig(kind="mfcc", **rc), np.float64)
     for w, o in zip(waves, outs):
-        assert_parity(o, o32.extract(w), o64.extract(w), ("mfcc-fast", cfg, len(w)))
+        assert_parity(o, o32.extract(w), o64.extract(w), ("mfcc-fast", cfg, len(w)), suite="mfcc_fast_path", kernel=ex.kernel_name, kind="mfcc")
 
 
 def test_c_abi_unaligned_offsets_and_staging_ring():
@@ -384,7 +391,7 @@ def test_spectrogram_fast_path(kind, cfg):
     for w, o in zip(waves, outs):
         assert o.shape[1] == 257
         want = o32.extract(w)
-        assert_parity(np.asarray(o), want, o64.extract(w), (kind, cfg, len(w)), abs_tol=LOGSPEC_ABS_TOL if kind == "log-spectrogram" else ABS_TOL)
+        assert_parity(np.asarray(o), want, o64.extract(w), (kind, cfg, len(w)), abs_tol=LOGSPEC_ABS_TOL if kind == "log-spectrogram" else ABS_TOL, suite="spectrogram_fast_path", kernel=ex.kernel_name, kind=kind)
         assert err_stats(np.asarray(o), want)["frac_within"] >= 0.9995
 
 
@@ -401,7 +408,7 @@ def test_fbank_fast_path_other_filterbanks(cfg):
     o32 = RefExtractor(RefConfig(kind="fbank", **cfg), np.float32)
     o64 = RefExtractor(RefConfig(kind="fbank", **cfg), np.float64)
     for w, o in zip(waves, outs):
-        assert_parity(o, o32.extract(w), o64.extract(w), ("fbank-fast", cfg, len(w)))
+        assert_parity(o, o32.extract(w), o64.extract(w), ("fbank-fast", cfg, len(w)), suite="fbank_other_filterbanks", kernel=ex.kernel_name)
 
 
 def test_layout_launch_is_hip_graph_capturable():

@@ -6,6 +6,8 @@ import warnings
 import numpy as np
 import pytest
 
+from _golden import record_parity
+
 import lhotse_amd as LA
 from oracle import kaldi_ref as K
 
@@ -78,6 +80,7 @@ def test_random_config_against_float64_oracle(idx):
         den = max(np.linalg.norm(truth), 1e-30)
         floor = np.linalg.norm(want - truth) / den
         rel = np.linalg.norm(got - truth) / den
+        record_parity("random_configs", (kind, sorted(cfg.items()), len(x)), ex.kernel_name, got, want, truth)
         assert rel <= max(1e-4, 3 * floor), (ex.kernel_name, kind, cfg, len(x), rel, floor)
 
 
