@@ -94,6 +94,38 @@ __device__ __forceinline__ void fft16(const v2 (&x)[16], v2 (&X)[16]) {
   }
 }
 
+// 32-point complex FFT in registers: one radix-2 decimation-in-frequency stage, then two 16-point FFTs
+//   X[2 k]     = FFT16(x[n] + x[n + 16])[k]
+//   X[2 k + 1] = FFT16((x[n] - x[n + 16]) W_32^n)[k]
+// Rows n >= NZ are structurally zero (zero padding of the frame): their adds / subtracts are not issued at all.
+template <int NZ>
+__device__ __forceinline__ void fft32(const v2 (&x)[32], v2 (&X)[32]) {
+  constexpr float C[16] = {1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f, 0.55557023301960222f,
+                           0.38268343236508977f, 0.19509032201612827f, 0.0f, -0.19509032201612827f, -0.38268343236508977f, -0.55557023301960222f,
+                           -0.70710678118654752f, -0.83146961230254524f, -0.92387953251128674f, -0.98078528040323044f};
+  constexpr float S[16] = {0.0f, 0.19509032201612827f, 0.38268343236508977f, 0.55557023301960222f, 0.70710678118654752f, 0.83146961230254524f,
+                           0.92387953251128674f, 0.98078528040323044f, 1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f,
+                           0.70710678118654752f, 0.55557023301960222f, 0.38268343236508977f, 0.19509032201612827f};
+  v2 e[16], o[16], E[16], O[16];
+#pragma unroll
+  for (int n = 0; n < 16; ++n) {
+    const bool hi = n + 16 < NZ;  // x[n + 16] may be non-zero
+    e[n] = hi ? x[n] + x[n + 16] : x[n];
+    const v2 d = hi ? x[n] - x[n + 16] : x[n];
+    // W_32^n = (cos, -sin): w = (c, -s), wp = (s, c)
+    if (n == 0) o[n] = d;
+    else if (n == 8) o[n] = rot_mi(d);
+    else o[n] = cmulc(d, v2{C[n], -S[n]}, v2{S[n], C[n]});
+  }
+  fft16(e, E);
+  fft16(o, O);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    X[2 * k] = E[k];
+    X[2 * k + 1] = O[k];
+  }
+}
+
 // 8-point complex FFT in registers (radix-4 x radix-2, natural order in and out)
 __device__ __forceinline__ void fft8(const v2* x, v2* X) {
   constexpr float R2 = 0.70710678118654752f;

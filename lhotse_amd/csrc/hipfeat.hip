@@ -19,6 +19,7 @@
 #include "fft512_common.hpp"
 #include "kernel_fft512b.hpp"
 #include "kernel_fft512c.hpp"
+#include "kernel_fft1024c.hpp"
 #include "mel4_schedule.hpp"
 #include "kernel_resample.hpp"
 #include "kernel_specaug.hpp"
@@ -110,6 +111,8 @@ struct hipfeat_plan {
   // fft512 wave-autonomous fbank kernel (variant 7)
   float* d_c_shared = nullptr;  // LDS image: FFT constants | 4x4-block filterbank weights | lane tables
   int c_shared_floats = 0, c_wtab_off = 0, c_ltab_off = 0, c_xs_floats = 0, c_rounds = 0;
+  // fft1024 wave-autonomous fbank kernel (variant 8; shares d_c_shared / c_* with variant 7)
+  int w_nsets = 0, w_steps[kWMaxSets] = {}, w_step0[kWMaxSets] = {};
   // wave-per-frame kernel (variant 5)
   float* d_mel_t = nullptr;  // filterbank blob (descriptors + compact weights)
   int mel_maxband = 0;
@@ -520,6 +523,95 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
 }
 
 // --------------------------------------------------------------------------------------
+// fft1024 wave-autonomous fbank kernel (kernel_fft1024c.hpp): 22.05 / 24 / 32 kHz Kaldi log-mel
+// --------------------------------------------------------------------------------------
+template <int NROWS>
+static const void* fft1024c_entry() {
+  return reinterpret_cast<const void*>(&fft1024c_kernel<NROWS>);
+}
+
+static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, const float* h_mel) {
+  const hipfeat_config& c = p->cfg;
+  const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
+  if (p->variant != 0 || c.kind != HIPFEAT_FBANK || c.fft_length != 1024 || (shift & 1) || N < 32 * 17 || c.use_energy || c.use_fft_mag ||
+      getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_AUTONOMOUS"))
+    return HIPFEAT_OK;
+  const int need = (N + 31) / 32;
+  const int nrows = need <= 20 ? 20 : (need <= 26 ? 26 : 32);
+  Mel4Schedule sch;
+  if (!build_mel4_schedule(h_mel, M, p->K, kWPRowStride, kWMaxSets, kWMaxSteps, sch)) return HIPFEAT_OK;
+  std::vector<float> img((size_t)(nrows * 16 + 512 + kWSplitSteps * 16) * 2, 0.0f);
+  for (int n1 = 0; n1 < nrows; ++n1)
+    for (int q = 0; q < 16; ++q)
+      for (int e = 0; e < 2; ++e) {
+        const int i = 32 * n1 + 2 * q + e;
+        img[2 * (n1 * 16 + q) + e] = i < N ? 0.5f * h_window[i] : 0.0f;
+      }
+  float* twp = img.data() + 2 * nrows * 16;
+  float* tws = twp + 1024;
+  for (int k1 = 0; k1 < 32; ++k1)
+    for (int q = 0; q < 16; ++q) {
+      const double a = -2.0 * M_PI * (double)(q * k1) / 512.0;
+      twp[2 * (k1 * 16 + q)] = (float)std::cos(a);
+      twp[2 * (k1 * 16 + q) + 1] = (float)std::sin(a);
+    }
+  for (int st = 0; st < kWSplitSteps; ++st)
+    for (int q = 0; q < 16; ++q) {  // bin of the step's first operand: lanes >= 1: q + 32 s; lane 0: 32 s (s <= 8), 16 + 32 (s - 9) (s <= 15), 240
+      int k;
+      if (q != 0) k = st < 16 ? q + 32 * st : 0;
+      else k = st <= 8 ? 32 * st : (st <= 15 ? 16 + 32 * (st - 9) : 240);
+      const double a = -2.0 * M_PI * (double)k / 1024.0;  // w = -i * W_1024^k = (sin(a), -cos(a))
+      tws[2 * (st * 16 + q)] = (float)std::sin(a);
+      tws[2 * (st * 16 + q) + 1] = (float)(-std::cos(a));
+    }
+  // the kernel runs two accumulation chains per set over chunks of 4 steps: every set's steps are padded to a multiple of 8
+  // (zero weights; the power-row reads stay inside the wave's region)
+  p->c_wtab_off = (int)img.size();
+  {
+    int step0 = 0;
+    for (int s2 = 0; s2 < sch.nsets; ++s2) {
+      const int padded = (sch.steps[s2] + 7) & ~7;
+      const size_t at = img.size();
+      img.resize(at + (size_t)padded * 64, 0.0f);
+      std::memcpy(img.data() + at, sch.wtab.data() + (size_t)sch.step0[s2] * 64, (size_t)sch.steps[s2] * 64 * sizeof(float));
+      sch.steps[s2] = padded;
+      sch.step0[s2] = step0;
+      step0 += padded;
+    }
+  }
+  p->c_ltab_off = (int)img.size();
+  img.insert(img.end(), sch.ltab.begin(), sch.ltab.end());
+  while (img.size() % 64) img.push_back(0.0f);
+  p->c_shared_floats = (int)img.size();
+  p->c_xs_floats = (3 * shift + 32 * nrows + 3) & ~3;
+  const size_t lds = ((size_t)p->c_shared_floats + (size_t)kWWaves * (p->c_xs_floats + kWRegion)) * sizeof(float);
+  if (lds > 160 * 1024 || (p->c_xs_floats >> 8) > 10) return HIPFEAT_OK;
+  const void* fn = nrows == 20 ? fft1024c_entry<20>() : (nrows == 26 ? fft1024c_entry<26>() : fft1024c_entry<32>());
+  hipError_t e = ensure_dynamic_lds(fn, lds);
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft1024c) failed: %s", hipGetErrorName(e));
+  hipfeat_status st;
+  if ((st = upload(&p->d_c_shared, img.data(), img.size())) != HIPFEAT_OK) return st;
+  p->w_nsets = sch.nsets;
+  int total_steps = 0;
+  for (int s2 = 0; s2 < kWMaxSets; ++s2) {
+    p->w_steps[s2] = s2 < sch.nsets ? sch.steps[s2] : 0;
+    p->w_step0[s2] = s2 < sch.nsets ? sch.step0[s2] : 0;
+    total_steps += p->w_steps[s2];
+  }
+  p->nrows = nrows;
+  p->c_rounds = 8;
+  p->fpb = kWWaves * p->c_rounds * 4;
+  p->fast_lds_bytes = lds;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kWWaves, lds) == hipSuccess) p->blocks_per_cu = nb;
+  char nm[128];
+  snprintf(nm, sizeof(nm), "fft1024c_kernel<%d> fbank lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, lds, p->blocks_per_cu, sch.nsets, total_steps);
+  p->kernel_name = nm;
+  p->variant = 8;
+  return HIPFEAT_OK;
+}
+
+// --------------------------------------------------------------------------------------
 // fft256 fast path (kernel_fft256.hpp): 8 kHz 25/10 ms frames, or <= 16 ms frames at 16 kHz
 // --------------------------------------------------------------------------------------
 template <int NROWS, int OUT>
@@ -898,6 +990,8 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   if (st != HIPFEAT_OK) return bail(st);
   st = setup_fft256(p, h_window, h_mel, h_dct, h_lifter);
   if (st != HIPFEAT_OK) return bail(st);
+  st = setup_fft1024c(p, h_window, h_mel);
+  if (st != HIPFEAT_OK) return bail(st);
   st = setup_wave(p, h_mel);
   if (st != HIPFEAT_OK) return bail(st);
 
@@ -1097,6 +1191,39 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)lay->batch), dim3(1024), 0, stream, lay->d_cuts, d_out, lay->out_row_stride,
                        (int32_t)c.num_filters, (int32_t)c.frame_shift);
+    HIP_TRY(hipGetLastError());
+    return HIPFEAT_OK;
+  }
+  if (plan->variant == 8) {
+    Fft1024cParams fp{};
+    fp.wave = d_wave;
+    fp.out = d_out;
+    fp.cuts = lay->d_cuts;
+    fp.shared_consts = plan->d_c_shared;
+    fp.out_stride = lay->out_row_stride;
+    fp.num_cuts = (int32_t)lay->batch;
+    fp.uniform_bpc = lay->uniform_bpc;
+    fp.frames_per_block = plan->fpb;
+    fp.rounds = plan->c_rounds;
+    fp.N = c.frame_length;
+    fp.shift = c.frame_shift;
+    fp.npad_left = plan->npad_left;
+    fp.M = c.num_filters;
+    fp.flags = c.remove_dc_offset ? F_REMOVE_DC : 0;
+    fp.preemph = c.preemph_coeff;
+    fp.mel_floor = c.mel_floor;
+    fp.shared_floats = plan->c_shared_floats;
+    fp.wtab_off = plan->c_wtab_off;
+    fp.ltab_off = plan->c_ltab_off;
+    fp.xs_floats = plan->c_xs_floats;
+    fp.nsets = plan->w_nsets;
+    for (int s2 = 0; s2 < kWMaxSets; ++s2) fp.steps[s2] = plan->w_steps[s2], fp.step0[s2] = plan->w_step0[s2];
+    DeviceGuard g(plan->device);
+    const dim3 grid((unsigned)lay->total_blocks), block(64 * kWWaves);
+    set_lds_poison(plan->fast_lds_bytes);
+    if (plan->nrows == 20) hipLaunchKernelGGL(fft1024c_kernel<20>, grid, block, plan->fast_lds_bytes, stream, fp);
+    else if (plan->nrows == 26) hipLaunchKernelGGL(fft1024c_kernel<26>, grid, block, plan->fast_lds_bytes, stream, fp);
+    else hipLaunchKernelGGL(fft1024c_kernel<32>, grid, block, plan->fast_lds_bytes, stream, fp);
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }
