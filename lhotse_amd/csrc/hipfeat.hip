@@ -533,8 +533,9 @@ static const void* fft1024c_entry() {
 static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, const float* h_mel) {
   const hipfeat_config& c = p->cfg;
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
-  if (p->variant != 0 || c.kind != HIPFEAT_FBANK || c.fft_length != 1024 || (shift & 1) || N < 32 * 17 || c.use_energy || c.use_fft_mag ||
-      getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_AUTONOMOUS"))
+  const bool librosa = c.kind == HIPFEAT_LIBROSA_FBANK;  // centred frames, |X| or |X|^2, log10 (librosa_fbank.py:66-137)
+  if (p->variant != 0 || (c.kind != HIPFEAT_FBANK && !librosa) || c.fft_length != 1024 || (shift & 1) || N < 32 * 17 || c.use_energy ||
+      (c.use_fft_mag && !librosa) || getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_AUTONOMOUS"))
     return HIPFEAT_OK;
   const int need = (N + 31) / 32;
   const int nrows = need <= 20 ? 20 : (need <= 26 ? 26 : 32);
@@ -1209,7 +1210,7 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.shift = c.frame_shift;
     fp.npad_left = plan->npad_left;
     fp.M = c.num_filters;
-    fp.flags = c.remove_dc_offset ? F_REMOVE_DC : 0;
+    fp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0) | (c.use_fft_mag ? F_FFT_MAG : 0) | (c.kind == HIPFEAT_LIBROSA_FBANK ? (F_CENTER | F_LOG10) : 0);
     fp.preemph = c.preemph_coeff;
     fp.mel_floor = c.mel_floor;
     fp.shared_floats = plan->c_shared_floats;

@@ -87,6 +87,8 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
   float* xs = smem + p.shared_floats + wv * (p.xs_floats + kWRegion);
   float* myreg = xs + p.xs_floats;
   const bool dc = (p.flags & F_REMOVE_DC) != 0;
+  const bool mag = (p.flags & F_FFT_MAG) != 0;
+  const float log_scale = (p.flags & F_LOG10) ? 0.30102999566398120f : 0.69314718055994531f;  // log2 -> log10 / ln
   const float inv_n = 1.0f / (float)N;
   const float c = p.preemph;
 
@@ -105,7 +107,10 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)nfull * 1024u + 4u * lane4)),
                                          (__attribute__((address_space(3))) void*)(xs + nfull * 256), 16, 0, 0);
     } else {
-      for (int i = (int)(lane4 >> 2); i < p.xs_floats; i += 64) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
+      if (p.flags & F_CENTER)  // torch.stft / librosa "reflect" padding (the edge sample is not repeated)
+        for (int i = (int)(lane4 >> 2); i < p.xs_floats; i += 64) xs[i] = load_sample_center(w, j0 + i, cd.num_samples);
+      else
+        for (int i = (int)(lane4 >> 2); i < p.xs_floats; i += 64) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
     }
   };
 
@@ -254,12 +259,14 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
           const v2 dm = m * HF_NCJ + zk;
           const v2 tt = cmul2(dm, tw[rr]);
           const v2 xp = sp + tt, xm = sp - tt;
+          float va = xp.x * xp.x + xp.y * xp.y, vb = xm.x * xm.x + xm.y * xm.y;
+          if (mag) va = __builtin_amdgcn_sqrtf(va), vb = __builtin_amdgcn_sqrtf(vb);  // |X| (librosa-style filterbanks)
           if (s <= 8) {
-            pA[32 * s] = xp.x * xp.x + xp.y * xp.y;
-            pB[-32 * s] = xm.x * xm.x + xm.y * xm.y;
+            pA[32 * s] = va;
+            pB[-32 * s] = vb;
           } else {
-            pA2[32 * s] = xp.x * xp.x + xp.y * xp.y;
-            pB2[-32 * s] = xm.x * xm.x + xm.y * xm.y;
+            pA2[32 * s] = va;
+            pB2[-32 * s] = vb;
           }
         }
       }
@@ -270,9 +277,11 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
         const v2 dm = m * HF_NCJ + zk;
         const v2 tt = cmul2(dm, tw);
         const v2 xp = sp + tt, xm = sp - tt;
+        float va = xp.x * xp.x + xp.y * xp.y, vb = xm.x * xm.x + xm.y * xm.y;
+        if (mag) va = __builtin_amdgcn_sqrtf(va), vb = __builtin_amdgcn_sqrtf(vb);
         if (q == 0) {
-          prow[240] = xp.x * xp.x + xp.y * xp.y;
-          prow[272] = xm.x * xm.x + xm.y * xm.y;
+          prow[240] = va;
+          prow[272] = vb;
         }
       }
     }
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
           float v = acc[i];
           v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4
           v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8
-          v = fast_log(fmaxf(v, p.mel_floor));
+          v = __builtin_amdgcn_logf(fmaxf(v, p.mel_floor)) * log_scale;
           if (col < p.M && i < nf) orow[i * p.out_stride + col] = v;
         }
       }

@@ -1,4 +1,5 @@
-"""GPU: HipLibrosaFbank (kind HIPFEAT_LIBROSA_FBANK: wave_kernel for power-of-two FFT sizes, generic_kernel otherwise)
+"""GPU: HipLibrosaFbank (kind HIPFEAT_LIBROSA_FBANK: fft1024c_kernel for n_fft 1024 with an even hop, wave_kernel for the other power-of-two FFT sizes,
+generic_kernel otherwise)
 against goldens produced by the reference's LibrosaFbank.extract (librosa's stft / mel restated, see
 oracle/librosa_ref.py) and against the oracle on seeded inputs.
 
@@ -46,7 +47,7 @@ def test_hip_librosa_matches_reference_golden(case):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     ex = LA.HipLibrosaFbank(_cfg(over))
     fft = over.get("fft_size", 1024)
-    assert ("wave_kernel" in ex.kernel_name) == (fft & (fft - 1) == 0), ex.kernel_name
+    assert ("wave_kernel" in ex.kernel_name or "fft1024c_kernel" in ex.kernel_name) == (fft & (fft - 1) == 0), ex.kernel_name
     for i, (kind, n, seed) in enumerate(inputs):
         x = make_signal(kind, n, seed)
         assert crc(x) == int(z[f"crc{i}"])
@@ -60,7 +61,7 @@ def test_hip_librosa_matches_reference_golden(case):
 @pytest.mark.parametrize(
     "over,kernel",
     [
-        ({}, "wave_kernel<8>"),
+        ({}, "fft1024c_kernel<32>"),  # the librosa defaults (22.05 kHz, n_fft 1024, hop 256): wave-autonomous kernel
         ({"sampling_rate": 16000, "fft_size": 512, "hop_size": 128, "num_mel_bins": 64, "fmin": 20, "fmax": None}, "wave_kernel<4>"),
         ({"sampling_rate": 44100, "fft_size": 2048, "hop_size": 512, "win_length": 1764, "num_mel_bins": 128, "fmin": 0, "fmax": 16000}, "wave_kernel<16>"),
         ({"sampling_rate": 16000, "fft_size": 400, "hop_size": 160, "num_mel_bins": 80, "fmin": 0, "fmax": 8000}, "generic"),
@@ -92,16 +93,25 @@ def test_configs_and_ragged_batches_against_the_oracle(over, kernel):
         _close(o, L.logmelfilterbank(p.astype(np.float32) / 32768.0, **okw), (kernel, "pcm16"))
 
 
-def test_wave_and_generic_kernels_agree(monkeypatch):
+def test_the_three_kernels_agree(monkeypatch):
+    """librosa defaults on the wave-autonomous fft1024 kernel, the wave-per-frame kernel and the generic kernel."""
     x = make_signal("speechlike", 66150, 3)
-    a = LA.HipLibrosaFbank().extract(x, 22050)
+    fast = LA.HipLibrosaFbank()
+    assert "fft1024c_kernel" in fast.kernel_name
+    a = fast.extract(x, 22050)
+    monkeypatch.setenv("HIPFEAT_NO_WAVE_AUTONOMOUS", "1")
+    wv = LA.HipLibrosaFbank()
+    assert "wave_kernel" in wv.kernel_name
+    c = wv.extract(x, 22050)
     monkeypatch.setenv("HIPFEAT_NO_WAVE_KERNEL", "1")
     g = LA.HipLibrosaFbank()
     assert "generic" in g.kernel_name
     b = g.extract(x, 22050)
     monkeypatch.delenv("HIPFEAT_NO_WAVE_KERNEL")
+    monkeypatch.delenv("HIPFEAT_NO_WAVE_AUTONOMOUS")
     want = L.logmelfilterbank(x)
-    _close(a, want, "wave")
+    _close(a, want, "fft1024c")
+    _close(c, want, "wave")
     _close(b, want, "generic")
 
 
