@@ -36,10 +36,12 @@ from .signal_transforms import HipGlobalMVN, HipSpecAugment  # noqa: F401,E402
 
 from .layers import HipWav2LogFilterBank, HipWav2LogSpec, HipWav2MFCC, HipWav2Spec  # noqa: F401,E402
 
-from .storage import compute_and_store_features_batch  # noqa: F401,E402
+from .storage import HipArchiveReader, HipArchiveWriter, compute_and_store_features_batch  # noqa: F401,E402
 
 __all__ = [
     "compute_and_store_features_batch",
+    "HipArchiveWriter",
+    "HipArchiveReader",
     "HipWhisperFbank",
     "HipLibrosaFbank",
     "HipGlobalMVN",

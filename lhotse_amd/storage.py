@@ -1,35 +1,232 @@
 """
-Bulk save path for the batch feature-extraction driver.
+Bulk save path for batch feature extraction.
 
-``compute_and_store_features_batch`` below is ``CutSet.compute_and_store_features_batch`` (lhotse/cut/set.py:2197-2408)
-with the same arguments, storage formats, manifests and resume semantics -- it drives the same ``SimpleCutSampler`` /
-``UnsupervisedWaveformDataset`` / ``DataLoader`` and the same ``FeaturesWriter`` classes -- but with the per-cut overheads of
-``_save_worker`` (:2307-2363) taken out of the way of a GPU extractor that is ~1000x faster than the CPU one it was written
-for:
+lhotse's ``CutSet.compute_and_store_features_batch`` (lhotse/cut/set.py:2197-2408) was written around a CPU extractor: its
+``_save_worker`` (:2307-2363) stores one object per cut through a ``FeaturesWriter`` (one file open / one HDF5 dataset
+per cut), builds a ``Features`` dataclass, validates it, ``fastcopy``-s the cut and serialises it with a recursive
+``dataclasses.asdict`` (≈0.5 ms per cut in all).  Behind a GPU extractor that produces a 600 s batch in 0.2 ms this is
+what a run spends its time in.  This module is a different design for the same job, in three pieces:
 
-  * ONE device-to-host transfer per batch (the packed feature matrix) instead of ``feat_mat.cpu().numpy()`` per cut;
-  * array writes of a batch go through a small thread pool when the writer stores one object per key
-    (``numpy_files``: independent files) -- manifests are still emitted strictly in input order;
-  * the cut manifest is flushed once per batch instead of once per cut.
+``HipArchiveWriter`` / ``HipArchiveReader`` -- a storage backend registered with lhotse as ``"hip_archive"``
+    (``lhotse/features/io.py:288-337``): ONE flat file of little-endian float32 rows per run.  A whole batch is appended
+    with one ``write`` (the packed ``(sum T_b, F)`` matrix exactly as it leaves the device); the storage key of a cut is
+    self-describing -- ``"<byte offset>:<rows>:<cols>"`` -- so there is no index to maintain and the reader is a
+    positioned read (sub-ranges of frames read only their own bytes).  ``Features.load()`` / ``cut.load_features()`` work
+    through lhotse's registry as for any other backend.
 
-Needs lhotse (it produces lhotse manifests); importing this module without lhotse works, calling the function does not.
+manifest templates -- the output manifest of a ``MonoCut`` is assembled as a plain dict from parts that are serialised once
+    (the recording, the constant ``Features`` fields) instead of dataclass -> copy -> recursive ``asdict`` per cut;
+    ``SequentialJsonlWriter.write`` accepts dicts (``lhotse/serialization.py:236-252``).  Other cut types go through
+    lhotse's own objects.  The frame-count contract that ``validate_features`` asserts (``lhotse/qa.py:286-301``) is
+    checked for the whole batch at once.
+
+``compute_and_store_features_batch`` -- the driver: lhotse's sampler + ``UnsupervisedWaveformDataset`` + ``DataLoader`` load
+    the audio (in ``num_workers`` processes), the extractor runs on the main thread, and one background thread appends the
+    batch to the archive and emits the manifests, in input order.  Same arguments and resume semantics as the method it
+    replaces; any registered ``FeaturesWriter`` can be passed as ``storage_type`` (per-cut ``write`` calls then).
+
+Measured with an instant extractor on 3000 one-second cuts (``tools/bench_storage.py``): see DESIGN.md section 4.4b.
 On-GPU lossy compression in the style of lilcom is NOT provided: lilcom is a third-party codec that is not available
 offline, so its bit stream cannot be pinned.
 """
 from __future__ import annotations
 
+import os
+import threading
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
 from .compat import HAVE_LHOTSE
 
+ARCHIVE_SUFFIX = ".hfa"
 
-def _batch_features_on_host(extractor, waves, sampling_rate: int, lengths) -> List[np.ndarray]:
-    """Per-cut feature matrices as numpy views of ONE host array (one D2H for Hip* extractors)."""
+
+def _archive_path(storage_path) -> Path:
+    p = Path(storage_path)
+    return p if p.suffix == ARCHIVE_SUFFIX else p.with_suffix(p.suffix + ARCHIVE_SUFFIX) if p.suffix else p.with_suffix(ARCHIVE_SUFFIX)
+
+
+def _parse_key(key: str) -> Tuple[int, int, int]:
+    off, rows, cols = key.split(":")
+    return int(off), int(rows), int(cols)
+
+
+class _ArchiveWriterImpl:
+    """Append-only flat file of float32 rows; keys are ``"<byte offset>:<rows>:<cols>"``."""
+
+    name = "hip_archive"
+
+    def __init__(self, storage_path, mode: str = "w", *args, **kwargs):
+        assert mode in ("w", "a"), mode
+        self._path = _archive_path(storage_path)
+        self._path.parent.mkdir(parents=True, exist_ok=True)
+        self._file = open(self._path, "wb" if mode == "w" else "ab")
+        self._offset = self._file.seek(0, os.SEEK_END)
+        self._lock = threading.Lock()
+
+    @property
+    def storage_path(self) -> str:
+        return str(self._path)
+
+    def write(self, key: str, value: np.ndarray) -> str:
+        value = np.ascontiguousarray(value, dtype="<f4")
+        assert value.ndim == 2, value.shape
+        return self.write_packed(value, [value.shape[0]])[0]
+
+    def write_packed(self, matrix: np.ndarray, frames: Sequence[int]) -> List[str]:
+        """Append the packed ``(sum(frames), F)`` matrix of a batch with ONE write; returns one key per item."""
+        matrix = np.ascontiguousarray(matrix, dtype="<f4")
+        cols = int(matrix.shape[1])
+        assert int(sum(frames)) == matrix.shape[0], (sum(frames), matrix.shape)
+        with self._lock:
+            base = self._offset
+            self._file.write(memoryview(matrix).cast("B"))
+            self._offset += matrix.nbytes
+        keys, off = [], base
+        for t in frames:
+            keys.append(f"{off}:{int(t)}:{cols}")
+            off += int(t) * cols * 4
+        return keys
+
+    def flush(self):
+        self._file.flush()
+
+    def close(self):
+        if self._file is not None:
+            self._file.close()
+            self._file = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args, **kwargs):
+        self.close()
+
+
+class _ArchiveReaderImpl:
+    name = "hip_archive"
+
+    def __init__(self, storage_path, *args, **kwargs):
+        self._path = _archive_path(storage_path)
+        self._fd = None
+        self._lock = threading.Lock()
+
+    def read(self, key: str, left_offset_frames: int = 0, right_offset_frames: Optional[int] = None) -> np.ndarray:
+        off, rows, cols = _parse_key(key)
+        lo = max(0, int(left_offset_frames))
+        hi = rows if right_offset_frames is None else min(rows, int(right_offset_frames))
+        n = max(0, hi - lo)
+        out = np.empty((n, cols), dtype="<f4")
+        if n:
+            with self._lock:
+                if self._fd is None:
+                    self._fd = os.open(self._path, os.O_RDONLY)
+            got = os.preadv(self._fd, [memoryview(out).cast("B")], off + lo * cols * 4)
+            if got != out.nbytes:
+                raise IOError(f"{self._path}: short read for key {key!r} ({got} of {out.nbytes} bytes)")
+        return out
+
+    def __del__(self):
+        try:
+            if self._fd is not None:
+                os.close(self._fd)
+        except Exception:
+            pass
+
+
+if HAVE_LHOTSE:
+    from lhotse.features.io import FeaturesReader, FeaturesWriter, register_reader, register_writer
+
+    @register_writer
+    class HipArchiveWriter(_ArchiveWriterImpl, FeaturesWriter):
+        """Registered with lhotse as storage backend ``"hip_archive"`` (writer side)."""
+
+        name = "hip_archive"
+
+    @register_reader
+    class HipArchiveReader(_ArchiveReaderImpl, FeaturesReader):
+        """Registered with lhotse as storage backend ``"hip_archive"`` (reader side)."""
+
+        name = "hip_archive"
+
+else:  # usable on their own (tests, tools) without lhotse
+
+    class HipArchiveWriter(_ArchiveWriterImpl):
+        pass
+
+    class HipArchiveReader(_ArchiveReaderImpl):
+        pass
+
+
+# ---- manifest templates ---------------------------------------------------------------------------------------------------
+def _features_dict(template: Dict, cut, num_frames: int, storage_key: str) -> Dict:
+    """``Features(...).to_dict()`` (lhotse/features/base.py:444-474, asdict_nonull field order) without the dataclass."""
+    d = dict(template)  # type, num_features, frame_shift, sampling_rate, storage_type, storage_path in dataclass order
+    d["num_frames"] = int(num_frames)
+    d["sampling_rate"] = cut.sampling_rate
+    d["start"] = cut.start
+    d["duration"] = cut.duration
+    d["storage_key"] = storage_key
+    return d
+
+
+def _nonull(obj):
+    """``lhotse.utils.asdict_nonull`` (lhotse/utils.py:166-182) for manifests whose leaves are JSON scalars: the same
+    recursion over dataclass fields, lists and dicts, dropping None fields -- without ``dataclasses.asdict``'s deep copy of
+    every leaf, which is where the reference spends most of a cut's serialisation."""
+    fields = getattr(obj, "__dataclass_fields__", None)
+    if fields is not None:
+        out = {}
+        for name in fields:
+            v = getattr(obj, name)
+            if v is not None:
+                out[name] = _nonull(v)
+        return out
+    if isinstance(obj, (list, tuple)):
+        return [_nonull(v) for v in obj]
+    if isinstance(obj, dict):
+        return {k: _nonull(v) for k, v in obj.items()}
+    return obj
+
+
+def _recording_dict(rec) -> Dict:
+    if getattr(rec, "transforms", None) is not None:
+        return rec.to_dict()  # transforms may be objects with their own to_dict (lhotse/audio/recording.py:365-371)
+    return _nonull(rec)
+
+
+_FEATURE_FIELD_ORDER = ("type", "num_frames", "num_features", "frame_shift", "sampling_rate", "start", "duration", "storage_type",
+                        "storage_path", "storage_key", "recording_id", "channels")
+
+
+def _mono_cut_dict(cut, feats: Dict, rec_cache: Dict[int, Dict]) -> Optional[Dict]:
+    """``fastcopy(cut, features=Features(...)).to_dict()`` for a MonoCut (lhotse/cut/data.py:90-98) assembled from parts; the
+    recording's dict is built once per Recording object.  None = leave this cut to lhotse's own serialiser."""
+    if cut.custom is not None:
+        return None  # custom fields may hold nested manifests
+    feats = dict(feats)
+    feats["recording_id"] = cut.recording_id
+    feats["channels"] = cut.channel
+    feats = {k: feats[k] for k in _FEATURE_FIELD_ORDER if feats.get(k) is not None}
+    d = {"id": cut.id, "start": cut.start, "duration": cut.duration, "channel": cut.channel}
+    d["supervisions"] = [_nonull(s) if s.custom is None and s.alignment is None else s.to_dict() for s in cut.supervisions]
+    d["features"] = feats
+    rec = cut.recording
+    if rec is not None:
+        rd = rec_cache.get(id(rec))
+        if rd is None:
+            rd = rec_cache[id(rec)] = _recording_dict(rec)
+        d["recording"] = rd
+    d["type"] = "MonoCut"
+    return d
+
+
+def _batch_features_on_host(extractor, waves, sampling_rate: int, lengths) -> Tuple[np.ndarray, List[int]]:
+    """Packed ``(sum T_b, F)`` host matrix + per-cut frame counts (one D2H transfer for the Hip* extractors)."""
     if lengths is None and hasattr(extractor, "_extract_items") and hasattr(extractor, "_to_host"):
         from .extractors import _as_1d_float
 
@@ -40,12 +237,13 @@ def _batch_features_on_host(extractor, waves, sampling_rate: int, lengths) -> Li
         with torch.no_grad():
             packed, frames = extractor._extract_items(items, pmax)
             host = extractor._to_host(packed).numpy()
-        bounds = np.concatenate([[0], np.cumsum(frames)])
-        return [host[int(bounds[i]) : int(bounds[i + 1])] for i in range(len(frames))]
-    feats = extractor.extract_batch(waves, sampling_rate=sampling_rate, lengths=lengths)
+        return host, [int(t) for t in frames]
+    with torch.no_grad():
+        feats = extractor.extract_batch(waves, sampling_rate=sampling_rate, lengths=lengths)
     if isinstance(feats, (np.ndarray, torch.Tensor)) and feats.ndim == 2:
         feats = [feats]
-    return [f.cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in feats]
+    mats = [f.cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f) for f in feats]
+    return (np.concatenate(mats, axis=0) if len(mats) != 1 else mats[0]), [int(m.shape[0]) for m in mats]
 
 
 def compute_and_store_features_batch(
@@ -59,102 +257,78 @@ def compute_and_store_features_batch(
     augment_fn: Optional[Callable] = None,
     storage_type=None,
     overwrite: bool = False,
-    save_threads: int = 8,
 ):
-    """Drop-in for ``CutSet.compute_and_store_features_batch`` (same arguments plus ``save_threads``); returns the CutSet
-    with ``Features`` manifests attached."""
+    """``CutSet.compute_and_store_features_batch`` with the bulk save path of this module (same arguments; ``storage_type``
+    defaults to ``HipArchiveWriter``).  Returns the CutSet with the ``Features`` manifests attached."""
     if not HAVE_LHOTSE:
         raise ImportError("compute_and_store_features_batch produces lhotse manifests: install lhotse")
     from lhotse import CutSet, Features, MonoCut
     from lhotse.cut import MixedCut, PaddingCut
-    from lhotse.cut.data import DataCut
     from lhotse.dataset import SimpleCutSampler, UnsupervisedWaveformDataset
     from lhotse.qa import validate_features
-    from lhotse.utils import fastcopy
+    from lhotse.utils import compute_num_frames, fastcopy
     from torch.utils.data import DataLoader
 
-    try:
-        from lhotse.features.io import default_features_storage_backend  # newer lhotse
-    except ImportError:  # pragma: no cover
-        default_features_storage_backend = None
-    if storage_type is None:
-        if default_features_storage_backend is not None:
-            storage_type = default_features_storage_backend()
-        else:  # pragma: no cover
-            from lhotse.features.io import NumpyFilesWriter as storage_type
-    if storage_type.name == "numpy_files":
-        storage_path = Path(storage_path)
-        if storage_path.exists() and storage_path.is_file():
-            storage_path = storage_path.with_name(f"{storage_path.name}_storage")
+    storage_type = storage_type or HipArchiveWriter
     frame_shift = extractor.frame_shift
-    cuts_writer = CutSet.open_writer(manifest_path, overwrite=overwrite)
+    manifest = CutSet.open_writer(manifest_path, overwrite=overwrite)
     sampler = SimpleCutSampler(cuts, max_duration=batch_duration)
-    sampler.filter(lambda cut: cut.id not in cuts_writer.ignore_ids)
-    dataset = UnsupervisedWaveformDataset(collate=collate)
-    dloader = DataLoader(dataset, batch_size=None, sampler=sampler, num_workers=num_workers)
-    parallel_writes = storage_type.name == "numpy_files" and save_threads > 1
+    sampler.filter(lambda cut: cut.id not in manifest.ignore_ids)  # resume: skip what the manifest already holds
+    loader = DataLoader(UnsupervisedWaveformDataset(collate=collate), batch_size=None, sampler=sampler, num_workers=num_workers)
+    rec_cache: Dict[int, Dict] = {}
 
-    def _save_batch(batch_cuts: Sequence, feats: List[np.ndarray], pool: Optional[ThreadPoolExecutor]) -> None:
-        todo = [(i, c) for i, c in enumerate(batch_cuts) if not isinstance(c, PaddingCut)]
-        if pool is not None:
-            keys = dict(zip((i for i, _ in todo), pool.map(lambda ic: feats_writer.write(ic[1].id, feats[ic[0]]), todo)))
+    def save(writer, batch_cuts, host: np.ndarray, frames: List[int], template: Dict) -> None:
+        # the frame-count contract of validate_features (qa.py:286-301), for the whole batch
+        for c, t in zip(batch_cuts, frames):
+            if not isinstance(c, PaddingCut) and compute_num_frames(c.duration, frame_shift, c.sampling_rate) != t:
+                raise AssertionError(f"cut {c.id}: {t} frames for {c.duration} s at frame_shift {frame_shift} (lhotse expects "
+                                     f"{compute_num_frames(c.duration, frame_shift, c.sampling_rate)})")
+        stored = [i for i, c in enumerate(batch_cuts) if not isinstance(c, PaddingCut)]
+        bounds = np.concatenate([[0], np.cumsum(frames)])
+        if hasattr(writer, "write_packed") and len(stored) == len(batch_cuts):
+            keys = writer.write_packed(host, frames)
         else:
-            keys = {i: feats_writer.write(c.id, feats[i]) for i, c in todo}
-        for i, cut in enumerate(batch_cuts):
-            feat_mat = feats[i]
-            if isinstance(cut, PaddingCut):
-                cuts_writer.write(fastcopy(cut, num_frames=feat_mat.shape[0], num_features=feat_mat.shape[1], frame_shift=frame_shift))
+            keys = [None] * len(batch_cuts)
+            for i in stored:
+                keys[i] = writer.write(batch_cuts[i].id, host[int(bounds[i]) : int(bounds[i + 1])])
+        for i, c in enumerate(batch_cuts):
+            if isinstance(c, PaddingCut):
+                manifest.write(fastcopy(c, num_frames=frames[i], num_features=host.shape[1], frame_shift=frame_shift))
                 continue
-            feat_manifest = Features(
-                start=cut.start,
-                duration=cut.duration,
-                type=extractor.name,
-                num_frames=feat_mat.shape[0],
-                num_features=feat_mat.shape[1],
-                frame_shift=frame_shift,
-                sampling_rate=cut.sampling_rate,
-                channels=cut.channel,
-                storage_type=feats_writer.name,
-                storage_path=str(feats_writer.storage_path),
-                storage_key=keys[i],
-            )
-            validate_features(feat_manifest, feats_data=feat_mat)
-            if isinstance(cut, DataCut):
-                feat_manifest.recording_id = cut.recording_id
-                cut = fastcopy(cut, features=feat_manifest)
-            if isinstance(cut, MixedCut):
-                feat_manifest.recording_id = cut.id
-                cut = MonoCut(
-                    id=cut.id,
-                    start=0,
-                    duration=cut.duration,
-                    channel=0,
-                    supervisions=[fastcopy(s, recording_id=cut.id, channel=0) for s in cut.supervisions],
-                    features=feat_manifest,
-                    recording=None,
-                )
-            cuts_writer.write(cut, flush=False)
-        # one flush per batch (the reference flushes after every cut, cut/set.py:2363)
-        if getattr(cuts_writer, "file", None) is not None:
-            cuts_writer.file.flush()
+            fd = _features_dict(template, c, frames[i], keys[i])
+            out = _mono_cut_dict(c, fd, rec_cache) if type(c) is MonoCut else None
+            if out is None:  # mixed cuts, custom fields: lhotse's own objects (lhotse/cut/set.py:2335-2363)
+                fm = Features(recording_id=c.id if isinstance(c, MixedCut) else c.recording_id, channels=0 if isinstance(c, MixedCut) else c.channel,
+                              **{k: v for k, v in fd.items()})
+                validate_features(fm)
+                if isinstance(c, MixedCut):
+                    out = MonoCut(id=c.id, start=0, duration=c.duration, channel=0, features=fm, recording=None,
+                                  supervisions=[fastcopy(s, recording_id=c.id, channel=0) for s in c.supervisions])
+                else:
+                    out = fastcopy(c, features=fm)
+            manifest.write(out)
+        if hasattr(writer, "flush"):
+            writer.flush()
+        if getattr(manifest, "file", None) is not None:
+            manifest.file.flush()  # one flush per batch
 
     futures = []
-    with cuts_writer, storage_type(storage_path, mode="w" if overwrite else "a") as feats_writer, ThreadPoolExecutor(max_workers=1) as saver:
-        pool = ThreadPoolExecutor(max_workers=save_threads) if parallel_writes else None
-        try:
-            for batch in dloader:
-                batch_cuts, waves = batch["cuts"], batch["audio"]
-                wave_lens = batch["audio_lens"] if collate else None
-                if len(batch_cuts) == 0:
-                    continue
-                assert all(c.sampling_rate == batch_cuts[0].sampling_rate for c in batch_cuts)
-                if augment_fn is not None:
-                    waves = [augment_fn(w, c.sampling_rate) for c, w in zip(batch_cuts, waves)]
-                feats = _batch_features_on_host(extractor, waves, batch_cuts[0].sampling_rate, wave_lens)
-                futures.append(saver.submit(_save_batch, list(batch_cuts), feats, pool))
-            for f in futures:
-                f.result()
-        finally:
-            if pool is not None:
-                pool.shutdown()
-    return cuts_writer.open_manifest()
+    with manifest, storage_type(storage_path, mode="w" if overwrite else "a") as writer, ThreadPoolExecutor(max_workers=1) as saver:
+        template = None
+        for batch in loader:
+            batch_cuts, waves = batch["cuts"], batch["audio"]
+            lens = batch["audio_lens"] if collate else None
+            if len(batch_cuts) == 0:
+                continue
+            sr = batch_cuts[0].sampling_rate
+            assert all(c.sampling_rate == sr for c in batch_cuts)
+            if augment_fn is not None:
+                waves = [augment_fn(w, c.sampling_rate) for c, w in zip(batch_cuts, waves)]
+            host, frames = _batch_features_on_host(extractor, waves, sr, lens)
+            if template is None:
+                template = {"type": extractor.name, "num_features": int(host.shape[1]), "frame_shift": frame_shift, "sampling_rate": sr,
+                            "storage_type": writer.name, "storage_path": str(writer.storage_path)}
+            futures.append(saver.submit(save, writer, list(batch_cuts), host, frames, template))
+        for f in futures:
+            f.result()
+    return manifest.open_manifest()

@@ -311,33 +311,69 @@ def test_fused_on_the_fly_features_equal_the_reference_strategy(cutset, cpu_devi
 
 
 def test_bulk_save_driver_equals_the_reference_driver(tmp_path, cutset, cpu_device):
-    """lhotse_amd.compute_and_store_features_batch (one D2H per batch, threaded array writes, one manifest flush per
-    batch) must produce what CutSet.compute_and_store_features_batch produces: same cuts in the same order, same
-    Features manifests, same stored arrays; and it must resume like the reference."""
+    """lhotse_amd.compute_and_store_features_batch (packed archive backend, template manifests, one flush per batch) must
+    describe and store what CutSet.compute_and_store_features_batch does: same cuts in the same order, the same Features
+    fields (up to where the bytes live), the same arrays through cut.load_features() -- and it must resume like the reference."""
     import lhotse_amd as LA
     from lhotse import CutSet, NumpyFilesWriter
+    from lhotse.features.io import get_reader, get_writer
 
+    assert get_writer("hip_archive") is LA.HipArchiveWriter and get_reader("hip_archive") is LA.HipArchiveReader
     ex = LA.HipFbank()
     ref = cutset.compute_and_store_features_batch(extractor=ex, storage_path=tmp_path / "ref", manifest_path=tmp_path / "ref.jsonl.gz",
                                                   batch_duration=3.0, num_workers=0, storage_type=NumpyFilesWriter)
     ours = LA.compute_and_store_features_batch(cutset, extractor=ex, storage_path=tmp_path / "ours", manifest_path=tmp_path / "ours.jsonl.gz",
-                                               batch_duration=3.0, num_workers=0, storage_type=NumpyFilesWriter, save_threads=4)
+                                               batch_duration=3.0, num_workers=0)
     ref, ours = list(ref), list(ours)
     assert [c.id for c in ours] == [c.id for c in ref] and len(ours) == 5
     for a, b in zip(ours, ref):
         fa, fb = a.features, b.features
-        assert (fa.type, fa.num_frames, fa.num_features, fa.frame_shift, fa.sampling_rate, fa.start, fa.duration, fa.storage_type, fa.storage_key,
-                fa.recording_id, fa.channels) == (fb.type, fb.num_frames, fb.num_features, fb.frame_shift, fb.sampling_rate, fb.start, fb.duration,
-                                                  fb.storage_type, fb.storage_key, fb.recording_id, fb.channels)
+        assert fa.storage_type == "hip_archive" and fa.storage_path.endswith(".hfa")
+        assert (fa.type, fa.num_frames, fa.num_features, fa.frame_shift, fa.sampling_rate, fa.start, fa.duration, fa.recording_id, fa.channels) == (
+            fb.type, fb.num_frames, fb.num_features, fb.frame_shift, fb.sampling_rate, fb.start, fb.duration, fb.recording_id, fb.channels)
         assert np.array_equal(a.load_features(), b.load_features())
-    # resume: everything is already in the manifest -> nothing is recomputed, same manifest comes back
+        # the template-built manifest is the dict lhotse's own objects serialise to
+        da, db = a.to_dict(), b.to_dict()
+        for k in ("storage_type", "storage_path", "storage_key"):
+            da["features"].pop(k), db["features"].pop(k)
+        assert da == db
+        # partial reads (left / right frame offsets) read only their own rows
+        full = a.load_features()
+        part = a.features.load(start=a.start + 0.2, duration=0.3)
+        assert np.array_equal(part, full[20:50])
+    # resume: everything is already in the manifest -> nothing is recomputed, same manifest comes back, archive untouched
+    size = os.path.getsize(ours[0].features.storage_path)
     again = LA.compute_and_store_features_batch(cutset, extractor=ex, storage_path=tmp_path / "ours", manifest_path=tmp_path / "ours.jsonl.gz",
-                                                batch_duration=3.0, num_workers=0, storage_type=NumpyFilesWriter)
-    assert [c.id for c in again] == [c.id for c in ours]
-    # in-memory manifests, collated batches, the reference's own extractor as a fallback path
+                                                batch_duration=3.0, num_workers=0)
+    assert [c.id for c in again] == [c.id for c in ours] and os.path.getsize(ours[0].features.storage_path) == size
+    # any registered writer still works (per-cut writes), in-memory manifests, collated batches
     mem = LA.compute_and_store_features_batch(cutset, extractor=ex, storage_path=tmp_path / "mem", batch_duration=100.0, num_workers=0,
                                               collate=True, storage_type=NumpyFilesWriter, overwrite=True)
-    assert len(list(mem)) == 5 and all(c.has_features for c in mem)
+    mem = list(mem)
+    assert len(mem) == 5 and all(c.has_features for c in mem)
+    for a, b in zip(mem, ref):
+        assert a.features.storage_type == "numpy_files" and np.allclose(a.load_features(), b.load_features(), atol=2e-3)
+
+
+def test_archive_backend_round_trip_without_lhotse_objects(tmp_path):
+    """The archive itself: packed batch appends, self-describing keys, positioned partial reads, append mode."""
+    import lhotse_amd as LA
+
+    rs = np.random.RandomState(0)
+    mats = [rs.rand(t, 7).astype(np.float32) for t in (5, 1, 40, 13)]
+    with LA.HipArchiveWriter(tmp_path / "feats") as w:
+        k0 = w.write("a", mats[0])
+        ks = w.write_packed(np.concatenate(mats[1:]), [m.shape[0] for m in mats[1:]])
+        path = w.storage_path
+    assert path.endswith(".hfa") and os.path.getsize(path) == sum(m.nbytes for m in mats)
+    r = LA.HipArchiveReader(tmp_path / "feats")
+    for k, m in zip([k0] + ks, mats):
+        assert np.array_equal(r.read(k), m)
+    assert np.array_equal(r.read(ks[1], left_offset_frames=3, right_offset_frames=11), mats[2][3:11])
+    assert r.read(ks[1], left_offset_frames=50).shape == (0, 7)
+    with LA.HipArchiveWriter(tmp_path / "feats", mode="a") as w:  # resume appends behind what is there
+        k4 = w.write("e", mats[0] * 2)
+    assert k4.startswith(str(sum(m.nbytes for m in mats)) + ":") and np.array_equal(LA.HipArchiveReader(path).read(k4), mats[0] * 2)
 
 
 LAYER_PAIRS = [("HipWav2Spec", "Wav2Spec"), ("HipWav2LogSpec", "Wav2LogSpec"), ("HipWav2LogFilterBank", "Wav2LogFilterBank"), ("HipWav2MFCC", "Wav2MFCC")]
