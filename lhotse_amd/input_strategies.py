@@ -34,28 +34,23 @@ if HAVE_LHOTSE:  # pragma: no cover - authoring container only
             self.return_device = return_device
 
         def __call__(self, cuts, recording_field: Optional[str] = None):
-            audios, cuts = read_audio_from_cuts(
-                cuts,
-                executor=_get_executor(self.num_workers, executor_type=self._executor_type),
-                suppress_errors=self.fault_tolerant,
-                recording_field=recording_field,
-            )
-            for tfnm in self.wave_transforms:
-                for idx in range(len(audios)):
-                    audios[idx] = tfnm(audios[idx])
-            # one launch for the whole batch: a single sampling rate, as with use_batch_extract=True (:437-443)
-            assert all(c.sampling_rate == cuts[0].sampling_rate for c in cuts)
-            features_batch, feature_lens = self.extractor.extract_collated(audios, sampling_rate=cuts[0].sampling_rate, padding_value=LOG_EPSILON)
-            if self.return_device is not None:
-                features_batch = features_batch.to(self.return_device)
-            out = (features_batch, feature_lens)
-            if self.return_audio:
-                audios = [a.squeeze(0) for a in audios]  # (1, T) -> (T, )
-                audio_lens = torch.tensor([a.shape[0] for a in audios], dtype=torch.int64)
-                out = out + (collate_vectors(audios, padding_value=0), audio_lens)
-            if self.fault_tolerant:
-                out = out + (cuts,)
-            return out
+            """Only the middle step differs from the parent: ``extract_batch`` + ``collate_matrices`` become ONE fused launch
+            (``extract_collated``).  The parent offers no hook between reading the audio and collating the features, so the two
+            ends of its pipeline are invoked here through the same public helpers it uses."""
+            pool = _get_executor(self.num_workers, executor_type=self._executor_type)
+            audios, cuts = read_audio_from_cuts(cuts, executor=pool, suppress_errors=self.fault_tolerant, recording_field=recording_field)
+            for transform in self.wave_transforms:
+                audios = [transform(a) for a in audios]
+            rates = {c.sampling_rate for c in cuts}
+            assert len(rates) == 1, f"one launch per batch needs a single sampling rate, got {sorted(rates)}"
+            feats, feat_lens = self.extractor.extract_collated(audios, sampling_rate=rates.pop(), padding_value=LOG_EPSILON)
+            result = [feats if self.return_device is None else feats.to(self.return_device), feat_lens]
+            if self.return_audio:  # (B, Tmax) zero-padded samples + their lengths, as the parent returns them
+                flat = [a.reshape(-1) for a in audios]
+                result += [collate_vectors(flat, padding_value=0), torch.tensor([len(a) for a in flat], dtype=torch.int64)]
+            if self.fault_tolerant:  # the cuts that survived audio loading
+                result.append(cuts)
+            return tuple(result)
 
 else:
 

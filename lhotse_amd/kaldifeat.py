@@ -13,8 +13,11 @@ reference's own cross-check between the two is ``assert_almost_equal(decimal=3)`
 test/features/test_kaldifeat_features.py:103-116).  Every item is framed on its own (reflected edges per item,
 as Kaldi does), i.e. ``edge_rule="reflect"``.
 
-Options that have no counterpart in the kernels raise ``NotImplementedError`` at construction:
-``htk_compat=True``, ``use_log_fbank=False``, ``mel_opts.htk_mode=True``, ``mel_opts.debug_mel=True``.
+``htk_compat=True`` (energy / C0 column last; C0 times sqrt(2) when it is not the energy) and ``use_log_fbank=False`` (linear
+mel energies) are applied on the device to the kernels' output, restating Kaldi's published ``feature-fbank.cc`` /
+``feature-mfcc.cc`` (the code kaldifeat wraps; not available offline, so these two are "parity unpinned" like the rest of
+this module).  ``mel_opts.htk_mode=True`` / ``mel_opts.debug_mel=True`` raise ``NotImplementedError`` at construction:
+the HTK variant of the mel-bin edges cannot be restated from memory reliably, and nothing would pin it.
 MFCC ``use_energy=True`` follows Kaldi (the log-energy replaces C0); lhotse's own torch-native layer crashes on it.
 ``vtln_low`` / ``vtln_high`` only act through a VTLN warp factor, which the lhotse wrapper never sets.
 ``chunk_size`` is accepted and ignored (one launch handles any batch).
@@ -202,6 +205,10 @@ class _HipKaldifeatExtractor(FeatureExtractor):
     def kernel_name(self) -> str:
         return self.inner.kernel_name
 
+    def _post(self, packed: torch.Tensor) -> torch.Tensor:
+        """Option handling on the packed (sum T, F) device tensor (column order, linear energies); identity by default."""
+        return packed
+
     def extract_batch(self, samples, sampling_rate: int, lengths=None):
         # kaldifeat expects a list of 1-D tensors (kaldifeat.py:91-93)
         if lengths is not None:
@@ -228,6 +235,7 @@ class _HipKaldifeatExtractor(FeatureExtractor):
         inner = self.inner
         with torch.no_grad():
             packed, frames = inner._extract_items(items)
+            packed = self._post(packed)
             if as_numpy:
                 packed = inner._to_host(packed).numpy()
         bounds = np.concatenate([[0], np.cumsum(frames)])
@@ -248,13 +256,24 @@ class HipKaldifeatFbank(_HipKaldifeatExtractor):
 
     def _make_inner(self) -> HipFbank:
         c = self.config
-        if c.htk_compat or not c.use_log_fbank:
-            raise NotImplementedError("hip-kaldifeat-fbank: htk_compat=True / use_log_fbank=False are not supported by the HIP kernels")
         kw = _frame_kwargs(c.frame_opts, c.mel_opts, self.name)
         inner = HipFbank(HipFbankConfig(use_energy=c.use_energy, energy_floor=c.energy_floor, raw_energy=c.raw_energy,
                                          use_fft_mag=not c.use_power, device=_device_str(c.device), **kw))
         inner.config.blackman_coeff = c.frame_opts.blackman_coeff
         return inner
+
+    def _post(self, packed: torch.Tensor) -> torch.Tensor:
+        """Kaldi's FbankComputer::Compute (feature-fbank.cc): without ``use_log_fbank`` the mel energies stay linear (the kernel's
+        floored log is undone: energies below 1.19e-7 come back as that floor); with ``htk_compat`` the log-energy column, if
+        any, goes last instead of first."""
+        c = self.config
+        e = 1 if c.use_energy else 0  # the kernels put the log-energy in column 0 (layers.py:575-576)
+        if not c.use_log_fbank:
+            packed = packed.clone()
+            packed[:, e:] = torch.exp(packed[:, e:])
+        if c.htk_compat and e:
+            packed = torch.cat([packed[:, 1:], packed[:, :1]], dim=1)
+        return packed
 
     def feature_dim(self, sampling_rate: int) -> int:
         return self.config.mel_opts.num_bins
@@ -281,13 +300,20 @@ class HipKaldifeatMfcc(_HipKaldifeatExtractor):
 
     def _make_inner(self) -> HipMfcc:
         c = self.config
-        if c.htk_compat:
-            raise NotImplementedError("hip-kaldifeat-mfcc: htk_compat=True is not supported by the HIP kernels")
         kw = _frame_kwargs(c.frame_opts, c.mel_opts, self.name)
         inner = HipMfcc(HipMfccConfig(use_energy=c.use_energy, energy_floor=c.energy_floor, raw_energy=c.raw_energy, num_ceps=c.num_ceps,
                                        cepstral_lifter=c.cepstral_lifter, device=_device_str(c.device), **kw))
         inner.config.blackman_coeff = c.frame_opts.blackman_coeff
         return inner
+
+    def _post(self, packed: torch.Tensor) -> torch.Tensor:
+        """Kaldi's MfccComputer::Compute (feature-mfcc.cc) with ``htk_compat``: the energy / C0 column goes last, and a C0 that
+        is a cepstral coefficient (not the log-energy) is scaled by sqrt(2)."""
+        c = self.config
+        if not c.htk_compat:
+            return packed
+        first = packed[:, :1] if c.use_energy else packed[:, :1] * (2.0 ** 0.5)
+        return torch.cat([packed[:, 1:], first], dim=1)
 
     def feature_dim(self, sampling_rate: int) -> int:
         return self.config.num_ceps

@@ -3,6 +3,7 @@ import pickle
 
 import numpy as np
 import pytest
+import torch
 
 import lhotse_amd as LA
 from lhotse_amd import compat
@@ -52,7 +53,7 @@ def test_option_mapping_onto_the_plan_config(monkeypatch):
     assert (m.num_ceps, m.cepstral_lifter, m.num_filters) == (20, 0.0, 30)
 
 
-@pytest.mark.parametrize("bad", [dict(htk_compat=True), dict(use_log_fbank=False), dict(mel_opts=LA.HipKaldifeatMelOptions(htk_mode=True))])
+@pytest.mark.parametrize("bad", [dict(mel_opts=LA.HipKaldifeatMelOptions(htk_mode=True)), dict(mel_opts=LA.HipKaldifeatMelOptions(debug_mel=True))])
 def test_unsupported_options_fail_loudly(bad):
     with pytest.raises(NotImplementedError):
         LA.HipKaldifeatFbank(LA.HipKaldifeatFbankConfig(**bad)).inner
@@ -70,3 +71,19 @@ def test_sampling_rate_mismatch_and_no_cpu_fallback():
 
         with pytest.raises(_lib.HipFeatError):
             ex.extract(np.zeros(16000, dtype=np.float32), 16000)
+
+
+def test_htk_compat_and_linear_fbank_are_column_operations_on_the_kernel_output():
+    """Kaldi's feature-fbank.cc / feature-mfcc.cc: htk_compat moves the energy / C0 column last (C0 x sqrt(2) when it is a
+    cepstral coefficient), use_log_fbank=False leaves the mel energies linear.  Checked on the hook itself (no GPU needed)."""
+    t = torch.arange(12, dtype=torch.float32).reshape(2, 6) / 10.0
+    fb = LA.HipKaldifeatFbank(LA.HipKaldifeatFbankConfig(use_energy=True, htk_compat=True))
+    assert torch.equal(fb._post(t), torch.cat([t[:, 1:], t[:, :1]], dim=1))
+    lin = LA.HipKaldifeatFbank(LA.HipKaldifeatFbankConfig(use_energy=True, use_log_fbank=False))._post(t)
+    assert torch.equal(lin[:, :1], t[:, :1]) and torch.allclose(lin[:, 1:], torch.exp(t[:, 1:]))  # the log-energy column stays a log
+    assert torch.allclose(LA.HipKaldifeatFbank(LA.HipKaldifeatFbankConfig(use_log_fbank=False))._post(t), torch.exp(t))
+    assert LA.HipKaldifeatFbank(LA.HipKaldifeatFbankConfig(htk_compat=True))._post(t) is t  # nothing to move without an energy column
+    mf = LA.HipKaldifeatMfcc(LA.HipKaldifeatMfccConfig(htk_compat=True))
+    assert torch.allclose(mf._post(t), torch.cat([t[:, 1:], t[:, :1] * 2.0 ** 0.5], dim=1))
+    me = LA.HipKaldifeatMfcc(LA.HipKaldifeatMfccConfig(htk_compat=True, use_energy=True))
+    assert torch.equal(me._post(t), torch.cat([t[:, 1:], t[:, :1]], dim=1))
