@@ -115,3 +115,67 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dirpath, f)
                 assert "kaldi_ref" not in text, os.path.join(dirpath, f)
+
+
+def test_cffi_branch_of_the_loader_with_a_minimal_cffi_module(monkeypatch):
+    """cffi is not installed in this image, so the cffi branch of lhotse_amd/_lib.py never runs with the real
+    package.  A minimal stand-in `cffi` module (FFI.cdef / dlopen / cast / NULL / string on top of ctypes) drives exactly that
+    branch: the header text it derives must declare every entry point of the ABI, pointer arguments go through ffi.cast,
+    NULL through ffi.NULL, C strings through ffi.string -- and the calls must give what the ctypes backend gives."""
+    import ctypes
+    import re
+    import sys
+    import types
+
+    from lhotse_amd import _lib, build
+
+    path = str(build.build())
+    cdefs = []
+
+    class _Ptr(int):
+        pass
+
+    class FakeFFI:
+        NULL = _Ptr(0)
+
+        def cdef(self, text):
+            cdefs.append(text)
+
+        def dlopen(self, p):
+            dll = ctypes.CDLL(p)
+            ns = types.SimpleNamespace()
+            for name, (ret, args) in _lib._SIGNATURES.items():
+                fn = getattr(dll, name)
+                fn.restype = ctypes.c_char_p if ret == "const char*" else _lib._CtypesBackend._SCALARS[ret]
+                fn.argtypes = [ctypes.c_void_p if a.endswith("*") else _lib._CtypesBackend._SCALARS[a] for a in args]
+                setattr(ns, name, fn)
+            return ns
+
+        def cast(self, ctype, value):
+            assert ctype.endswith("*"), ctype
+            return _Ptr(value)
+
+        def string(self, v):
+            return v
+
+    fake = types.ModuleType("cffi")
+    fake.FFI = FakeFFI
+    monkeypatch.setitem(sys.modules, "cffi", fake)
+    lib = _lib.Lib(path, prefer="cffi")
+    assert lib.backend.name == "cffi"
+    # the declarations handed to cdef: no preprocessor lines, no export macro, every entry point present
+    text = cdefs[0]
+    assert "#" not in re.sub(r"/\*.*?\*/", "", text, flags=re.S) and "HIPFEAT_API" not in text
+    for name in _lib._SIGNATURES:
+        assert re.search(r"\b%s\s*\(" % name, text), name
+    ref = _lib.Lib(path, prefer="ctypes")
+    assert ref.backend.name == "ctypes"
+    assert lib.raw("hipfeat_abi_version") == ref.raw("hipfeat_abi_version") == _lib.ABI_VERSION
+    for n in (0, 139, 140, 16000, 160079, 160080):
+        assert lib.raw("hipfeat_num_frames", n, 400, 160, 0) == ref.raw("hipfeat_num_frames", n, 400, 160, 0)
+    with pytest.raises(_lib.HipFeatError, match="TOO_SHORT"):
+        lib.check("hipfeat_check_length", 100, 400, 160, 0)  # status + thread-local error string through ffi.string
+    cnt = np.zeros(1, dtype=np.int32)
+    st = lib.raw("hipfeat_device_count", _lib.addr(cnt))  # a pointer argument through ffi.cast
+    assert st in (0, _lib.ERR_HIP)
+    assert lib.raw("hipfeat_device_count", None) == _lib.ERR_INVALID  # None -> ffi.NULL
