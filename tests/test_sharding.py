@@ -83,3 +83,36 @@ def test_rank_from_env(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "8")
     assert S.rank_and_world() == (3, 8)
     assert S.all_reduce_stats(5, 0.5) == (5, 0.5)
+
+
+def test_bench_launches_itself_for_n_gt_1(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE re-execs under torch.distributed.run on 127.0.0.1 with its own argv."""
+    import importlib.util
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_execv(exe, cmd):
+        seen["exe"], seen["cmd"] = exe, list(cmd)
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    cmd = seen["cmd"]
+    assert seen["exe"] == sys.executable and cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    # the driver's own launch line (WORLD_SIZE already set) must NOT re-exec: it proceeds to the GPU check instead
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    seen.clear()
+    with pytest.raises(AssertionError, match="needs a GPU"):
+        bench.main()
+    assert not seen
