@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -24,6 +25,7 @@
 #include "kernel_resample.hpp"
 #include "kernel_specaug.hpp"
 #include "kernel_whisper2.hpp"
+#include "kernel_whisper3.hpp"
 #include "kernel_fft256.hpp"
 #include "kernel_wave.hpp"
 
@@ -94,7 +96,7 @@ struct hipfeat_plan {
   int span = 0, off_z = 0, off_p = 0, off_tw = 0, off_stat = 0, off_mel = 0;
   size_t lds_bytes = 0;
   // fft512 fast path
-  int variant = 0;  // 0 generic, 2 fft512 "b" (16-frame tiles), 4 fft256, 5 wave-per-frame, 6 whisper, 7 fft512 "c" (wave-autonomous fbank)
+  int variant = 0;  // 0 generic, 2 fft512 "b" (16-frame tiles), 4 fft256, 5 wave-per-frame, 6 whisper, 7 fft512 "c" (wave-autonomous fbank), 8 fft1024 "c", 9 whisper wave-autonomous + fused normalisation
   float* d_mel_a4 = nullptr;
   float* d_dct_consts = nullptr;
   bool fast_mfcc = false;
@@ -148,7 +150,15 @@ struct hipfeat_layout {
   CutDesc* d_cuts = nullptr;
   bool owns = true;
   std::vector<int64_t> num_frames;
+  // Whisper (variant 9): per-cut normalisation scratch behind the descriptors, kNormSlots copies handed out round-robin so that
+  // launches of one layout that overlap on different streams do not share one (each copy re-arms itself at the end of its launch)
+  // copy k: [total_blocks][2] float workgroup statistics, then [batch] uint32 completion counters (armed = 0)
+  unsigned char* d_norm = nullptr;
+  int norm_slots = 0;
+  mutable std::atomic<unsigned> norm_next{0};
 };
+constexpr int kNormSlots = 4;
+static size_t norm_slot_bytes(const hipfeat_layout* lay) { return (2 * (size_t)lay->total_blocks + (size_t)lay->batch) * 4; }
 
 // --------------------------------------------------------------------------------------
 // library / pure helpers
@@ -865,6 +875,69 @@ static hipfeat_status setup_whisper2(hipfeat_plan* p, const float* h_mel) {
   return HIPFEAT_OK;
 }
 
+// whisper, wave-autonomous with the normalisation fused (kernel_whisper3.hpp): shares the DFT-25 coefficient table of setup_whisper2
+template <int NSETS>
+static const void* whisper3_entry() {
+  return reinterpret_cast<const void*>(&whisper3_kernel<NSETS>);
+}
+
+static hipfeat_status setup_whisper3(hipfeat_plan* p, const float* h_window, const float* h_mel) {
+  const hipfeat_config& c = p->cfg;
+  if (p->variant != 6) return HIPFEAT_OK;  // setup_whisper2 decides whether this is the Whisper fast-path configuration
+  const char* v = getenv("HIPFEAT_WHISPER_VARIANT");
+  if (v && v[0] == '2') return HIPFEAT_OK;
+  const int M = c.num_filters;
+  Mel4Schedule sch;
+  if (!build_mel4_schedule(h_mel, M, 201, kW3PRowStride, kW3MaxSets, kW3Steps, sch)) return HIPFEAT_OK;
+  const int nsets = sch.nsets <= 2 ? 2 : 3;
+  std::vector<float> img((size_t)kW3N + 13 * 16 * 2, 0.0f);
+  for (int i = 0; i < kW3N; ++i) img[(size_t)i] = h_window[i];
+  for (int k2 = 0; k2 < 13; ++k2)
+    for (int l = 0; l < 16; ++l) {
+      const double th = 2.0 * M_PI * (double)((l * k2) % 400) / 400.0;
+      img[(size_t)kW3N + ((size_t)k2 * 16 + l) * 2] = (float)std::cos(th);
+      img[(size_t)kW3N + ((size_t)k2 * 16 + l) * 2 + 1] = (float)-std::sin(th);
+    }
+  // the kernel runs `nsets` sets of kW3Steps steps unconditionally: pad the tables (weights 0, no output column)
+  p->c_wtab_off = (int)img.size();
+  img.resize(img.size() + (size_t)nsets * kW3Steps * 64, 0.0f);
+  for (int s2 = 0; s2 < sch.nsets; ++s2)
+    std::memcpy(img.data() + p->c_wtab_off + (size_t)s2 * kW3Steps * 64, sch.wtab.data() + (size_t)sch.step0[s2] * 64, (size_t)sch.steps[s2] * 64 * sizeof(float));
+  p->c_ltab_off = (int)img.size();
+  img.resize(img.size() + (size_t)nsets * 256, 0.0f);
+  {
+    const int none = kMel4NoColumn;
+    for (int s2 = 0; s2 < nsets; ++s2)
+      for (int lane = 0; lane < 64; ++lane) {
+        float* lt = img.data() + p->c_ltab_off + ((size_t)s2 * 64 + lane) * 4;
+        if (s2 < sch.nsets) std::memcpy(lt, sch.ltab.data() + ((size_t)s2 * 64 + lane) * 4, 4 * sizeof(float));
+        else std::memcpy(lt + 1, &none, 4);
+      }
+  }
+  while (img.size() % 64) img.push_back(0.0f);
+  const size_t lds = (img.size() + (size_t)kW3Waves * (kW3Span + kW3Region) + kW3Tail) * sizeof(float);
+  if (lds > 80 * 1024) return HIPFEAT_OK;  // two workgroups of 8 waves per CU or nothing
+  const void* fn = nsets == 2 ? whisper3_entry<2>() : whisper3_entry<3>();
+  hipError_t e = ensure_dynamic_lds(fn, lds);
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(whisper3) failed: %s", hipGetErrorName(e));
+  hipfeat_status st;
+  if ((st = upload(&p->d_c_shared, img.data(), img.size())) != HIPFEAT_OK) return st;
+  p->c_shared_floats = (int)img.size();
+  p->w_nsets = nsets;
+  p->c_rounds = 8;  // 8 waves x 8 rounds x 4 frames = 256 frames per workgroup
+  p->fpb = kW3Waves * p->c_rounds * 4;
+  p->fast_lds_bytes = lds;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kW3Waves, lds) == hipSuccess) p->blocks_per_cu = nb;
+  int total_steps = 0;
+  for (int s2 = 0; s2 < sch.nsets; ++s2) total_steps += sch.steps[s2];
+  char nm[160];
+  snprintf(nm, sizeof(nm), "whisper3_kernel<%d> fft400=16x25 fused-norm lds=%zuB blocks/CU=%d mel4=%dx%d", nsets, lds, p->blocks_per_cu, sch.nsets, total_steps);
+  p->kernel_name = nm;
+  p->variant = 9;
+  return HIPFEAT_OK;
+}
+
 extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* cfg, const float* h_window,
                                               const float* h_mel, const float* h_dct, const float* h_lifter,
                                               int32_t device, hipfeat_plan** out) {
@@ -989,6 +1062,8 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   if (st != HIPFEAT_OK) return bail(st);
   st = setup_whisper2(p, h_mel);
   if (st != HIPFEAT_OK) return bail(st);
+  st = setup_whisper3(p, h_window, h_mel);
+  if (st != HIPFEAT_OK) return bail(st);
   st = setup_fft256(p, h_window, h_mel, h_dct, h_lifter);
   if (st != HIPFEAT_OK) return bail(st);
   st = setup_fft1024c(p, h_window, h_mel);
@@ -1087,11 +1162,20 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_layout_create(const hipfeat_plan* 
     return st;
   }
   DeviceGuard g(plan->device);
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&lay->d_cuts), std::max<size_t>(descs.size(), 1) * sizeof(CutDesc));
+  // one allocation: descriptors, then (Whisper with the fused normalisation) kNormSlots armed copies of the normalisation scratch
+  const size_t desc_bytes = std::max<size_t>(descs.size(), 1) * sizeof(CutDesc);
+  const size_t norm_bytes = plan->variant == 9 ? (size_t)kNormSlots * norm_slot_bytes(lay) : 0;
+  std::vector<unsigned char> blob(desc_bytes + norm_bytes, 0);  // zeros = armed counters
+  if (!descs.empty()) std::memcpy(blob.data(), descs.data(), descs.size() * sizeof(CutDesc));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&lay->d_cuts), blob.size());
   if (e == hipSuccess && !descs.empty()) {
     // synchronous w.r.t. the host (pageable source), ordered on `stream`
-    e = hipMemcpyAsync(lay->d_cuts, descs.data(), descs.size() * sizeof(CutDesc), hipMemcpyHostToDevice, (hipStream_t)stream);
+    e = hipMemcpyAsync(lay->d_cuts, blob.data(), blob.size(), hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  }
+  if (norm_bytes) {
+    lay->d_norm = reinterpret_cast<unsigned char*>(lay->d_cuts) + desc_bytes;
+    lay->norm_slots = kNormSlots;
   }
   if (e != hipSuccess) {
     (void)hipFree(lay->d_cuts);
@@ -1170,6 +1254,42 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
       default: hipLaunchKernelGGL(wave_kernel<16>, grid, block, plan->wave_lds_bytes, stream, wp); break;
     }
     HIP_TRY(hipGetLastError());
+    return HIPFEAT_OK;
+  }
+  if (plan->variant == 9) {
+    Whisper3Params wp{};
+    wp.wave = d_wave;
+    wp.out = d_out;
+    wp.cuts = lay->d_cuts;
+    wp.shared_consts = plan->d_c_shared;
+    wp.cs = plan->d_wh2_cs;
+    wp.out_stride = lay->out_row_stride;
+    wp.num_cuts = (int32_t)lay->batch;
+    wp.uniform_bpc = lay->uniform_bpc;
+    wp.total_blocks = (int32_t)lay->total_blocks;
+    wp.frames_per_block = plan->fpb;
+    wp.rounds = plan->c_rounds;
+    wp.M = c.num_filters;
+    wp.mel_floor = c.mel_floor;
+    wp.shared_floats = plan->c_shared_floats;
+    wp.wtab_off = plan->c_wtab_off;
+    wp.ltab_off = plan->c_ltab_off;
+    if (lay->d_norm) {
+      unsigned char* slot = lay->d_norm + (size_t)(lay->norm_next.fetch_add(1u) % (unsigned)lay->norm_slots) * norm_slot_bytes(lay);
+      wp.wg_stat = reinterpret_cast<float*>(slot);
+      wp.cut_done = reinterpret_cast<uint32_t*>(slot + 2 * (size_t)lay->total_blocks * sizeof(float));
+    }
+    DeviceGuard g(plan->device);
+    const dim3 grid((unsigned)lay->total_blocks), block(64 * kW3Waves);
+    set_lds_poison(plan->fast_lds_bytes);
+    if (plan->w_nsets == 2) hipLaunchKernelGGL(whisper3_kernel<2>, grid, block, plan->fast_lds_bytes, stream, wp);
+    else hipLaunchKernelGGL(whisper3_kernel<3>, grid, block, plan->fast_lds_bytes, stream, wp);
+    HIP_TRY(hipGetLastError());
+    if (!wp.wg_stat) {  // no scratch behind this layout: finish with the separate pass
+      hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)lay->batch), dim3(1024), 0, stream, lay->d_cuts, d_out, lay->out_row_stride,
+                         (int32_t)c.num_filters, (int32_t)c.frame_shift);
+      HIP_TRY(hipGetLastError());
+    }
     return HIPFEAT_OK;
   }
   if (plan->variant == 6) {
@@ -1442,7 +1562,9 @@ static hipfeat_status extract_transient(const hipfeat_plan* plan, const float* d
     for (int64_t b = 0; b < batch; ++b) h_num_frames[b] = lay.num_frames[(size_t)b];
   if (lay.total_blocks == 0 && max_pad == 0) return HIPFEAT_OK;
   DeviceGuard g(plan->device);
-  const size_t bytes = descs.size() * sizeof(CutDesc);
+  // Whisper with the fused normalisation: one armed scratch entry per cut travels behind the descriptors (fresh for every call)
+  const size_t desc_bytes = descs.size() * sizeof(CutDesc);
+  const size_t bytes = desc_bytes + (plan->variant == 9 ? norm_slot_bytes(&lay) : 0);
   std::lock_guard<std::mutex> lk(plan->mu);
   StagingSlot& s = plan->slots[plan->next_slot];
   plan->next_slot = (plan->next_slot + 1) % 4;
@@ -1461,7 +1583,12 @@ static hipfeat_status extract_transient(const hipfeat_plan* plan, const float* d
     HIP_TRY(hipMalloc(&s.d, cap));
     s.cap = cap;
   }
-  std::memcpy(s.h, descs.data(), bytes);
+  std::memcpy(s.h, descs.data(), desc_bytes);
+  if (bytes > desc_bytes) {
+    std::memset(static_cast<unsigned char*>(s.h) + desc_bytes, 0, bytes - desc_bytes);
+    lay.d_norm = static_cast<unsigned char*>(s.d) + desc_bytes;
+    lay.norm_slots = 1;
+  }
   HIP_TRY(hipMemcpyAsync(s.d, s.h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
   lay.d_cuts = static_cast<CutDesc*>(s.d);
   st = HIPFEAT_OK;

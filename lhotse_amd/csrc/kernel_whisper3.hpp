@@ -1,0 +1,395 @@
+// Whisper log-mel (frame 400, hop 160), wave-autonomous: the arithmetic of kernel_whisper2.hpp (400-point real DFT as a 16 x 25
+// mixed-radix FFT on 16 lanes per frame) in the organisation of kernel_fft512c.hpp -- a wave owns its four frames from the samples in
+// HBM to the stored rows, and the per-cut normalisation of log_mel_spectrogram (lhotse/features/whisper_fbank.py:67-80) is finished
+// inside the same launch.
+//
+// What changes against kernel_whisper2.hpp (measured there: 53 % of the wave cycles in s_waitcnt; sample loads 0.7 ms and the mel GEMM
+// with its two workgroup barriers per tile 0.75 ms of 2.44 ms per 4000 cuts; the separate normalisation pass 0.48 ms on top):
+//   * samples: the wave's span (3 hops + 400 floats) arrives by LDS-DMA in a wave-private buffer, requested one round ahead; the 25
+//     decimated samples of a lane are ds_read_b32s instead of 25 global loads whose latency nobody hides;
+//   * the transpose between the 25-point DFTs and the 16-point FFT goes through the wave's own region in two halves (k2 = 0..6, 7..12);
+//   * mel filterbank on v_mfma_f32_4x4x1_16B_f32 from the wave's own four power rows (mel4_schedule.hpp, 2 accumulator sets for 80
+//     filters, 3 for 128): no workgroup barrier in the steady state;
+//   * normalisation: the rows are stored as (v + 4) / 4 with zeros in the padding row; a workgroup publishes the maximum of v and the
+//     minimum of what it stored and bumps the cut's completion counter; the workgroup that finds itself LAST for a cut (no spinning, so
+//     no forward-progress assumption) applies the clamp max(v, cut_max - 8) to those row blocks that hold anything under it (section 6).
+#pragma once
+#include "common.hpp"
+#include "fft_common.hpp"
+#include "kernel_fft512c.hpp"  // HFC_SEP, mul24
+
+namespace hipfeat {
+
+constexpr int kW3N = 400, kW3Shift = 160;
+constexpr int kW3Waves = 8;                      // waves per workgroup
+constexpr int kW3Span = 3 * kW3Shift + kW3N;     // 880 floats per wave and round
+constexpr int kW3TStride = 34;                   // transpose row: 16 complex + 1 complex of padding
+constexpr int kW3PRowStride = 272;               // power row stride (== 16 mod 64); also the frame stride of the transpose halves (7 x 34 <= 272)
+constexpr int kW3Region = 4 * kW3PRowStride;     // 1088 floats per wave
+constexpr int kW3MaxSets = 3;                    // accumulator sets (16 slots of 4 filters each): 128 filters need 3
+constexpr int kW3Steps = 16;                     // MFMA steps per set
+constexpr int kW3Tail = 32;                      // floats at the end of the workgroup's LDS for the end-of-kernel reduction
+
+struct Whisper3Params {
+  const float* wave;
+  float* out;
+  const CutDesc* cuts;
+  // LDS image, copied once per workgroup: [400] window | [13][16] v2 W400^(l k2) | weight table [sets][16 steps / 4][64 lanes][4] |
+  // lane table [sets][64 lanes][4] (power-row offset, output column, m4, m8)
+  const float* shared_consts;
+  const float* cs;  // [12 rows j = 1..12][24]: cos(2 pi j k / 25), k = 1..12, then -sin(2 pi j k / 25): read through the scalar cache
+  int64_t out_stride;
+  int32_t num_cuts, uniform_bpc, total_blocks;
+  int32_t frames_per_block, rounds;  // frames_per_block = 8 waves * rounds * 4
+  int32_t M;
+  float mel_floor;
+  int32_t shared_floats, wtab_off, ltab_off;
+  // fused normalisation scratch (nullptr: leave log10(max(mel, floor)) in the rows, the caller runs whisper_norm_kernel)
+  float* wg_stat;      // [total_blocks][2] per workgroup: maximum of log10(mel), minimum of the stored (v + 4) / 4 (rewritten by every launch)
+  uint32_t* cut_done;  // [num_cuts] workgroups of the cut that have finished; armed state 0, re-armed by the finishing workgroup
+};
+
+template <int NSETS>
+__global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whisper3Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  HF_POISON_LDS(smem);
+  const float* cwin = smem;                                   // [400]
+  const v2* ctw = reinterpret_cast<const v2*>(smem + kW3N);   // [13][16] row k2, column l
+  const float* wtab = smem + p.wtab_off;
+  const float* ltab = smem + p.ltab_off;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int blk = blockIdx.x;
+  int cut, fb;
+  if (p.uniform_bpc > 0) {
+    cut = blk / p.uniform_bpc;
+    fb = blk - cut * p.uniform_bpc;
+  } else {
+    cut = find_cut(p.cuts, p.num_cuts, blk);
+    fb = blk - p.cuts[cut].first_block;
+  }
+  const CutDesc cd = p.cuts[cut];
+  const float* __restrict__ w = p.wave + cd.wave_off;
+  const int S = cd.num_samples;
+  const int valid = min(S / kW3Shift, cd.num_frames);  // frames that exist (whisper_fbank.py:62 drops the last STFT column); the rest is padding
+
+  for (int i = tid; i < p.shared_floats; i += 64 * kW3Waves) smem[i] = p.shared_consts[i];
+  float* xs = smem + p.shared_floats + wv * (kW3Span + kW3Region);
+  float* myreg = xs + kW3Span;
+  float* tail = smem + p.shared_floats + kW3Waves * (kW3Span + kW3Region);
+  // the tails of the power rows (floats 238..271) are never written by a round but may meet zero weights: make them finite once
+  for (int i = lane; i < kW3Region; i += 64) myreg[i] = 0.f;
+
+  auto stage_span = [&](int f0, unsigned lane4) {
+    const int64_t j0 = (int64_t)f0 * kW3Shift - kW3N / 2;
+    if (j0 >= 0 && j0 + kW3Span <= (int64_t)S) {
+      const char* src = reinterpret_cast<const char*>(w + j0);  // uniform
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)ch * 1024u + 4u * lane4)),
+                                         (__attribute__((address_space(3))) void*)(xs + ch * 256), 16, 0, 0);
+      if (768u + lane4 < (unsigned)kW3Span)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (3072u + 4u * lane4)),
+                                         (__attribute__((address_space(3))) void*)(xs + 768), 16, 0, 0);
+    } else {  // torch.stft's "reflect" padding around the cut (the edge sample is not repeated)
+      for (int i = (int)(lane4 >> 2); i < kW3Span; i += 64) xs[i] = load_sample_center(w, j0 + i, S);
+    }
+  };
+
+  const int first_frame = fb * p.frames_per_block + 4 * wv;  // the waves take the frame quads round-robin
+  __syncthreads();  // the constant tables are in place (the only workgroup barrier before the end of the kernel)
+  if (first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
+
+  const bool fused = p.wg_stat != nullptr;
+  float mx = -INFINITY, mn = INFINITY;
+  for (int r = 0; r < p.rounds; ++r) {
+    const int f0 = first_frame + 4 * kW3Waves * r;
+    if (f0 >= cd.num_frames) break;
+    const int nf = min(4, cd.num_frames - f0);
+    const int nv = valid - f0;  // rows i < nv of this round count for the maximum
+
+    if (r == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); later rounds waited before their predecessor's stores
+    int lane_o = lane;  // opaque copy: keeps LICM from pinning per-lane addresses in VGPRs for the whole kernel
+    asm volatile("" : "+v"(lane_o));
+    const int q = lane_o & 15, g = lane_o >> 4;
+
+    // ---- 1. decimated, windowed samples: lane l takes the samples 16 j + l of its group's frame -------------------------------
+    float s[25];
+    {
+      const float* x = xs + mul24(g, kW3Shift) + q;
+      const float* wn = cwin + q;
+      float wj[25];
+#pragma unroll
+      for (int j = 0; j < 25; ++j) {
+        s[j] = x[16 * j];
+        HFC_SEP();
+      }
+#pragma unroll
+      for (int j = 0; j < 25; ++j) {
+        wj[j] = wn[16 * j];
+        HFC_SEP();
+      }
+      // once the samples sit in registers the buffer is free for the next round's span
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (r + 1 < p.rounds && f0 + 4 * kW3Waves < cd.num_frames) stage_span(f0 + 4 * kW3Waves, (unsigned)lane_o * 4u);
+#pragma unroll
+      for (int j = 0; j < 25; ++j) s[j] *= wj[j];
+    }
+    // ---- 2. 25-point real DFT, k2 = 0 .. 12 (kernel_whisper2.hpp): coefficients as scalar operands --------------------------------
+    v2 Y[13];
+    {
+      float a[12], b[12];
+      float sum = s[0];
+#pragma unroll
+      for (int j = 1; j <= 12; ++j) {
+        a[j - 1] = s[j] + s[25 - j];
+        b[j - 1] = s[j] - s[25 - j];
+        sum += a[j - 1];
+      }
+      Y[0] = v2{sum, 0.f};
+      float re[12], im[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) re[k] = s[0], im[k] = 0.f;
+#pragma unroll
+      for (int j = 1; j <= 12; ++j) {
+        // constant address space: the loads stay scalar (s_load) after the opaque copy; tying the copy to the previous row's first
+        // accumulator bounds the coefficient rows in flight (they would otherwise be hoisted out of the round loop and spilled)
+        const __attribute__((address_space(4))) float* cj = (const __attribute__((address_space(4))) float*)(p.cs) + (j - 1) * 24;
+        asm volatile("" : "+s"(cj), "+v"(re[0]));
+        const float aj = a[j - 1], bj = b[j - 1];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          re[k] = fmaf(aj, cj[k], re[k]);
+          im[k] = fmaf(bj, cj[12 + k], im[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) Y[1 + k] = v2{re[k], im[k]};
+    }
+    // ---- 3. twiddle W400^(l k2), transpose inside the 16-lane group in two halves (rows k2 = 0..6, then 7..12) ------------------
+    v2 xin[16];
+    {
+      v2 tw[12];
+#pragma unroll
+      for (int k = 1; k <= 12; ++k) {
+        tw[k - 1] = ctw[k * 16 + q];
+        HFC_SEP();
+      }
+#pragma unroll
+      for (int k = 1; k <= 12; ++k) Y[k] = cmul2(Y[k], tw[k - 1]);
+      float* exf = myreg + mul24(g, kW3PRowStride);
+      const int myrow = min(q, 12);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int rr = 0; rr < 7; ++rr)
+          if (7 * h + rr <= 12) *reinterpret_cast<v2*>(exf + rr * kW3TStride + 2 * q) = Y[7 * h + rr];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if ((myrow >= 7) == (h == 1)) {
+          const float* src = exf + mul24(myrow - 7 * h, kW3TStride);
+#pragma unroll
+          for (int l = 0; l < 16; ++l) {
+            xin[l] = *reinterpret_cast<const v2*>(src + 2 * l);
+            HFC_SEP();
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // ---- 4. 16-point FFT over l -> X[k2 + 25 k1]; |X|^2 into the frame's power row ----------------------------------------------------
+    {
+      v2 X[16];
+      fft16(xin, X);
+      float* prow = myreg + mul24(g, kW3PRowStride);
+      if (q == 0) {
+#pragma unroll
+        for (int k1 = 0; k1 <= 8; ++k1) prow[25 * k1] = X[k1].x * X[k1].x + X[k1].y * X[k1].y;
+      } else if (q <= 12) {  // bins k2 + 25 k1 (k1 < 8) and, through X[400 - k] = conj X[k], 25 (16 - k1) - k2 (k1 >= 8)
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+          const int bin = k1 < 8 ? q + 25 * k1 : 25 * (16 - k1) - q;
+          prow[bin] = X[k1].x * X[k1].x + X[k1].y * X[k1].y;
+        }
+      }
+      // bins 201..237 still hold transpose data of this round (finite; they meet zero weights only)
+    }
+    // the wave's four power rows are complete once its own (in-order) LDS queue has drained
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // the next round's span (requested at the start of this round) must have landed before this round's stores join the same
+    // in-order vmcnt queue
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    // ---- 5. mel filterbank on the matrix cores (kernel_fft512c.hpp), log10, stores, running maximum ---------------------------------
+    float* orow = p.out + (cd.out_row + f0) * p.out_stride;
+    int lt_poff[NSETS];
+#pragma unroll
+    for (int s2 = 0; s2 < NSETS; ++s2) lt_poff[s2] = __builtin_bit_cast(int, ltab[s2 * 256 + 4 * lane_o]);
+    // operands of two sets are in flight at a time (a third set re-uses the registers of the first once its MFMAs are issued)
+    f32x4 av[2][kW3Steps / 4], bv[2][kW3Steps / 4];
+    auto load_set = [&](int buf, int s2) {
+      const float* pa = myreg + lt_poff[s2];
+      const float* wb = wtab + s2 * (kW3Steps * 64) + 4 * lane_o;
+#pragma unroll
+      for (int c4 = 0; c4 < kW3Steps / 4; ++c4) {
+        av[buf][c4] = *reinterpret_cast<const f32x4*>(pa + 4 * c4);
+        bv[buf][c4] = *reinterpret_cast<const f32x4*>(wb + c4 * 256);
+      }
+    };
+    load_set(0, 0);
+    load_set(1, 1);
+#pragma unroll
+    for (int s2 = 0; s2 < NSETS; ++s2) {
+      const float* lt = ltab + s2 * 256 + 4 * lane_o;  // (the scalars one by one: hipcc miscompiles bit casts of vector elements)
+      const int col = __builtin_bit_cast(int, lt[1]);
+      const float m4 = lt[2], m8 = lt[3];
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c4 = 0; c4 < kW3Steps / 4; ++c4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s2 & 1][c4][i], bv[s2 & 1][c4][i], acc, 0, 0, 0);
+      }
+      if (s2 + 2 < NSETS) {
+        asm volatile("" ::: "memory");  // not before this set's MFMAs have been issued: the registers are theirs until then
+        load_set(s2 & 1, s2 + 2);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[i];
+        v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4
+        v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8
+        v = fast_log(fmaxf(v, p.mel_floor)) * 0.4342944819032518f;
+        if (col < p.M && i < nf) {
+          // fused normalisation: y = (v + 4) / 4 right away (zeros in the padding row), the clamp follows in section 6; agent-scope
+          // store = written through to memory, where the workgroup that finishes the cut may have to read it
+          const float y = (v + 4.0f) * 0.25f;
+          if (i < nv) mx = fmaxf(mx, v), mn = fminf(mn, y);
+          __hip_atomic_store(orow + i * p.out_stride + col, fused ? (i < nv ? y : 0.0f) : v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+
+  // ---- 6. per-cut normalisation, finished by the workgroup that completes the cut -----------------------------------------------------------
+  // The rows above already hold y = (v + 4) / 4; what is missing is the clamp max(v, cut_max - 8), i.e. max(y, c) with
+  // c = ((cut_max - 8) + 4) / 4 (y is monotonic in v, so max(y, c) reproduces (max(v, cut_max - 8) + 4) / 4 bit for bit).  Every
+  // workgroup publishes the maximum of v and the minimum of y over what it stored; the workgroup that finds itself LAST for a cut (no
+  // spinning, so no forward-progress assumption) reads them and re-visits only the row blocks whose minimum lies under c -- for most
+  // audio (less than 80 dB between the loudest mel bin of the cut and its quietest) that is none at all.
+  // Cross-workgroup visibility without cache flushes: rows and statistics are written with agent-scope (write-through, sc1) stores,
+  // so waiting for the wave's own vmcnt makes them visible device-wide; the counter is an agent-scope atomic; the finishing workgroup
+  // reads with agent-scope (sc1) loads.  Agent-scope release/acquire FENCES instead would write back and invalidate the XCD's whole L2
+  // once per workgroup (measured: 1.9 ms -> 12.7 ms per 4000 cuts).
+  if (!fused) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+  }
+  if (lane == 0) tail[wv] = mx, tail[8 + wv] = mn;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's rows have reached memory
+  __syncthreads();
+  const int nblk = p.uniform_bpc > 0 ? p.uniform_bpc : ((cut + 1 < p.num_cuts ? p.cuts[cut + 1].first_block : p.total_blocks) - cd.first_block);
+  const int blk0 = blk - fb;  // first workgroup of the cut
+  int* icount = reinterpret_cast<int*>(tail + 16);
+  if (tid == 0) {
+    float m = tail[0], l = tail[8];
+#pragma unroll
+    for (int i = 1; i < kW3Waves; ++i) m = fmaxf(m, tail[i]), l = fminf(l, tail[8 + i]);
+    __hip_atomic_store(p.wg_stat + 2 * blk, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p.wg_stat + 2 * blk + 1, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // ... and so have the workgroup's statistics, before the counter moves
+    const unsigned old = __hip_atomic_fetch_add(p.cut_done + cut, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    icount[0] = 0;
+    icount[1] = (old + 1u == (unsigned)nblk) ? 1 : 0;
+  }
+  __syncthreads();
+  if (icount[1] == 0) return;
+  constexpr int NT = 64 * kW3Waves;
+  float cmax = -INFINITY;
+  for (int i = tid; i < nblk; i += NT) cmax = fmaxf(cmax, __hip_atomic_load(p.wg_stat + 2 * (blk0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64));
+  if (lane == 0) tail[wv] = cmax;  // (thread 0 read tail[0..15] before the barrier above)
+  __syncthreads();
+  cmax = tail[0];
+#pragma unroll
+  for (int i = 1; i < kW3Waves; ++i) cmax = fmaxf(cmax, tail[i]);
+  if (tid == 0) __hip_atomic_store(p.cut_done + cut, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+  const float c = ((cmax - 8.0f) + 4.0f) * 0.25f;
+  // the row blocks (= workgroups) that hold something under c, collected in the (now idle) span buffers
+  int* list = reinterpret_cast<int*>(smem + p.shared_floats);
+  const int cap = kW3Waves * (kW3Span + kW3Region);
+  const bool listed = nblk <= cap;
+  if (listed) {
+    for (int i = tid; i < nblk; i += NT)
+      if (__hip_atomic_load(p.wg_stat + 2 * (blk0 + i) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c)
+        list[__hip_atomic_fetch_add(icount, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = i;
+    __syncthreads();
+  }
+  const int todo = listed ? icount[0] : nblk;
+  float* __restrict__ base = p.out + cd.out_row * p.out_stride;
+  const int M = p.M;
+  for (int t = 0; t < todo; ++t) {
+    const int jb = listed ? list[t] : t;
+    const int fr0 = jb * p.frames_per_block, fr1 = min(fr0 + p.frames_per_block, valid);
+    if (fr1 <= fr0) continue;
+    if (p.out_stride == M && ((reinterpret_cast<uintptr_t>(base + (int64_t)fr0 * M) & 15) == 0)) {
+      // dense rows on a 16-byte boundary: linear sweep, eight 16-byte agent-scope loads in flight per lane (the sweep is latency bound).
+      // The loads and the wait for them sit in ONE asm statement, so the compiler never touches a destination before its data arrived.
+      float* b = base + (int64_t)fr0 * M;
+      const int n = (fr1 - fr0) * M, n4 = n >> 2;
+      const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+      f32x4* o4 = reinterpret_cast<f32x4*>(b);
+      auto fix = [&](f32x4 v) { return f32x4{fmaxf(v.x, c), fmaxf(v.y, c), fmaxf(v.z, c), fmaxf(v.w, c)}; };
+      int i = tid;
+      for (; i + 7 * NT < n4; i += 8 * NT) {
+        f32x4 v0, v1, v2_, v3, v4, v5, v6, v7;
+        asm volatile(
+            "global_load_dwordx4 %0, %8, off sc1\n\t"
+            "global_load_dwordx4 %1, %9, off sc1\n\t"
+            "global_load_dwordx4 %2, %10, off sc1\n\t"
+            "global_load_dwordx4 %3, %11, off sc1\n\t"
+            "global_load_dwordx4 %4, %12, off sc1\n\t"
+            "global_load_dwordx4 %5, %13, off sc1\n\t"
+            "global_load_dwordx4 %6, %14, off sc1\n\t"
+            "global_load_dwordx4 %7, %15, off sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(v0), "=&v"(v1), "=&v"(v2_), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+            : "v"(b4 + i), "v"(b4 + i + NT), "v"(b4 + i + 2 * NT), "v"(b4 + i + 3 * NT), "v"(b4 + i + 4 * NT), "v"(b4 + i + 5 * NT),
+              "v"(b4 + i + 6 * NT), "v"(b4 + i + 7 * NT)
+            : "memory");
+        o4[i] = fix(v0);
+        o4[i + NT] = fix(v1);
+        o4[i + 2 * NT] = fix(v2_);
+        o4[i + 3 * NT] = fix(v3);
+        o4[i + 4 * NT] = fix(v4);
+        o4[i + 5 * NT] = fix(v5);
+        o4[i + 6 * NT] = fix(v6);
+        o4[i + 7 * NT] = fix(v7);
+      }
+      for (; i < n4; i += NT) {
+        f32x4 v0;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v0) : "v"(b4 + i) : "memory");
+        o4[i] = fix(v0);
+      }
+      for (i = (n4 << 2) + tid; i < n; i += NT) b[i] = fmaxf(__hip_atomic_load(b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c);
+    } else {
+      const int n = (fr1 - fr0) * M;
+      for (int i = tid; i < n; i += NT) {
+        const int rr = i / M;
+        float* e = base + (int64_t)(fr0 + rr) * p.out_stride + (i - rr * M);
+        *e = fmaxf(__hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c);
+      }
+    }
+  }
+}
+
+}  // namespace hipfeat
