@@ -805,8 +805,8 @@ static hipfeat_status setup_whisper2(hipfeat_plan* p, const float* h_mel) {
   for (int j = 1; j <= 12; ++j)
     for (int k = 1; k <= 12; ++k) {
       const double th = 2.0 * M_PI * (double)((j * k) % 25) / 25.0;
-      cs[(size_t)(j - 1) * 24 + (k - 1)] = (float)std::cos(th);
-      cs[(size_t)(j - 1) * 24 + 12 + (k - 1)] = (float)-std::sin(th);
+      cs[(size_t)(j - 1) * 24 + 2 * (k - 1)] = (float)std::cos(th);
+      cs[(size_t)(j - 1) * 24 + 2 * (k - 1) + 1] = (float)-std::sin(th);
     }
   std::vector<float> tw((size_t)13 * 16 * 2);
   for (int k2 = 0; k2 < 13; ++k2)

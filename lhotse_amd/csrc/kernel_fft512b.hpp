@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 4) void fft512b_kernel(const Fft512Params p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (q / RPP == h) {
+        if (h == 0 || q / RPP == h) {  // part 0: every lane reads (b is never undefined: nothing for hipcc to carry around the tile loop)
 #pragma unroll
           for (int n2 = 0; n2 < 16; ++n2) { b[n2] = *reinterpret_cast<const v2*>(exf + (q % RPP) * kBExRowStride + 2 * n2); HF_SEP(); }
         }

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (q / 8 == h) {
+        if (h == 0 || q >= 8) {  // half 0: every lane reads (b is never undefined: nothing for hipcc to carry around the round loop); half 1: lanes 8.. replace it
 #pragma unroll
           for (int n2 = 0; n2 < 16; ++n2) {
             b[n2] = *reinterpret_cast<const v2*>(exf + (q % 8) * kCExRowStride + 2 * n2);

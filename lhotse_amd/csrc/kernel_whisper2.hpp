@@ -37,7 +37,7 @@ struct Whisper2Params {
   float* out;
   const CutDesc* cuts;
   const float* window;  // [400]
-  const float* cs;      // [12 rows j = 1..12][24]: cos(2 pi j k / 25) for k = 1..12, then -sin(2 pi j k / 25) for k = 1..12
+  const float* cs;      // [12 rows j = 1..12][12 k = 1..12][2]: cos(2 pi j k / 25), -sin(2 pi j k / 25)
   const float* tw;      // [13][16] complex W400^(l k2): row k2, column l
   const float* mel_a;   // [chunks][64 lanes][4 k-steps] A operands of the mel GEMM in lane order (bands padded to whole chunks)
   int64_t out_stride;
@@ -112,29 +112,21 @@ __global__ __launch_bounds__(256, HIPFEAT_W2_OCC) void whisper2_kernel(const Whi
         sum += a[j - 1];
       }
       Y[0] = v2{sum, 0.f};
-      // j outermost: the 24 coefficients of one j (12 cosines, 12 negated sines; consecutive in memory, fetched through the
-      // scalar cache and used as SGPR operands) update 24 independent accumulators -- no dependent chains.
+      // j outermost: the 12 (cos, -sin) coefficient pairs of one j (consecutive in memory, fetched through the scalar cache and used as
+      // SGPR-pair operands of v_pk_fma_f32) update 12 independent (Re, Im) accumulators -- no dependent chains.
       // The opaque pointer keeps hipcc from hoisting all 288 loop-invariant loads out of the tile loop (they do not fit the
       // SGPR file and would come back as spilled VGPRs).
-      float re[12], im[12];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) re[k] = s[0], im[k] = 0.f;
-      {
+      for (int k = 0; k < 12; ++k) Y[1 + k] = v2{s[0], 0.f};
 #pragma unroll
-        for (int j = 1; j <= 12; ++j) {
-          // constant address space: the loads stay scalar (s_load) after the opaque copy
-          const __attribute__((address_space(4))) float* cj = (const __attribute__((address_space(4))) float*)(p.cs) + (j - 1) * 24;
-          asm volatile("" : "+s"(cj), "+v"(re[0]));  // ... and after the previous j: at most two rows of coefficients in flight
-          const float aj = a[j - 1], bj = b[j - 1];
+      for (int j = 1; j <= 12; ++j) {
+        // constant address space: the loads stay scalar (s_load) after the opaque copy
+        const __attribute__((address_space(4))) float* cj = (const __attribute__((address_space(4))) float*)(p.cs) + (j - 1) * 24;
+        asm volatile("" : "+s"(cj), "+v"(Y[1]));  // ... and after the previous j: at most two rows of coefficients in flight
+        const v2 ab = v2{a[j - 1], b[j - 1]};
 #pragma unroll
-          for (int k = 0; k < 12; ++k) {
-            re[k] = fmaf(aj, cj[k], re[k]);
-            im[k] = fmaf(bj, cj[12 + k], im[k]);
-          }
-        }
+        for (int k = 0; k < 12; ++k) Y[1 + k] = ab * v2{cj[2 * k], cj[2 * k + 1]} + Y[1 + k];
       }
-#pragma unroll
-      for (int k = 0; k < 12; ++k) Y[1 + k] = v2{re[k], im[k]};
     }
     // ---- 3. twiddle, transpose inside the group ---------------------------------------------------------------------------
     *reinterpret_cast<v2*>(tb + 2 * q) = Y[0];

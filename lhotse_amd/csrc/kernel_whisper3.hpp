@@ -37,7 +37,7 @@ struct Whisper3Params {
   // LDS image, copied once per workgroup: [400] window | [13][16] v2 W400^(l k2) | weight table [sets][16 steps / 4][64 lanes][4] |
   // lane table [sets][64 lanes][4] (power-row offset, output column, m4, m8)
   const float* shared_consts;
-  const float* cs;  // [12 rows j = 1..12][24]: cos(2 pi j k / 25), k = 1..12, then -sin(2 pi j k / 25): read through the scalar cache
+  const float* cs;  // [12 rows j = 1..12][12 k = 1..12][2]: cos(2 pi j k / 25), -sin(2 pi j k / 25): read through the scalar cache
   int64_t out_stride;
   int32_t num_cuts, uniform_bpc, total_blocks;
   int32_t frames_per_block, rounds;  // frames_per_block = 8 waves * rounds * 4
@@ -105,6 +105,9 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
 
   const bool fused = p.wg_stat != nullptr;
   float mx = -INFINITY, mn = INFINITY;
+#ifdef HIPFEAT_PHASE_TIMERS
+  unsigned long long hfc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hfc_last = __builtin_readcyclecounter();
+#endif
   for (int r = 0; r < p.rounds; ++r) {
     const int f0 = first_frame + 4 * kW3Waves * r;
     if (f0 >= cd.num_frames) break;
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
       }
       // once the samples sit in registers the buffer is free for the next round's span
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      HFC_T(0);  // sample + window reads
       if (r + 1 < p.rounds && f0 + 4 * kW3Waves < cd.num_frames) stage_span(f0 + 4 * kW3Waves, (unsigned)lane_o * 4u);
 #pragma unroll
       for (int j = 0; j < 25; ++j) s[j] *= wj[j];
@@ -150,25 +154,22 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
         sum += a[j - 1];
       }
       Y[0] = v2{sum, 0.f};
-      float re[12], im[12];
+      // accumulators as (Re, Im) pairs, coefficients as (cos, -sin) pairs in consecutive SGPRs: one v_pk_fma_f32 with a scalar pair
+      // operand per (j, k) and no scalar shuffling (a split cos | sin table made hipcc build the pairs with s_mov / v_writelane)
 #pragma unroll
-      for (int k = 0; k < 12; ++k) re[k] = s[0], im[k] = 0.f;
+      for (int k = 0; k < 12; ++k) Y[1 + k] = v2{s[0], 0.f};
 #pragma unroll
       for (int j = 1; j <= 12; ++j) {
         // constant address space: the loads stay scalar (s_load) after the opaque copy; tying the copy to the previous row's first
         // accumulator bounds the coefficient rows in flight (they would otherwise be hoisted out of the round loop and spilled)
         const __attribute__((address_space(4))) float* cj = (const __attribute__((address_space(4))) float*)(p.cs) + (j - 1) * 24;
-        asm volatile("" : "+s"(cj), "+v"(re[0]));
-        const float aj = a[j - 1], bj = b[j - 1];
+        asm volatile("" : "+s"(cj), "+v"(Y[1]));
+        const v2 ab = v2{a[j - 1], b[j - 1]};
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-          re[k] = fmaf(aj, cj[k], re[k]);
-          im[k] = fmaf(bj, cj[12 + k], im[k]);
-        }
+        for (int k = 0; k < 12; ++k) Y[1 + k] = ab * v2{cj[2 * k], cj[2 * k + 1]} + Y[1 + k];
       }
-#pragma unroll
-      for (int k = 0; k < 12; ++k) Y[1 + k] = v2{re[k], im[k]};
     }
+    HFC_T(1);  // DMA issue, window, 25-point DFTs
     // ---- 3. twiddle W400^(l k2), transpose inside the 16-lane group in two halves (rows k2 = 0..6, then 7..12) ------------------
     v2 xin[16];
     {
@@ -190,8 +191,10 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if ((myrow >= 7) == (h == 1)) {
-          const float* src = exf + mul24(myrow - 7 * h, kW3TStride);
+        // half 0: every lane reads (lanes 7.. get a row they do not need); half 1: lanes 7.. replace it -- xin is never undefined, which
+        // keeps hipcc from carrying it around the round loop
+        if (h == 0 || myrow >= 7) {
+          const float* src = exf + mul24(h == 0 ? min(myrow, 6) : myrow - 7, kW3TStride);
 #pragma unroll
           for (int l = 0; l < 16; ++l) {
             xin[l] = *reinterpret_cast<const v2*>(src + 2 * l);
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
         __builtin_amdgcn_wave_barrier();
       }
     }
+    HFC_T(2);  // twiddles, transpose
     // ---- 4. 16-point FFT over l -> X[k2 + 25 k1]; |X|^2 into the frame's power row ----------------------------------------------------
     {
       v2 X[16];
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
       }
       // bins 201..237 still hold transpose data of this round (finite; they meet zero weights only)
     }
+    HFC_T(3);  // fft16, power rows
     // the wave's four power rows are complete once its own (in-order) LDS queue has drained
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -227,6 +232,7 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
     // the next round's span (requested at the start of this round) must have landed before this round's stores join the same
     // in-order vmcnt queue
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    HFC_T(4);  // wait for the next span
     // ---- 5. mel filterbank on the matrix cores (kernel_fft512c.hpp), log10, stores, running maximum ---------------------------------
     float* orow = p.out + (cd.out_row + f0) * p.out_stride;
     int lt_poff[NSETS];
@@ -275,7 +281,17 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
         }
       }
     }
+    HFC_T(5);  // mel filterbank, log10, stores
+#ifdef HIPFEAT_PHASE_TIMERS
+    hfc_acc[7] += 1;
+#endif
   }
+#ifdef HIPFEAT_PHASE_TIMERS
+  if (lane == 0 && g_phase_buf) {
+    unsigned long long* o = g_phase_buf + ((size_t)blockIdx.x * kW3Waves + wv) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = hfc_acc[i];
+  }
+#endif
 
   // ---- 6. per-cut normalisation, finished by the workgroup that completes the cut -----------------------------------------------------------
   // The rows above already hold y = (v + 4) / 4; what is missing is the clamp max(v, cut_max - 8), i.e. max(y, c) with
