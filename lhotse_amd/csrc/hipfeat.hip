@@ -21,6 +21,7 @@
 #include "kernel_fft512b.hpp"
 #include "kernel_fft512c.hpp"
 #include "kernel_fft1024c.hpp"
+#include "kernel_fft2048c.hpp"
 #include "mel4_schedule.hpp"
 #include "kernel_resample.hpp"
 #include "kernel_specaug.hpp"
@@ -96,7 +97,7 @@ struct hipfeat_plan {
   int span = 0, off_z = 0, off_p = 0, off_tw = 0, off_stat = 0, off_mel = 0;
   size_t lds_bytes = 0;
   // fft512 fast path
-  int variant = 0;  // 0 generic, 2 fft512 "b" (16-frame tiles), 4 fft256, 5 wave-per-frame, 6 whisper, 7 fft512 "c" (wave-autonomous fbank), 8 fft1024 "c", 9 whisper wave-autonomous + fused normalisation
+  int variant = 0;  // 0 generic, 2 fft512 "b" (16-frame tiles), 4 fft256, 5 wave-per-frame, 6 whisper, 7 fft512 "c" (wave-autonomous fbank), 8 fft1024 "c", 9 whisper wave-autonomous + fused normalisation, 10 fft2048 "c"
   float* d_mel_a4 = nullptr;
   float* d_dct_consts = nullptr;
   bool fast_mfcc = false;
@@ -115,6 +116,10 @@ struct hipfeat_plan {
   int c_shared_floats = 0, c_wtab_off = 0, c_ltab_off = 0, c_xs_floats = 0, c_rounds = 0;
   // fft1024 wave-autonomous fbank kernel (variant 8; shares d_c_shared / c_* with variant 7)
   int w_nsets = 0, w_steps[kWMaxSets] = {}, w_step0[kWMaxSets] = {};
+  // fft2048 wave-autonomous fbank kernel (variant 10; shares d_c_shared / c_* / w_* with variants 7 and 8)
+  float* d_x_twp = nullptr;  // [32][32] v2 W_1024^(q k1)
+  int x_waves = 0, x_tws_off = 0, x_tw32_off = 0;
+  bool x_odd = false;
   // wave-per-frame kernel (variant 5)
   float* d_mel_t = nullptr;  // filterbank blob (descriptors + compact weights)
   int mel_maxband = 0;
@@ -218,6 +223,7 @@ static void plan_free(hipfeat_plan* p) {
   (void)hipFree(p->d_mel);
   (void)hipFree(p->d_mel_range);
   (void)hipFree(p->d_wh2_cs);
+  (void)hipFree(p->d_x_twp);
   (void)hipFree(p->d_wh2_tw);
   (void)hipFree(p->d_wh2_mel);
   (void)hipFree(p->d_wh2_sched);
@@ -875,6 +881,113 @@ static hipfeat_status setup_whisper2(hipfeat_plan* p, const float* h_mel) {
   return HIPFEAT_OK;
 }
 
+// fft2048 wave-autonomous fbank kernel (kernel_fft2048c.hpp): 44.1 / 48 kHz Kaldi filterbanks, librosa-style log-mel with n_fft 2048
+template <int NROWS, bool ODD>
+static const void* fft2048c_entry() {
+  return reinterpret_cast<const void*>(&fft2048c_kernel<NROWS, ODD>);
+}
+
+static hipfeat_status setup_fft2048c(hipfeat_plan* p, const float* h_window, const float* h_mel) {
+  const hipfeat_config& c = p->cfg;
+  const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
+  const bool librosa = c.kind == HIPFEAT_LIBROSA_FBANK;  // centred frames, |X| or |X|^2, log10 (librosa_fbank.py:66-137)
+  if (p->variant != 0 || (c.kind != HIPFEAT_FBANK && !librosa) || c.fft_length != 2048 || N <= 1024 || c.use_energy ||
+      (c.use_fft_mag && !librosa) || getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_AUTONOMOUS"))
+    return HIPFEAT_OK;
+  const bool odd = (shift & 1) != 0;
+  const int need = (N + 63) / 64;
+  const int nrows = odd ? (need <= 18 ? 18 : 32) : (need <= 19 ? 19 : 32);
+  Mel4Schedule sch;
+  if (!build_mel4_schedule(h_mel, M, p->K, kXPRowStride, kXMaxSets, kXMaxSteps, sch)) return HIPFEAT_OK;
+  // LDS image: window/2 as (even, odd) sample pairs per (row n1, lane q)
+  std::vector<float> img((size_t)nrows * 32 * 2, 0.0f);
+  for (int n1 = 0; n1 < nrows; ++n1)
+    for (int q = 0; q < 32; ++q)
+      for (int e = 0; e < 2; ++e) {
+        const int i = 64 * n1 + 2 * q + e;
+        img[2 * (n1 * 32 + q) + e] = i < N ? 0.5f * h_window[i] : 0.0f;
+      }
+  // split twiddles -i W_2048^k per (step, lane); k = bin of the step's first operand: lanes 1..16: l + 64 s, lanes 17..31:
+  // (64 - l) + 64 s; lane 0: 64 s (s <= 8), 32 + 64 (s - 9) (s <= 15), 480 (s = 16)
+  p->x_tws_off = (int)img.size();
+  img.resize(img.size() + (size_t)kXSplitSteps * 32 * 2, 0.0f);
+  for (int st = 0; st < kXSplitSteps; ++st)
+    for (int q = 0; q < 32; ++q) {
+      int k;
+      if (q != 0) k = st < 16 ? (q <= 16 ? q : 64 - q) + 64 * st : 0;
+      else k = st <= 8 ? 64 * st : (st <= 15 ? 32 + 64 * (st - 9) : 480);
+      const double a = -2.0 * M_PI * (double)k / 2048.0;  // w = -i * W_2048^k = (sin(a), -cos(a))
+      img[(size_t)p->x_tws_off + 2 * (st * 32 + q)] = (float)std::sin(a);
+      img[(size_t)p->x_tws_off + 2 * (st * 32 + q) + 1] = (float)(-std::cos(a));
+    }
+  // butterfly twiddles of pass 2: row 0 = ones (even outputs), row 1 = W_32^n (odd outputs)
+  p->x_tw32_off = (int)img.size();
+  img.resize(img.size() + 2 * 16 * 2, 0.0f);
+  for (int n = 0; n < 16; ++n) {
+    const double a = -2.0 * M_PI * (double)n / 32.0;
+    img[(size_t)p->x_tw32_off + 2 * n] = 1.0f;
+    img[(size_t)p->x_tw32_off + 2 * (16 + n)] = (float)std::cos(a);
+    img[(size_t)p->x_tw32_off + 2 * (16 + n) + 1] = (float)std::sin(a);
+  }
+  p->c_wtab_off = (int)img.size();
+  img.insert(img.end(), sch.wtab.begin(), sch.wtab.end());
+  // a wave carries TWO frames: rows 2 and 3 of every 4 x 4 block read the power rows of frames 0 and 1 again (their results are dropped)
+  for (size_t i = 0; i < sch.ltab.size(); i += 4) {
+    const int lane = (int)((i / 4) % 64);
+    if ((lane & 3) >= 2) {
+      int v;
+      std::memcpy(&v, &sch.ltab[i], 4);
+      v -= 2 * kXPRowStride;
+      std::memcpy(&sch.ltab[i], &v, 4);
+    }
+  }
+  p->c_ltab_off = (int)img.size();
+  img.insert(img.end(), sch.ltab.begin(), sch.ltab.end());
+  while (img.size() % 64) img.push_back(0.0f);
+  p->c_shared_floats = (int)img.size();
+  p->c_xs_floats = (shift + 64 * nrows + 3) & ~3;
+  if ((p->c_xs_floats >> 8) > 10) return HIPFEAT_OK;
+  int waves = kXMaxWaves;
+  auto lds_of = [&](int wv) { return ((size_t)p->c_shared_floats + (size_t)wv * (p->c_xs_floats + kXRegion)) * sizeof(float); };
+  while (waves > 0 && lds_of(waves) > 160 * 1024) --waves;
+  if (waves < 4) return HIPFEAT_OK;
+  const size_t lds = lds_of(waves);
+  const void* fn = odd ? (nrows == 18 ? fft2048c_entry<18, true>() : fft2048c_entry<32, true>())
+                       : (nrows == 19 ? fft2048c_entry<19, false>() : fft2048c_entry<32, false>());
+  hipError_t e = ensure_dynamic_lds(fn, lds);
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft2048c) failed: %s", hipGetErrorName(e));
+  std::vector<float> twp((size_t)32 * 32 * 2);
+  for (int k1 = 0; k1 < 32; ++k1)
+    for (int q = 0; q < 32; ++q) {
+      const double a = -2.0 * M_PI * (double)(q * k1) / 1024.0;
+      twp[2 * ((size_t)k1 * 32 + q)] = (float)std::cos(a);
+      twp[2 * ((size_t)k1 * 32 + q) + 1] = (float)std::sin(a);
+    }
+  hipfeat_status st;
+  if ((st = upload(&p->d_c_shared, img.data(), img.size())) != HIPFEAT_OK) return st;
+  if ((st = upload(&p->d_x_twp, twp.data(), twp.size())) != HIPFEAT_OK) return st;
+  p->w_nsets = sch.nsets;
+  int total_steps = 0;
+  for (int s2 = 0; s2 < kXMaxSets; ++s2) {
+    p->w_steps[s2] = s2 < sch.nsets ? sch.steps[s2] : 0;
+    p->w_step0[s2] = s2 < sch.nsets ? sch.step0[s2] : 0;
+    total_steps += p->w_steps[s2];
+  }
+  p->nrows = nrows;
+  p->x_odd = odd;
+  p->x_waves = waves;
+  p->c_rounds = 8;
+  p->fpb = waves * p->c_rounds * 2;
+  p->fast_lds_bytes = lds;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * waves, lds) == hipSuccess) p->blocks_per_cu = nb;
+  char nm[160];
+  snprintf(nm, sizeof(nm), "fft2048c_kernel<%d,%d> fbank waves=%d lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, (int)odd, waves, lds, p->blocks_per_cu, sch.nsets, total_steps);
+  p->kernel_name = nm;
+  p->variant = 10;
+  return HIPFEAT_OK;
+}
+
 // whisper, wave-autonomous with the normalisation fused (kernel_whisper3.hpp): shares the DFT-25 coefficient table of setup_whisper2
 template <int NSETS>
 static const void* whisper3_entry() {
@@ -1067,6 +1180,8 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
   st = setup_fft256(p, h_window, h_mel, h_dct, h_lifter);
   if (st != HIPFEAT_OK) return bail(st);
   st = setup_fft1024c(p, h_window, h_mel);
+  if (st != HIPFEAT_OK) return bail(st);
+  st = setup_fft2048c(p, h_window, h_mel);
   if (st != HIPFEAT_OK) return bail(st);
   st = setup_wave(p, h_mel);
   if (st != HIPFEAT_OK) return bail(st);
@@ -1312,6 +1427,47 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)lay->batch), dim3(1024), 0, stream, lay->d_cuts, d_out, lay->out_row_stride,
                        (int32_t)c.num_filters, (int32_t)c.frame_shift);
+    HIP_TRY(hipGetLastError());
+    return HIPFEAT_OK;
+  }
+  if (plan->variant == 10) {
+    Fft2048cParams fp{};
+    fp.wave = d_wave;
+    fp.out = d_out;
+    fp.cuts = lay->d_cuts;
+    fp.shared_consts = plan->d_c_shared;
+    fp.twp = plan->d_x_twp;
+    fp.out_stride = lay->out_row_stride;
+    fp.num_cuts = (int32_t)lay->batch;
+    fp.uniform_bpc = lay->uniform_bpc;
+    fp.frames_per_block = plan->fpb;
+    fp.rounds = plan->c_rounds;
+    fp.waves = plan->x_waves;
+    fp.N = c.frame_length;
+    fp.shift = c.frame_shift;
+    fp.npad_left = plan->npad_left;
+    fp.M = c.num_filters;
+    fp.flags = (c.remove_dc_offset ? F_REMOVE_DC : 0) | (c.use_fft_mag ? F_FFT_MAG : 0) | (c.kind == HIPFEAT_LIBROSA_FBANK ? (F_CENTER | F_LOG10) : 0);
+    fp.preemph = c.preemph_coeff;
+    fp.mel_floor = c.mel_floor;
+    fp.shared_floats = plan->c_shared_floats;
+    fp.tws_off = plan->x_tws_off;
+    fp.tw32_off = plan->x_tw32_off;
+    fp.wtab_off = plan->c_wtab_off;
+    fp.ltab_off = plan->c_ltab_off;
+    fp.xs_floats = plan->c_xs_floats;
+    fp.nsets = plan->w_nsets;
+    for (int s2 = 0; s2 < kXMaxSets; ++s2) fp.steps[s2] = plan->w_steps[s2], fp.step0[s2] = plan->w_step0[s2];
+    DeviceGuard g(plan->device);
+    const dim3 grid((unsigned)lay->total_blocks), block(64 * plan->x_waves);
+    set_lds_poison(plan->fast_lds_bytes);
+    if (plan->x_odd) {
+      if (plan->nrows == 18) hipLaunchKernelGGL((fft2048c_kernel<18, true>), grid, block, plan->fast_lds_bytes, stream, fp);
+      else hipLaunchKernelGGL((fft2048c_kernel<32, true>), grid, block, plan->fast_lds_bytes, stream, fp);
+    } else {
+      if (plan->nrows == 19) hipLaunchKernelGGL((fft2048c_kernel<19, false>), grid, block, plan->fast_lds_bytes, stream, fp);
+      else hipLaunchKernelGGL((fft2048c_kernel<32, false>), grid, block, plan->fast_lds_bytes, stream, fp);
+    }
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }

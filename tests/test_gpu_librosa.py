@@ -1,4 +1,4 @@
-"""GPU: HipLibrosaFbank (kind HIPFEAT_LIBROSA_FBANK: fft1024c_kernel for n_fft 1024 with an even hop, wave_kernel for the other power-of-two FFT sizes,
+"""GPU: HipLibrosaFbank (kind HIPFEAT_LIBROSA_FBANK: fft1024c_kernel for n_fft 1024 with an even hop, fft2048c_kernel for n_fft 2048, wave_kernel for the other power-of-two FFT sizes,
 generic_kernel otherwise)
 against goldens produced by the reference's LibrosaFbank.extract (librosa's stft / mel restated, see
 oracle/librosa_ref.py) and against the oracle on seeded inputs.
@@ -47,7 +47,7 @@ def test_hip_librosa_matches_reference_golden(case):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     ex = LA.HipLibrosaFbank(_cfg(over))
     fft = over.get("fft_size", 1024)
-    assert ("wave_kernel" in ex.kernel_name or "fft1024c_kernel" in ex.kernel_name) == (fft & (fft - 1) == 0), ex.kernel_name
+    assert any(k in ex.kernel_name for k in ("wave_kernel", "fft1024c_kernel", "fft2048c_kernel")) == (fft & (fft - 1) == 0), ex.kernel_name
     for i, (kind, n, seed) in enumerate(inputs):
         x = make_signal(kind, n, seed)
         assert crc(x) == int(z[f"crc{i}"])
@@ -63,7 +63,7 @@ def test_hip_librosa_matches_reference_golden(case):
     [
         ({}, "fft1024c_kernel<32>"),  # the librosa defaults (22.05 kHz, n_fft 1024, hop 256): wave-autonomous kernel
         ({"sampling_rate": 16000, "fft_size": 512, "hop_size": 128, "num_mel_bins": 64, "fmin": 20, "fmax": None}, "wave_kernel<4>"),
-        ({"sampling_rate": 44100, "fft_size": 2048, "hop_size": 512, "win_length": 1764, "num_mel_bins": 128, "fmin": 0, "fmax": 16000}, "wave_kernel<16>"),
+        ({"sampling_rate": 44100, "fft_size": 2048, "hop_size": 512, "win_length": 1764, "num_mel_bins": 128, "fmin": 0, "fmax": 16000}, "fft2048c_kernel<32,0>"),
         ({"sampling_rate": 16000, "fft_size": 400, "hop_size": 160, "num_mel_bins": 80, "fmin": 0, "fmax": 8000}, "generic"),
         ({"sampling_rate": 8000, "fft_size": 256, "hop_size": 80, "win_length": 200, "window": "blackman", "num_mel_bins": 23, "fmin": 100, "fmax": 3800}, "generic"),
         ({"sampling_rate": 22050, "fft_size": 1024, "hop_size": 275, "win_length": 1000, "window": "hamming"}, "wave_kernel<8>"),
