@@ -307,10 +307,12 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
         const float m4 = lt[2], m8 = lt[3];
         const float* pa = myreg + poff;
         const float* wb = wtab + p.step0[s] * 64 + 4 * lane_o;
+        int nsteps = p.steps[s];  // opaque per round: keeps hipcc from hoisting (and then spilling) every "chunk exists" test
+        asm volatile("" : "+s"(nsteps));
         f32x4 av[kWMaxSteps / 4], bv[kWMaxSteps / 4];
 #pragma unroll
         for (int c4 = 0; c4 < kWMaxSteps / 4; ++c4) {
-          if (4 * c4 < p.steps[s]) {  // uniform
+          if (4 * c4 < nsteps) {  // uniform
             av[c4] = *reinterpret_cast<const f32x4*>(pa + 4 * c4);
             bv[c4] = *reinterpret_cast<const f32x4*>(wb + c4 * 256);
           }
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c4 = 0; c4 < kWMaxSteps / 4; c4 += 2) {
-          if (4 * c4 < p.steps[s]) {  // uniform; steps are padded to multiples of 8 on the host (zero weights)
+          if (4 * c4 < nsteps) {  // uniform; steps are padded to multiples of 8 on the host (zero weights)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c4][i], bv[c4][i], acc0, 0, 0, 0);

@@ -347,25 +347,29 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
         const float m4 = lt[2], m8 = lt[3];
         const float* pa = myreg + poff;
         const float* wb = wtab + p.step0[s] * 64 + 4 * lane_o;
+        // opaque per round: otherwise hipcc evaluates every "chunk c4 exists" test once per kernel, runs out of SGPRs for the results
+        // and fetches them back with v_readlane in front of every chunk
+        int nsteps = p.steps[s];
+        asm volatile("" : "+s"(nsteps));
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int blk8 = 0; blk8 < kXMaxSteps / 32; ++blk8) {
-          if (32 * blk8 < p.steps[s]) {  // uniform
+          if (32 * blk8 < nsteps) {  // uniform
             f32x4 av[8], bv[8];
 #pragma unroll
             for (int c4 = 0; c4 < 8; ++c4) {
-              if (32 * blk8 + 4 * c4 < p.steps[s]) {  // uniform
+              if (32 * blk8 + 4 * c4 < nsteps) {  // uniform
                 av[c4] = *reinterpret_cast<const f32x4*>(pa + 32 * blk8 + 4 * c4);
                 bv[c4] = *reinterpret_cast<const f32x4*>(wb + (8 * blk8 + c4) * 256);
               }
             }
 #pragma unroll
             for (int c4 = 0; c4 < 8; ++c4) {
-              if (32 * blk8 + 4 * c4 < p.steps[s]) {  // uniform
+              if (32 * blk8 + 4 * c4 < nsteps) {  // uniform
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  if (c4 & 1) acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c4][i], bv[c4][i], acc1, 0, 0, 0);
-                  else acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c4][i], bv[c4][i], acc0, 0, 0, 0);
+                for (int i = 0; i < 4; i += 2) {  // two accumulation chains, alternating: no back-to-back dependent MFMAs
+                  acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c4][i], bv[c4][i], acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[c4][i + 1], bv[c4][i + 1], acc1, 0, 0, 0);
                 }
               }
             }
