@@ -358,9 +358,9 @@ static std::vector<float> build_dct_operands(const hipfeat_config& c, const floa
 // --------------------------------------------------------------------------------------
 // fft512 wave-autonomous fbank kernel (kernel_fft512c.hpp); its filterbank schedule is built in mel4_schedule.hpp
 // --------------------------------------------------------------------------------------
-template <int NROWS>
+template <int NROWS, int NFULL>
 static const void* fft512c_entry() {
-  return reinterpret_cast<const void*>(&fft512c_kernel<NROWS>);
+  return reinterpret_cast<const void*>(&fft512c_kernel<NROWS, NFULL>);
 }
 
 // Returns HIPFEAT_OK with p->variant == 7 when the configuration takes the wave-autonomous kernel, HIPFEAT_OK with the
@@ -414,7 +414,8 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
   p->c_xs_floats = (3 * shift + 32 * nrows + 3) & ~3;
   const size_t lds = ((size_t)p->c_shared_floats + (size_t)kCWaves * (p->c_xs_floats + kCRegion)) * sizeof(float);
   if (lds > 80 * 1024 || (p->c_xs_floats >> 8) > 6) return HIPFEAT_OK;  // two workgroups of 8 waves per CU or nothing
-  const void* fn = nrows == 10 ? fft512c_entry<10>() : (nrows == 13 ? fft512c_entry<13>() : fft512c_entry<16>());
+  // 25 ms at 16 kHz (N = 400: 12 full rows of 32 samples + a partial one) gets the instance without length masks on the full rows
+  const void* fn = nrows == 10 ? fft512c_entry<10, 0>() : (nrows == 13 ? (N >= 384 ? fft512c_entry<13, 12>() : fft512c_entry<13, 0>()) : fft512c_entry<16, 0>());
   hipError_t e = ensure_dynamic_lds(fn, lds);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft512c) failed: %s", hipGetErrorName(e));
   hipfeat_status st;
@@ -1529,9 +1530,10 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(64 * kCWaves);
     set_lds_poison(plan->fast_lds_bytes);
-    if (plan->nrows == 10) hipLaunchKernelGGL(fft512c_kernel<10>, grid, block, plan->fast_lds_bytes, stream, fp);
-    else if (plan->nrows == 13) hipLaunchKernelGGL(fft512c_kernel<13>, grid, block, plan->fast_lds_bytes, stream, fp);
-    else hipLaunchKernelGGL(fft512c_kernel<16>, grid, block, plan->fast_lds_bytes, stream, fp);
+    if (plan->nrows == 10) hipLaunchKernelGGL((fft512c_kernel<10, 0>), grid, block, plan->fast_lds_bytes, stream, fp);
+    else if (plan->nrows == 13 && c.frame_length >= 384) hipLaunchKernelGGL((fft512c_kernel<13, 12>), grid, block, plan->fast_lds_bytes, stream, fp);
+    else if (plan->nrows == 13) hipLaunchKernelGGL((fft512c_kernel<13, 0>), grid, block, plan->fast_lds_bytes, stream, fp);
+    else hipLaunchKernelGGL((fft512c_kernel<16, 0>), grid, block, plan->fast_lds_bytes, stream, fp);
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }

@@ -62,7 +62,8 @@ struct Fft512cParams {
 // lane-index multiplies: v_mul_u32_u24 issues at the full VALU rate, v_mul_lo_u32 at a quarter of it
 __device__ __forceinline__ int mul24(int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); }
 
-template <int NROWS>
+// NROWS: pass-1 rows that can hold samples; NFULL: rows known to lie entirely inside the frame (N >= 32 NFULL): no length masks there
+template <int NROWS, int NFULL>
 __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   HF_POISON_LDS(smem);
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
       // samples at or beyond N (the frame length) are not part of the frame (uniform test per row, lane mask only in
       // the boundary rows)
 #pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) {
+      for (int n1 = NFULL; n1 < NROWS; ++n1) {
         if (32 * (n1 + 1) > N) {
           const int m0 = 32 * n1 + 2 * q;
           if (m0 >= N) z[n1].x = 0.f;
