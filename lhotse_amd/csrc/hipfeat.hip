@@ -113,7 +113,7 @@ struct hipfeat_plan {
   WaveWork* d_work = nullptr;
   // fft512 wave-autonomous fbank kernel (variant 7)
   float* d_c_shared = nullptr;  // LDS image: FFT constants | 4x4-block filterbank weights | lane tables
-  int c_shared_floats = 0, c_wtab_off = 0, c_ltab_off = 0, c_xs_floats = 0, c_rounds = 0;
+  int c_shared_floats = 0, c_wtab_off = 0, c_ltab_off = 0, c_xs_floats = 0, c_rounds = 0, c_mode = 0;
   // fft1024 wave-autonomous fbank kernel (variant 8; shares d_c_shared / c_* with variant 7)
   int w_nsets = 0, w_steps[kWMaxSets] = {}, w_step0[kWMaxSets] = {};
   // fft2048 wave-autonomous fbank kernel (variant 10; shares d_c_shared / c_* / w_* with variants 7 and 8)
@@ -358,18 +358,46 @@ static std::vector<float> build_dct_operands(const hipfeat_config& c, const floa
 // --------------------------------------------------------------------------------------
 // fft512 wave-autonomous fbank kernel (kernel_fft512c.hpp); its filterbank schedule is built in mel4_schedule.hpp
 // --------------------------------------------------------------------------------------
-template <int NROWS, int NFULL>
+template <int NROWS, int NFULL, int MODE>
 static const void* fft512c_entry() {
-  return reinterpret_cast<const void*>(&fft512c_kernel<NROWS, NFULL>);
+  return reinterpret_cast<const void*>(&fft512c_kernel<NROWS, NFULL, MODE>);
+}
+
+// (rows, frame length, mode) -> kernel instance; `launch` == false only returns the entry point
+template <int MODE>
+static const void* fft512c_pick(int nrows, int N, bool launch, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const Fft512cParams* fp) {
+  // 25 ms at 16 kHz (N = 400: 12 full rows of 32 samples + a partial one) gets the instance without length masks on the full rows
+#define HF_C_CASE(R, F)                                                                                   \
+  {                                                                                                       \
+    if (launch) hipLaunchKernelGGL((fft512c_kernel<R, F, MODE>), grid, block, lds, stream, *fp);          \
+    return fft512c_entry<R, F, MODE>();                                                                   \
+  }
+  if (nrows == 10) HF_C_CASE(10, 0)
+  if (nrows == 13 && N >= 384) HF_C_CASE(13, 12)
+  if (nrows == 13) HF_C_CASE(13, 0)
+  HF_C_CASE(16, 0)
+#undef HF_C_CASE
+}
+static const void* fft512c_dispatch(int mode, int nrows, int N, bool launch, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const Fft512cParams* fp) {
+  return mode == 0 ? fft512c_pick<0>(nrows, N, launch, grid, block, lds, stream, fp)
+                   : (mode == 1 ? fft512c_pick<1>(nrows, N, launch, grid, block, lds, stream, fp) : fft512c_pick<2>(nrows, N, launch, grid, block, lds, stream, fp));
 }
 
 // Returns HIPFEAT_OK with p->variant == 7 when the configuration takes the wave-autonomous kernel, HIPFEAT_OK with the
 // variant untouched when it does not (the caller then sets up kernel "b").
-static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, const float* h_mel, int nrows) {
+static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, const float* h_mel, int nrows, const float* h_dct, const float* h_lifter) {
   const hipfeat_config& c = p->cfg;
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
+  const bool mfcc = c.kind == HIPFEAT_MFCC;
+  if (mfcc && (M > 4 * kCDctChunks || c.num_ceps > 64 || !h_dct)) return HIPFEAT_OK;
+  // mode 0: 2 accumulator sets x 16 steps (many narrow filters); modes 1 / 2 (MFCC): 1 set x 32 steps (few, wide filters)
   Mel4Schedule sch;
-  if (!build_mel4_schedule(h_mel, M, p->K, kCPRowStride, kCMaxSets, kCMaxSteps, sch)) return HIPFEAT_OK;
+  int mode = mfcc ? 2 : 0;
+  if (mfcc || !build_mel4_schedule(h_mel, M, p->K, kCPRowStride, kCMaxSets, kCMaxSteps, sch)) {
+    if (!build_mel4_schedule(h_mel, M, p->K, kCPRowStride, 1, 2 * kCMaxSteps, sch)) return HIPFEAT_OK;
+    if (!mfcc) mode = 1;
+  }
+  const int tsets = mode == 0 ? kCMaxSets : 1, tsteps = mode == 0 ? kCMaxSteps : 2 * kCMaxSteps;
   // LDS image: window/2 as (even, odd) sample pairs per (row n1, lane q); pass twiddles W_256^(q k1) per (row k1, lane q);
   // split-step twiddles -i W_512^(q + 16 k2) per (row k2 < 8, lane q); then the filterbank tables
   std::vector<float> img((size_t)(nrows * 16 + 256 + 128) * 2, 0.0f);
@@ -393,16 +421,16 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
       tws[2 * (k2 * 16 + q)] = (float)std::sin(a);
       tws[2 * (k2 * 16 + q) + 1] = (float)(-std::cos(a));
     }
-  // the kernel runs kCMaxSets sets of kCMaxSteps steps unconditionally: pad the tables (weights 0, no output column)
+  // the kernel runs `tsets` sets of `tsteps` steps unconditionally: pad the tables (weights 0, no output column)
   p->c_wtab_off = (int)img.size();
-  img.resize(img.size() + (size_t)kCMaxSets * kCMaxSteps * 64, 0.0f);
+  img.resize(img.size() + (size_t)tsets * tsteps * 64, 0.0f);
   for (int s2 = 0; s2 < sch.nsets; ++s2)
-    std::memcpy(img.data() + p->c_wtab_off + (size_t)s2 * kCMaxSteps * 64, sch.wtab.data() + (size_t)sch.step0[s2] * 64, (size_t)sch.steps[s2] * 64 * sizeof(float));
+    std::memcpy(img.data() + p->c_wtab_off + (size_t)s2 * tsteps * 64, sch.wtab.data() + (size_t)sch.step0[s2] * 64, (size_t)sch.steps[s2] * 64 * sizeof(float));
   p->c_ltab_off = (int)img.size();
-  img.resize(img.size() + (size_t)kCMaxSets * 256, 0.0f);
+  img.resize(img.size() + (size_t)tsets * 256, 0.0f);
   {
     const int none = kMel4NoColumn;
-    for (int s2 = 0; s2 < kCMaxSets; ++s2)
+    for (int s2 = 0; s2 < tsets; ++s2)
       for (int lane = 0; lane < 64; ++lane) {
         float* lt = img.data() + p->c_ltab_off + ((size_t)s2 * 64 + lane) * 4;
         if (s2 < sch.nsets) std::memcpy(lt, sch.ltab.data() + ((size_t)s2 * 64 + lane) * 4, 4 * sizeof(float));
@@ -414,12 +442,20 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
   p->c_xs_floats = (3 * shift + 32 * nrows + 3) & ~3;
   const size_t lds = ((size_t)p->c_shared_floats + (size_t)kCWaves * (p->c_xs_floats + kCRegion)) * sizeof(float);
   if (lds > 80 * 1024 || (p->c_xs_floats >> 8) > 6) return HIPFEAT_OK;  // two workgroups of 8 waves per CU or nothing
-  // 25 ms at 16 kHz (N = 400: 12 full rows of 32 samples + a partial one) gets the instance without length masks on the full rows
-  const void* fn = nrows == 10 ? fft512c_entry<10, 0>() : (nrows == 13 ? (N >= 384 ? fft512c_entry<13, 12>() : fft512c_entry<13, 0>()) : fft512c_entry<16, 0>());
+  const void* fn = fft512c_dispatch(mode, nrows, N, false, dim3(), dim3(), 0, nullptr, nullptr);
   hipError_t e = ensure_dynamic_lds(fn, lds);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft512c) failed: %s", hipGetErrorName(e));
   hipfeat_status st;
   if ((st = upload(&p->d_c_shared, img.data(), img.size())) != HIPFEAT_OK) return st;
+  if (mfcc) {  // DCT operands in matrix-core lane order: [chunk of 4 filters][lane = cepstral coefficient][filter in the chunk], then the lifter
+    const int C = c.num_ceps;
+    std::vector<float> dt((size_t)kCDctChunks * 256 + 64, 0.0f);
+    for (int m = 0; m < M; ++m)
+      for (int cc = 0; cc < C; ++cc) dt[((size_t)(m / 4) * 64 + cc) * 4 + (m & 3)] = h_dct[(size_t)m * C + cc];
+    for (int cc = 0; cc < 64; ++cc) dt[(size_t)kCDctChunks * 256 + cc] = (c.apply_lifter && h_lifter && cc < C) ? h_lifter[cc] : 1.0f;
+    if ((st = upload(&p->d_dct_consts, dt.data(), dt.size())) != HIPFEAT_OK) return st;
+  }
+  p->c_mode = mode;
   p->nrows = nrows;
   p->c_rounds = 8;  // 8 waves x 8 rounds x 4 frames = 256 frames per workgroup
   p->fpb = kCWaves * p->c_rounds * 4;
@@ -429,7 +465,7 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
   int total_steps = 0;
   for (int s2 = 0; s2 < sch.nsets; ++s2) total_steps += sch.steps[s2];
   char nm[128];
-  snprintf(nm, sizeof(nm), "fft512c_kernel<%d> fbank lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, lds, p->blocks_per_cu, sch.nsets, total_steps);
+  snprintf(nm, sizeof(nm), "fft512c_kernel<%d> %s lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, mfcc ? "mfcc" : "fbank", lds, p->blocks_per_cu, sch.nsets, total_steps);
   p->kernel_name = nm;
   p->variant = 7;
   return HIPFEAT_OK;
@@ -451,10 +487,10 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   const int ntiles = spec ? 0 : (M + 15) / 16;
   if (ntiles > 8) return HIPFEAT_OK;
 
-  if (!mfcc && !spec) {  // log-mel filterbank: the wave-autonomous kernel, unless the schedule or the LDS budget says no
+  if (!spec) {  // log-mel filterbank / MFCC: the wave-autonomous kernel, unless the schedule or the LDS budget says no
     const char* var = getenv("HIPFEAT_FFT512_VARIANT");
-    if (!(var && var[0] == 'b')) {  // HIPFEAT_FFT512_VARIANT=b: the 16-frame-tile kernel for log-mel too (tests compare the two)
-      hipfeat_status stc = setup_fft512c(p, h_window, h_mel, nrows);
+    if (!(var && var[0] == 'b')) {  // HIPFEAT_FFT512_VARIANT=b: the 16-frame-tile kernel for these too (tests compare the two)
+      hipfeat_status stc = setup_fft512c(p, h_window, h_mel, nrows, h_dct, h_lifter);
       if (stc != HIPFEAT_OK || p->variant == 7) return stc;
     }
   }
@@ -1527,13 +1563,12 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.wtab_off = plan->c_wtab_off;
     fp.ltab_off = plan->c_ltab_off;
     fp.xs_floats = plan->c_xs_floats;
+    fp.dct_tab = plan->d_dct_consts;
+    fp.C = c.num_ceps;
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(64 * kCWaves);
     set_lds_poison(plan->fast_lds_bytes);
-    if (plan->nrows == 10) hipLaunchKernelGGL((fft512c_kernel<10, 0>), grid, block, plan->fast_lds_bytes, stream, fp);
-    else if (plan->nrows == 13 && c.frame_length >= 384) hipLaunchKernelGGL((fft512c_kernel<13, 12>), grid, block, plan->fast_lds_bytes, stream, fp);
-    else if (plan->nrows == 13) hipLaunchKernelGGL((fft512c_kernel<13, 0>), grid, block, plan->fast_lds_bytes, stream, fp);
-    else hipLaunchKernelGGL((fft512c_kernel<16, 0>), grid, block, plan->fast_lds_bytes, stream, fp);
+    fft512c_dispatch(plan->c_mode, plan->nrows, c.frame_length, true, grid, block, plan->fast_lds_bytes, stream, &fp);
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }

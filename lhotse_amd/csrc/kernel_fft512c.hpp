@@ -34,6 +34,8 @@ constexpr int kCRegion = 4 * kCExFrameStride + 16;         // 1168 dwords per wa
 constexpr int kCMaxSets = 2;                               // accumulator sets (16 slots each)
 constexpr int kCMaxSteps = 16;                             // MFMA steps per set
 constexpr int kCWaves = 8;                                 // waves per workgroup
+constexpr int kCLmStride = 48;                             // MFCC: floats per log-mel row in LDS (<= 40 filters; rows 3 bank quads apart)
+constexpr int kCDctChunks = 10;                            // MFCC: DCT steps / 4 (<= 40 filters), operands resident in registers
 
 struct Fft512cParams {
   const float* wave;
@@ -51,6 +53,9 @@ struct Fft512cParams {
   int32_t shared_floats;  // floats of the shared image
   int32_t wtab_off, ltab_off;  // float offsets of the weight / lane tables inside the image
   int32_t xs_floats;      // floats of one wave's sample-span buffer (multiple of 4)
+  // MFCC (MODE 2): [kCDctChunks][64 lanes][4] DCT operands (lane = cepstral coefficient, step = filter; layers.py:697-706), then [64] lifter
+  const float* dct_tab;
+  int32_t C;
 };
 
 #ifdef HIPFEAT_PHASE_TIMERS
@@ -62,8 +67,10 @@ struct Fft512cParams {
 // lane-index multiplies: v_mul_u32_u24 issues at the full VALU rate, v_mul_lo_u32 at a quarter of it
 __device__ __forceinline__ int mul24(int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); }
 
-// NROWS: pass-1 rows that can hold samples; NFULL: rows known to lie entirely inside the frame (N >= 32 NFULL): no length masks there
-template <int NROWS, int NFULL>
+// NROWS: pass-1 rows that can hold samples; NFULL: rows known to lie entirely inside the frame (N >= 32 NFULL): no length masks there;
+// MODE 0: log-mel filterbank on 2 accumulator sets x 16 steps (many narrow filters: the 80-filter default); 1: log-mel on 1 set x 32
+// steps (few, wide filters: 23 / 40); 2: MFCC = mode 1 + the DCT as a second run of 4 x 4 x 1 blocks (Wav2MFCC, layers.py:708-724)
+template <int NROWS, int NFULL, int MODE>
 __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   HF_POISON_LDS(smem);
@@ -126,6 +133,14 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
   __syncthreads();  // the constant tables are in place (the only workgroup barrier of the kernel)
   if (first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
 
+  // MFCC: the DCT operands of this lane (its cepstral coefficient x every filter) and its lifter value stay in registers
+  f32x4 dw[MODE == 2 ? kCDctChunks : 1];
+  float lift = 1.0f;
+  if (MODE == 2) {
+#pragma unroll
+    for (int c4 = 0; c4 < kCDctChunks; ++c4) dw[c4] = *reinterpret_cast<const f32x4*>(p.dct_tab + (c4 * 64 + lane) * 4);
+    lift = p.dct_tab[kCDctChunks * 256 + lane];
+  }
 #ifdef HIPFEAT_PHASE_TIMERS
   unsigned long long hfc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hfc_last = __builtin_readcyclecounter();
 #endif
@@ -302,35 +317,50 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
     // same in-order vmcnt queue: waiting here instead of at the top of the next round never waits for the stores
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     float* orow = p.out + (cd.out_row + f0) * p.out_stride;
-    int lt_poff[kCMaxSets], lt_col[kCMaxSets];
-    float lt_m4[kCMaxSets], lt_m8[kCMaxSets];
+    constexpr int S = MODE == 0 ? kCMaxSets : 1, T = MODE == 0 ? kCMaxSteps : 2 * kCMaxSteps;  // S x T = 32 steps either way
+    int lt_poff[S], lt_col[S];
+    float lt_m4[S], lt_m8[S];
 #pragma unroll
-    for (int s = 0; s < kCMaxSets; ++s) {
+    for (int s = 0; s < S; ++s) {
       const float* lt = ltab + s * 256 + 4 * lane_o;
       lt_poff[s] = __builtin_bit_cast(int, lt[0]);
       lt_col[s] = __builtin_bit_cast(int, lt[1]);
       lt_m4[s] = lt[2];
       lt_m8[s] = lt[3];
     }
-    f32x4 av[kCMaxSets][kCMaxSteps / 4], bv[kCMaxSets][kCMaxSteps / 4];
+    f32x4 av[S][T / 4], bv[S][T / 4];
 #pragma unroll
-    for (int s = 0; s < kCMaxSets; ++s) {
+    for (int s = 0; s < S; ++s) {
       const float* pa = myreg + lt_poff[s];
-      const float* wb = wtab + s * (kCMaxSteps * 64) + 4 * lane_o;
+      const float* wb = wtab + s * (T * 64) + 4 * lane_o;
 #pragma unroll
-      for (int c4 = 0; c4 < kCMaxSteps / 4; ++c4) {
+      for (int c4 = 0; c4 < T / 4; ++c4) {
         av[s][c4] = *reinterpret_cast<const f32x4*>(pa + 4 * c4);
         bv[s][c4] = *reinterpret_cast<const f32x4*>(wb + c4 * 256);
       }
     }
     HFC_T(5);  // operand reads of the mel phase issued (not yet waited for)
+    float lm[4];  // MODE 2: the lane's log-mel values of the four frames
 #pragma unroll
-    for (int s = 0; s < kCMaxSets; ++s) {
+    for (int s = 0; s < S; ++s) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (MODE == 0) {
 #pragma unroll
-      for (int c4 = 0; c4 < kCMaxSteps / 4; ++c4) {
+        for (int c4 = 0; c4 < T / 4; ++c4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s][c4][i], bv[s][c4][i], acc, 0, 0, 0);
+          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s][c4][i], bv[s][c4][i], acc, 0, 0, 0);
+        }
+      } else {  // one set of 32 steps: two accumulation chains
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c4 = 0; c4 < T / 4; ++c4) {
+#pragma unroll
+          for (int i = 0; i < 4; i += 2) {
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s][c4][i], bv[s][c4][i], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s][c4][i + 1], bv[s][c4][i + 1], acc1, 0, 0, 0);
+          }
+        }
+        acc += acc1;
       }
       const int col = lt_col[s];
       const float m4 = lt_m4[s], m8 = lt_m8[s];
@@ -340,8 +370,41 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4 -- the odd slot of a pair takes its left neighbour's partial sum
         v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8 -- the last slot of a group of 3 or 4 takes the first slot(s)'
         v = fast_log(fmaxf(v, p.mel_floor));
-        if (col < p.M && i < nf) orow[i * p.out_stride + col] = v;
+        if (MODE == 2) lm[i] = v;
+        else if (col < p.M && i < nf) orow[i * p.out_stride + col] = v;
       }
+    }
+    if (MODE == 2) {
+      // ---- DCT on the matrix cores: block = (4 frames) x (4 cepstral coefficients) x (1 filter); all 16 blocks walk the filters together.
+      // The power rows are dead (every operand of the filterbank sits in registers): the four log-mel rows overwrite their start.
+      float* lmrow = myreg;
+      const int col = lt_col[0];
+      if (col < p.M) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lmrow[i * kCLmStride + col] = lm[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      f32x4 al[kCDctChunks];  // A operand: lane (block b, frame i) = log-mel of frame i, four filters per read (the same for every block)
+#pragma unroll
+      for (int c4 = 0; c4 < kCDctChunks; ++c4) al[c4] = *reinterpret_cast<const f32x4*>(lmrow + (lane_o & 3) * kCLmStride + 4 * c4);
+      f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c4 = 0; c4 < kCDctChunks; ++c4) {
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(al[c4][i], dw[c4][i], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(al[c4][i + 1], dw[c4][i + 1], d1, 0, 0, 0);
+        }
+      }
+      d0 += d1;
+      if (lane_o < p.C) {  // lane = cepstral coefficient, register = frame
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nf) orow[i * p.out_stride + lane_o] = d0[i] * lift;
+      }
+      // the next round's exchange writes follow these reads in the wave's own LDS queue (in order)
     }
     HFC_T(6);  // MFMAs, reduction, log, stores
 #ifdef HIPFEAT_PHASE_TIMERS

@@ -318,18 +318,33 @@ def test_generic_and_fast_kernels_agree(monkeypatch):
         assert err_stats(a, b)["rel_l2"] < 2e-6
     for a, b in zip(outs["fast_c"][1], outs["fast_b"][1]):
         assert err_stats(a, b)["rel_l2"] < 2e-6
+    # the same three for MFCC (40 filters x 40 cepstra) and for a 23-filter log-mel bank (one accumulator set of 32 steps)
+    for kind, cfg in (("mfcc", {"num_filters": 40, "num_ceps": 40}), ("mfcc", {}), ("fbank", {"num_filters": 23})):
+        res = {}
+        for name, env in [("fast_c", {}), ("fast_b", {"HIPFEAT_FFT512_VARIANT": "b"}), ("generic", {"HIPFEAT_FORCE_GENERIC": "1"})]:
+            for k in ("HIPFEAT_FFT512_VARIANT", "HIPFEAT_FORCE_GENERIC"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ex = make_hip(kind, cfg)
+            res[name] = (ex.kernel_name, ex.extract_batch(waves, 16000))
+        assert res["fast_c"][0].startswith("fft512c_kernel<13>") and res["fast_b"][0].startswith("fft512b_kernel") and res["generic"][0] == "generic", res["fast_c"][0]
+        for a, b, g in zip(res["fast_c"][1], res["fast_b"][1], res["generic"][1]):
+            assert np.abs(a - b).max() <= 2e-3 and np.abs(a - g).max() <= 2e-3, (kind, cfg, np.abs(a - b).max(), np.abs(a - g).max())
 
 
-@pytest.mark.parametrize("cfg,fast", [({}, True), ({"num_filters": 40, "num_ceps": 40}, True),
-                                      ({"num_filters": 80, "num_ceps": 20, "cepstral_lifter": 0}, True),
-                                      ({"num_filters": 40, "num_ceps": 13, "frame_length": 0.02}, True)])
-def test_mfcc_fast_path(cfg, fast):
-    """MFCC on the fft512 kernel (DCT as a second MFMA GEMM) against the oracle, including the 23-filter /
-    13-cepstra Kaldi default whose 16-mel tiles have 112- and 144-bin bands."""
+@pytest.mark.parametrize("cfg,kernel", [({}, "fft512c_kernel<13> mfcc"), ({"num_filters": 40, "num_ceps": 40}, "fft512c_kernel<13> mfcc"),
+                                        ({"num_filters": 80, "num_ceps": 20, "cepstral_lifter": 0}, "fft512b_kernel<13,1> mfcc"),
+                                        ({"num_filters": 40, "num_ceps": 13, "frame_length": 0.02}, "fft512c_kernel<10> mfcc"),
+                                        ({"num_filters": 30, "num_ceps": 30, "cepstral_lifter": 0, "preemph_coeff": 0.0, "window_type": "hamming"}, "fft512c_kernel<13> mfcc")])
+def test_mfcc_fast_path(cfg, kernel):
+    """MFCC on the fft512 kernels against the oracle: the wave-autonomous kernel (filterbank on one accumulator set of 32 steps, DCT as a
+    second run of 4 x 4 x 1 matrix-core blocks with its operands resident in registers) for up to 40 filters -- including the 23-filter /
+    13-cepstra Kaldi default --, the 16-frame-tile kernel (DCT as a 16 x 16 x 4 GEMM) beyond."""
     from _hip import make_hip
 
     ex = make_hip("mfcc", cfg)
-    assert (ex.kernel_name.startswith("fft512b_kernel") and " mfcc " in ex.kernel_name) == fast, ex.kernel_name
+    assert ex.kernel_name.startswith(kernel), ex.kernel_name
     rs = np.random.RandomState(21)
     waves = [(rs.rand(n).astype(np.float32) - 0.5) for n in (16000, 140, 31999, 160000, 5000)]
     outs = ex.extract_batch(waves, 16000)
