@@ -59,7 +59,6 @@ __global__ __launch_bounds__(256, 4) void fft512b_kernel(const Fft512Params p) {
   const CutDesc cd = p.cuts[cut];
   const float* __restrict__ w = p.wave + cd.wave_off;
   const int N = p.N, shift = p.shift;
-  const int span = (kTileFrames - 1) * shift + N;
   const int nchunks = (p.xs_floats + 255) >> 8;  // 1 KiB LDS-DMA chunks covering the span buffer
 
   for (int i = tid; i < p.const_floats; i += 256) smem[p.xs_floats + i] = p.lds_consts[i];

@@ -96,7 +96,6 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
   const CutDesc cd = p.cuts[cut];
   const float* __restrict__ w = p.wave + cd.wave_off;
   const int N = p.N, shift = p.shift;
-  const int span = 3 * shift + N;
 
   for (int i = tid; i < p.shared_floats; i += 64 * kCWaves) smem[i] = p.shared_consts[i];
   float* xs = smem + p.shared_floats + wv * (p.xs_floats + kCRegion);
