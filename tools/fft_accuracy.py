@@ -11,7 +11,7 @@ def rep(name, y):
     i = np.unravel_index(np.argmax(d / t64), d.shape)
     print(f"{name:10s} max abs err / frame max power = {rel.max():.3e}   mean = {rel.mean():.3e}   worst bin rel err = {(d / t64).max():.3e} at (frame, bin) {i}; rel err by bin class: DC {(d / t64)[:, 0].max():.2e} Nyquist {(d / t64)[:, 256].max():.2e} bin128 {(d / t64)[:, 128].max():.2e} others {np.delete(d / t64, [0, 128, 256], axis=1).max():.2e}")
 rep("oracle32", o32)
-for env, name in [({}, "fast_c"), ({"HIPFEAT_FFT512_VARIANT": "b"}, "fast_b"), ({"HIPFEAT_FORCE_GENERIC": "1"}, "generic")]:
+for env, name in [({}, "fast"), ({"HIPFEAT_FORCE_GENERIC": "1"}, "generic")]:
     for k in ("HIPFEAT_FORCE_GENERIC", "HIPFEAT_FFT512_VARIANT"): os.environ.pop(k, None)
     os.environ.update(env)
     ex = make_hip("spectrogram", {})
