@@ -47,6 +47,14 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long lo
     } else if (MODE == 9) {  // 4 x ds_bpermute_b32
       REP4(asm volatile("ds_bpermute_b32 %0, %2, %3\n ds_bpermute_b32 %1, %2, %3\n ds_bpermute_b32 %0, %2, %3\n ds_bpermute_b32 %1, %2, %3\n s_waitcnt lgkmcnt(0)"
                         : "=v"(s0), "=v"(s1) : "v"(a4), "v"((float)lane));)
+    } else if (MODE >= 12 && MODE <= 14) {
+      // 2 x ds_read_b128 with the A-operand pattern of the 4x4x1 mel phase: lane = 4 slot + frame, frame rows 272 dwords apart
+      // (16 bank quads), slot start = 4 s dwords with s = slot % 4 (MODE 12: the four slots of a 16-lane group cover all 64 banks),
+      // (slot % 4) / 2 (MODE 13: two slots per 16 banks), 0 (MODE 14: all four slots on the same 16 banks)
+      const int slot = lane >> 2, fr = lane & 3;
+      const int sv = MODE == 12 ? (slot & 3) : (MODE == 13 ? ((slot & 3) >> 1) : 0);
+      const unsigned ap = (unsigned)(wv * 8192 + (fr * 272 + 4 * sv + 16 * (slot & 3) + 64 * (slot >> 2)) * 4);  // distinct addresses in every lane
+      REP4(asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2 offset:16\n s_waitcnt lgkmcnt(0)" : "=v"(q0), "=v"(q1) : "v"(ap));)
     } else if (MODE == 10) {  // 16 x ds_read_b64, one wait (burst as the kernels issue them)
       asm volatile(
           "ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:512\n ds_read_b64 %2, %4 offset:1024\n ds_read_b64 %3, %4 offset:1536\n"
@@ -114,6 +122,9 @@ int main() {
     run<7>(w, "ds_write2_b64 x2 /wait", 4 * 4 * 512.0, 8);
     run<8>(w, "ds_write_b128 x2 /wait", 4 * 2 * 1024.0, 8);
     run<9>(w, "ds_bpermute_b32 x4 /wait", 4 * 4 * 256.0, 16);
+    run<12>(w, "b128 mel-A, 4 slots x 16 banks", 4 * 2 * 1024.0, 8);
+    run<13>(w, "b128 mel-A, 2 slots share", 4 * 2 * 1024.0, 8);
+    run<14>(w, "b128 mel-A, 4 slots share", 4 * 2 * 1024.0, 8);
   }
   return 0;
 }
