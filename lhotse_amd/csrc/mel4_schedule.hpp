@@ -45,7 +45,8 @@ inline bool build_mel4_schedule(const float* h_mel, int M, int K, int prow_strid
         }
     if (h > 0) lo[g] = l & ~3, alen[g] = h - (l & ~3);
   }
-  struct Place { int set, row, pos, cnt; };
+  // pstride: bins between the starts of consecutive pieces of a split group; shift: bins (multiple of 4) the first piece starts below lo
+  struct Place { int set, row, pos, cnt, pstride, shift; };
   struct Plan { int total = 1 << 30; std::vector<int> T; std::vector<Place> place; };
   Plan best;
   std::vector<int> order(ng);
@@ -59,22 +60,40 @@ inline bool build_mel4_schedule(const float* h_mel, int M, int K, int prow_strid
     int total = 0;
     for (int t : T) total += t;
     if (total >= best.total) return;
-    // free[s][r][pos]
+    // free[s][r][pos]; quads[s][r][q]: slots of DPP row r whose reads start on bank quad q (mod 16 dwords).  A 16-lane group of the
+    // kernels' ds_read_b128 is conflict-free only if its four slots start on four different quads (tools/ubench/lds_rate.hip: 3.9 /
+    // 7.1 / 12.1 clk per instruction for 1 / 2 / 4 slots per quad), so placement minimises the worst multiplicity of the row.
     std::vector<std::vector<std::vector<char>>> used(ns, std::vector<std::vector<char>>(4, std::vector<char>(4, 0)));
+    std::vector<std::vector<std::vector<int>>> quads(ns, std::vector<std::vector<int>>(4, std::vector<int>(4, 0)));
     std::vector<Place> place(ng);
-    auto fit = [&](int s, int c, Place& pl) {
+    auto fit = [&](int g, int s, int c, Place& pl) {
+      const int Ts = T[s];
+      // pieces of a split group: a stride that is an odd number of quads puts them on different quads by itself; otherwise stagger
+      // them by one quad less (Ts - 4) when the band still fits
+      int pstride = Ts;
+      if (c > 1 && ((Ts / 4) & 1) == 0 && (c > 2 || ((Ts / 4) & 3) == 0) && (c - 1) * (Ts - 4) + Ts >= alen[g]) pstride = Ts - 4;
+      const int cap = (c - 1) * pstride + Ts;
+      int best_cost = 1 << 30;
       for (int r = 0; r < 4; ++r) {
         const int step = c == 2 ? 2 : (c == 1 ? 1 : 4);
         for (int pos = 0; pos + c <= 4; pos += step) {
           bool fr = true;
           for (int k = 0; k < c; ++k) fr = fr && !used[s][r][pos + k];
-          if (fr) {
-            pl = Place{s, r, pos, c};
-            return true;
+          if (!fr) continue;
+          for (int shift = 0; shift <= 12 && shift <= lo[g] && alen[g] + shift <= cap; shift += 4) {
+            int q[4] = {quads[s][r][0], quads[s][r][1], quads[s][r][2], quads[s][r][3]};
+            for (int k = 0; k < c; ++k) ++q[((lo[g] - shift + k * pstride) / 4) & 3];
+            const int mult = std::max(std::max(q[0], q[1]), std::max(q[2], q[3]));
+            const int cost = mult * 64 + r * 4 + pos + (shift ? 16 : 0);  // fewest conflicts, then first fit, unshifted preferred
+            if (cost < best_cost) {
+              best_cost = cost;
+              pl = Place{s, r, pos, c, pstride, shift};
+            }
           }
+          break;  // positions further right in the same row are equivalent for the row's quad census
         }
       }
-      return false;
+      return best_cost != (1 << 30);
     };
     for (int g : order) {
       // candidate sets ordered by slots needed (fewest first), then by smaller step count
@@ -88,8 +107,11 @@ inline bool build_mel4_schedule(const float* h_mel, int M, int K, int prow_strid
       bool done = false;
       for (int s : cand) {
         Place pl;
-        if (fit(s, (alen[g] + T[s] - 1) / T[s], pl)) {
-          for (int k = 0; k < pl.cnt; ++k) used[s][pl.row][pl.pos + k] = 1;
+        if (fit(g, s, (alen[g] + T[s] - 1) / T[s], pl)) {
+          for (int k = 0; k < pl.cnt; ++k) {
+            used[s][pl.row][pl.pos + k] = 1;
+            ++quads[s][pl.row][((lo[g] - pl.shift + k * pl.pstride) / 4) & 3];
+          }
           place[g] = pl;
           done = true;
           break;
@@ -142,8 +164,8 @@ inline bool build_mel4_schedule(const float* h_mel, int M, int K, int prow_strid
     const int Ts = best.T[pl.set];
     for (int k = 0; k < pl.cnt; ++k) {
       const int b = 4 * pl.row + pl.pos + k;  // slot index inside the set
-      int bin0 = lo[g] + k * Ts;
-      const int slo = bin0, shi = std::min(lo[g] + alen[g], bin0 + Ts);
+      int bin0 = lo[g] - pl.shift + k * pl.pstride;
+      const int slo = bin0, shi = std::min(lo[g] + alen[g], k + 1 < pl.cnt ? bin0 + pl.pstride : bin0 + Ts);
       bin0 = std::max(0, std::min(bin0, (prow_stride - Ts) & ~3));
       for (int t = 0; t < Ts; ++t) {
         const int bin = bin0 + t;
