@@ -190,17 +190,33 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
       }
 #pragma unroll
       for (int n1 = NROWS; n1 < 32; ++n1) z[n1] = v2{0.f, 0.f};
-      // the pass twiddles W_512^(q k1) are requested before the 32-point FFT (62 registers that a 2-waves-per-SIMD kernel has)
+      // the pass twiddles W_512^(q k1) are requested before the 32-point FFT (62 registers that a 2-waves-per-SIMD kernel has) --
+      // except when all 32 input rows are live (NROWS == 32: that request would spill): then in two bursts of 16 after it
       v2 twp[32];
+      if (NROWS < 32) {
 #pragma unroll
-      for (int k1 = 1; k1 < 32; ++k1) {
-        twp[k1] = ctwp[k1 * 16 + q];
-        HFC_SEP();
+        for (int k1 = 1; k1 < 32; ++k1) {
+          twp[k1] = ctwp[k1 * 16 + q];
+          HFC_SEP();
+        }
       }
       v2 a[32];
       fft32<NROWS>(z, a);
+      if (NROWS < 32) {
 #pragma unroll
-      for (int k1 = 1; k1 < 32; ++k1) a[k1] = cmul2(a[k1], twp[k1]);
+        for (int k1 = 1; k1 < 32; ++k1) a[k1] = cmul2(a[k1], twp[k1]);
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int k1 = 16 * h + (h == 0 ? 1 : 0); k1 < 16 * h + 16; ++k1) {
+            twp[k1] = ctwp[k1 * 16 + q];
+            HFC_SEP();
+          }
+#pragma unroll
+          for (int k1 = 16 * h + (h == 0 ? 1 : 0); k1 < 16 * h + 16; ++k1) a[k1] = cmul2(a[k1], twp[k1]);
+        }
+      }
       HFC_T(2);  // mean, prolog, pass 1, twiddles
       // exchange in two halves of 16 rows: half 0 carries every lane's first row (k1 = q), half 1 its second one
       // (k1 = 32 - q, i.e. slot (16 - q) % 16 of the half; lane 0: k1 = 16, slot 0)

@@ -168,16 +168,18 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
         }
         // the pass twiddles W_1024^(q k1) come from global memory (L1): requested BEFORE the next span, so that the wait for them
         // (vmcnt is in order) does not include the span's trip to HBM
+        // (with all 32 input rows live -- NROWS == 32 -- that request would spill: there both the twiddle request and, after it, the
+        // span request follow the 32-point FFT)
         v2 twp[32];
-        {
-          const v2* gt = reinterpret_cast<const v2*>(p.twp) + q;
+        const v2* gt = reinterpret_cast<const v2*>(p.twp) + q;
+        if (NROWS < 32) {
 #pragma unroll
           for (int k1 = 1; k1 < 32; ++k1) twp[k1] = gt[k1 * 32];
         }
         // the samples are in flight to registers; once they have arrived the buffer is free for the next round's span
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         HFC_T(0);  // sample, neighbour and window reads
-        if (r + 1 < p.rounds && f0 + 2 * p.waves < cd.num_frames) stage_span(f0 + 2 * p.waves, (unsigned)lane_o * 4u);
+        if (NROWS < 32 && r + 1 < p.rounds && f0 + 2 * p.waves < cd.num_frames) stage_span(f0 + 2 * p.waves, (unsigned)lane_o * 4u);
         HFC_T(1);  // span request (LDS-DMA issue)
 
 #pragma unroll
@@ -217,6 +219,12 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
 #pragma unroll
         for (int n1 = NROWS; n1 < 32; ++n1) z[n1] = v2{0.f, 0.f};
         fft32<NROWS>(z, a);
+        if (NROWS == 32) {
+          asm volatile("" : "+v"(a[0].x), "+v"(a[31].y) : : "memory");  // not before the FFT's results exist (hipcc would hoist the loads)
+#pragma unroll
+          for (int k1 = 1; k1 < 32; ++k1) twp[k1] = gt[k1 * 32];
+          if (r + 1 < p.rounds && f0 + 2 * p.waves < cd.num_frames) stage_span(f0 + 2 * p.waves, (unsigned)lane_o * 4u);
+        }
 #pragma unroll
         for (int k1 = 1; k1 < 32; ++k1) a[k1] = cmul2(a[k1], twp[k1]);
       }
