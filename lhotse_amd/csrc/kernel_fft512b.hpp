@@ -93,6 +93,18 @@ __global__ __launch_bounds__(256, 4) void fft512b_kernel(const Fft512Params p) {
   const int first_tile = fb * p.tiles_per_block;
   if (first_tile * kTileFrames < cd.num_frames) stage_span(first_tile * kTileFrames, (unsigned)lane * 16u);
 
+  // (log-)spectrograms: both twiddle tables of this lane stay in registers for the whole kernel (as in kernel_fft512c.hpp; the other
+  // output stages have no room for them under the 4-waves-per-SIMD register budget); read from the global copy of the tables: the LDS
+  // copy is not yet visible here
+  constexpr bool kRegTw = SPEC && NROWS <= 13;
+  v2 twpreg[kRegTw ? 16 : 1], twsreg[kRegTw ? 8 : 1];
+  if (kRegTw) {
+    const v2* gtw = reinterpret_cast<const v2*>(p.lds_consts) + NROWS * 16 + (lane & 15);
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) twpreg[k1] = gtw[k1 * 16];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) twsreg[k2] = gtw[256 + k2 * 16];
+  }
 #ifdef HIPFEAT_PHASE_TIMERS
   unsigned long long hf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -159,8 +171,13 @@ __global__ __launch_bounds__(256, 4) void fft512b_kernel(const Fft512Params p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         v2 tw[8];
+        if (kRegTw) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { tw[r] = ctwp[(8 * h + r) * 16 + q]; HF_SEP(); }
+          for (int r = 0; r < 8; ++r) tw[r] = twpreg[8 * h + r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) { tw[r] = ctwp[(8 * h + r) * 16 + q]; HF_SEP(); }
+        }
 #pragma unroll
         for (int r = (h == 0 ? 1 : 0); r < 8; ++r) a[8 * h + r] = cmul2(a[8 * h + r], tw[r]);
       }
@@ -209,8 +226,11 @@ __global__ __launch_bounds__(256, 4) void fft512b_kernel(const Fft512Params p) {
         v2 tw[4];  // split-step twiddles of 4 bin pairs per burst
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          tw[r] = ctws[(4 * h + r) * 16 + q];
-          HF_SEP();
+          if (kRegTw) tw[r] = twsreg[4 * h + r];
+          else {
+            tw[r] = ctws[(4 * h + r) * 16 + q];
+            HF_SEP();
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -132,6 +132,17 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
   __syncthreads();  // the constant tables are in place (the only workgroup barrier of the kernel)
   if (first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
 
+  // Both twiddle tables of this lane (15 + 8 complex values) live in registers for the whole kernel where the register budget of 4 waves
+  // per SIMD allows it (not in MFCC mode, whose DCT operands take that room): 24 LDS reads less per round, + 4.9 % (same-call A/B).  The
+  // window on top of that does not fit (10 spilled registers, - 2.5 %).
+  constexpr bool kRegTw = MODE != 2 && NROWS <= 13;  // (16 live input rows leave no room either: 24 spilled registers)
+  v2 twpreg[kRegTw ? 16 : 1], twsreg[kRegTw ? 8 : 1];
+  if (kRegTw) {
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) twpreg[k1] = ctwp[k1 * 16 + (lane & 15)];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) twsreg[k2] = ctws[k2 * 16 + (lane & 15)];
+  }
   // MFCC: the DCT operands of this lane (its cepstral coefficient x every filter) and its lifter value stay in registers
   f32x4 dw[MODE == 2 ? kCDctChunks : 1];
   float lift = 1.0f;
@@ -227,10 +238,15 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         v2 tw[8];
+        if (kRegTw) {
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-          tw[rr] = ctwp[(8 * h + rr) * 16 + q];
-          HFC_SEP();
+          for (int rr = 0; rr < 8; ++rr) tw[rr] = twpreg[8 * h + rr];
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) {
+            tw[rr] = ctwp[(8 * h + rr) * 16 + q];
+            HFC_SEP();
+          }
         }
 #pragma unroll
         for (int rr = (h == 0 ? 1 : 0); rr < 8; ++rr) a[8 * h + rr] = cmul2(a[8 * h + rr], tw[rr]);
@@ -283,10 +299,15 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         v2 tw[4];  // split-step twiddles of 4 bin pairs per burst
+        if (kRegTw) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          tw[rr] = ctws[(4 * h + rr) * 16 + q];
-          HFC_SEP();
+          for (int rr = 0; rr < 4; ++rr) tw[rr] = twsreg[4 * h + rr];
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            tw[rr] = ctws[(4 * h + rr) * 16 + q];
+            HFC_SEP();
+          }
         }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {

@@ -103,6 +103,18 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
   __syncthreads();  // the constant tables are in place (the only workgroup barrier before the end of the kernel)
   if (first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
 
+  // this lane's 25 window values and 12 twiddles stay in registers for the whole kernel (the kernel needs 71 of the 128 registers that 4
+  // waves per SIMD leave): 37 LDS reads less per round
+  // (with a third accumulator set -- 128 filters -- only the twiddles: the window would spill 14 registers)
+  constexpr bool kRegWin = NSETS == 2;
+  float wreg[25];
+  v2 twreg[12];
+  if (kRegWin) {
+#pragma unroll
+    for (int j = 0; j < 25; ++j) wreg[j] = cwin[16 * j + (lane & 15)];
+  }
+#pragma unroll
+  for (int k = 1; k <= 12; ++k) twreg[k - 1] = ctw[k * 16 + (lane & 15)];
   const bool fused = p.wg_stat != nullptr;
   float mx = -INFINITY, mn = INFINITY;
 #ifdef HIPFEAT_PHASE_TIMERS
@@ -123,24 +135,24 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
     float s[25];
     {
       const float* x = xs + mul24(g, kW3Shift) + q;
-      const float* wn = cwin + q;
-      float wj[25];
 #pragma unroll
       for (int j = 0; j < 25; ++j) {
         s[j] = x[16 * j];
         HFC_SEP();
       }
+      if (!kRegWin) {
 #pragma unroll
-      for (int j = 0; j < 25; ++j) {
-        wj[j] = wn[16 * j];
-        HFC_SEP();
+        for (int j = 0; j < 25; ++j) {
+          wreg[j] = cwin[16 * j + q];
+          HFC_SEP();
+        }
       }
       // once the samples sit in registers the buffer is free for the next round's span
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       HFC_T(0);  // sample + window reads
       if (r + 1 < p.rounds && f0 + 4 * kW3Waves < cd.num_frames) stage_span(f0 + 4 * kW3Waves, (unsigned)lane_o * 4u);
 #pragma unroll
-      for (int j = 0; j < 25; ++j) s[j] *= wj[j];
+      for (int j = 0; j < 25; ++j) s[j] *= wreg[j];
     }
     // ---- 2. 25-point real DFT, k2 = 0 .. 12 (kernel_whisper2.hpp): coefficients as scalar operands --------------------------------
     v2 Y[13];
@@ -173,14 +185,8 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
     // ---- 3. twiddle W400^(l k2), transpose inside the 16-lane group in two halves (rows k2 = 0..6, then 7..12) ------------------
     v2 xin[16];
     {
-      v2 tw[12];
 #pragma unroll
-      for (int k = 1; k <= 12; ++k) {
-        tw[k - 1] = ctw[k * 16 + q];
-        HFC_SEP();
-      }
-#pragma unroll
-      for (int k = 1; k <= 12; ++k) Y[k] = cmul2(Y[k], tw[k - 1]);
+      for (int k = 1; k <= 12; ++k) Y[k] = cmul2(Y[k], twreg[k - 1]);
       float* exf = myreg + mul24(g, kW3PRowStride);
       const int myrow = min(q, 12);
 #pragma unroll
