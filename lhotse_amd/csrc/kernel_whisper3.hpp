@@ -115,6 +115,10 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
   }
 #pragma unroll
   for (int k = 1; k <= 12; ++k) twreg[k - 1] = ctw[k * 16 + (lane & 15)];
+  // ... and so do the power-row offsets of its filterbank slots (a dependent LDS look-up in front of the operand reads otherwise: + 1 %)
+  int poffreg[NSETS];
+#pragma unroll
+  for (int s2 = 0; s2 < NSETS; ++s2) poffreg[s2] = __builtin_bit_cast(int, ltab[s2 * 256 + 4 * lane]);
   const bool fused = p.wg_stat != nullptr;
   float mx = -INFINITY, mn = INFINITY;
 #ifdef HIPFEAT_PHASE_TIMERS
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
     float* orow = p.out + (cd.out_row + f0) * p.out_stride;
     int lt_poff[NSETS];
 #pragma unroll
-    for (int s2 = 0; s2 < NSETS; ++s2) lt_poff[s2] = __builtin_bit_cast(int, ltab[s2 * 256 + 4 * lane_o]);
+    for (int s2 = 0; s2 < NSETS; ++s2) lt_poff[s2] = poffreg[s2];
     // operands of two sets are in flight at a time (a third set re-uses the registers of the first once its MFMAs are issued)
     f32x4 av[2][kW3Steps / 4], bv[2][kW3Steps / 4];
     auto load_set = [&](int buf, int s2) {
