@@ -170,6 +170,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
     asm volatile("" : "+v"(lane_o));
     const int q = lane_o & 15, g = lane_o >> 4;
 
+    int early_poff[2] = {0, 0};
     v2 Z[16];
     {
       const float* x = xs + mul24(g, shift) + 2 * q;
@@ -275,6 +276,10 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         __builtin_amdgcn_wave_barrier();
       }
       HFC_T(3);  // exchange
+      // the power-row offsets of this lane's filterbank slots are requested here, a phase early: the operand reads of the mel phase then
+      // start without a dependent LDS look-up in front of them (+ 0.6 %)
+      early_poff[0] = __builtin_bit_cast(int, ltab[4 * lane_o]);
+      if (MODE == 0) early_poff[1] = __builtin_bit_cast(int, ltab[256 + 4 * lane_o]);
       fft16(b, Z);
     }
 
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const float* lt = ltab + s * 256 + 4 * lane_o;
-      lt_poff[s] = __builtin_bit_cast(int, lt[0]);
+      lt_poff[s] = early_poff[s];
       lt_col[s] = __builtin_bit_cast(int, lt[1]);
       lt_m4[s] = lt[2];
       lt_m8[s] = lt[3];
