@@ -28,6 +28,7 @@
 #include "kernel_whisper2.hpp"
 #include "kernel_whisper3.hpp"
 #include "kernel_fft256.hpp"
+#include "kernel_fft256c.hpp"
 #include "kernel_wave.hpp"
 
 using namespace hipfeat;
@@ -97,7 +98,7 @@ struct hipfeat_plan {
   int span = 0, off_z = 0, off_p = 0, off_tw = 0, off_stat = 0, off_mel = 0;
   size_t lds_bytes = 0;
   // fft512 fast path
-  int variant = 0;  // 0 generic, 2 fft512 "b" (16-frame tiles), 4 fft256, 5 wave-per-frame, 6 whisper, 7 fft512 "c" (wave-autonomous fbank), 8 fft1024 "c", 9 whisper wave-autonomous + fused normalisation, 10 fft2048 "c"
+  int variant = 0;  // 0 generic, 2 fft512 "b" (16-frame tiles), 4 fft256, 5 wave-per-frame, 6 whisper, 7 fft512 "c" (wave-autonomous fbank), 8 fft1024 "c", 9 whisper wave-autonomous + fused normalisation, 10 fft2048 "c", 11 fft256 "c"
   float* d_mel_a4 = nullptr;
   float* d_dct_consts = nullptr;
   bool fast_mfcc = false;
@@ -673,6 +674,80 @@ static const void* fft256_entry() {
   return reinterpret_cast<const void*>(&fft256_kernel<NROWS, OUT>);
 }
 
+// fft256 wave-autonomous log-mel kernel (kernel_fft256c.hpp); shares d_c_shared / c_* with the other wave-autonomous kernels
+template <int NROWS>
+static const void* fft256c_entry() {
+  return reinterpret_cast<const void*>(&fft256c_kernel<NROWS>);
+}
+
+static hipfeat_status setup_fft256c(hipfeat_plan* p, const float* h_window, const float* h_mel, int nrows) {
+  const hipfeat_config& c = p->cfg;
+  const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
+  Mel4Schedule sch;
+  if (!build_mel4_schedule(h_mel, M, p->K, kDPRowStride, kDSets, kDSteps, sch)) return HIPFEAT_OK;
+  // LDS image: window/2 pairs per (row n1, lane q) | W_128^(q k1) per (row k1, lane q) | split-step twiddles -i W_256^(q + 8 j)
+  std::vector<float> img((size_t)(nrows * 8 + 128 + 64) * 2, 0.0f);
+  for (int n1 = 0; n1 < nrows; ++n1)
+    for (int q = 0; q < 8; ++q)
+      for (int e = 0; e < 2; ++e) {
+        const int i = 16 * n1 + 2 * q + e;
+        img[2 * (n1 * 8 + q) + e] = i < N ? 0.5f * h_window[i] : 0.0f;
+      }
+  float* twp = img.data() + 2 * nrows * 8;
+  float* tws = twp + 256;
+  for (int k1 = 0; k1 < 16; ++k1)
+    for (int q = 0; q < 8; ++q) {
+      const double a = -2.0 * M_PI * (double)(q * k1) / 128.0;
+      twp[2 * (k1 * 8 + q)] = (float)std::cos(a);
+      twp[2 * (k1 * 8 + q) + 1] = (float)std::sin(a);
+    }
+  for (int j = 0; j < 8; ++j)
+    for (int q = 0; q < 8; ++q) {  // w = -i * W_256^k = (sin(a), -cos(a)) with a = -2 pi k / 256
+      const double a = -2.0 * M_PI * (double)(q + 8 * j) / 256.0;
+      tws[2 * (j * 8 + q)] = (float)std::sin(a);
+      tws[2 * (j * 8 + q) + 1] = (float)(-std::cos(a));
+    }
+  // the kernel runs kDSets sets of kDSteps steps unconditionally: pad the tables (weights 0, no output column)
+  p->c_wtab_off = (int)img.size();
+  img.resize(img.size() + (size_t)kDSets * kDSteps * 64, 0.0f);
+  for (int s2 = 0; s2 < sch.nsets; ++s2)
+    std::memcpy(img.data() + p->c_wtab_off + (size_t)s2 * kDSteps * 64, sch.wtab.data() + (size_t)sch.step0[s2] * 64, (size_t)sch.steps[s2] * 64 * sizeof(float));
+  p->c_ltab_off = (int)img.size();
+  img.resize(img.size() + (size_t)kDSets * 256, 0.0f);
+  {
+    const int none = kMel4NoColumn;
+    for (int s2 = 0; s2 < kDSets; ++s2)
+      for (int lane = 0; lane < 64; ++lane) {
+        float* lt = img.data() + p->c_ltab_off + ((size_t)s2 * 64 + lane) * 4;
+        if (s2 < sch.nsets) std::memcpy(lt, sch.ltab.data() + ((size_t)s2 * 64 + lane) * 4, 4 * sizeof(float));
+        else std::memcpy(lt + 1, &none, 4);
+      }
+  }
+  while (img.size() % 64) img.push_back(0.0f);
+  p->c_shared_floats = (int)img.size();
+  p->c_xs_floats = (7 * shift + 16 * nrows + 3) & ~3;
+  const size_t lds = ((size_t)p->c_shared_floats + (size_t)kDWaves * (p->c_xs_floats + kDRegion)) * sizeof(float);
+  if (lds > 80 * 1024 || (p->c_xs_floats >> 8) > 6) return HIPFEAT_OK;  // two workgroups of 8 waves per CU or nothing
+  const void* fn = nrows == 13 ? fft256c_entry<13>() : fft256c_entry<16>();
+  hipError_t e = ensure_dynamic_lds(fn, lds);
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft256c) failed: %s", hipGetErrorName(e));
+  hipfeat_status st;
+  if ((st = upload(&p->d_c_shared, img.data(), img.size())) != HIPFEAT_OK) return st;
+  p->nrows = nrows;
+  p->c_rounds = 4;  // 8 waves x 4 rounds x 8 frames = 256 frames per workgroup
+  p->fpb = kDWaves * p->c_rounds * 8;
+  p->fast_lds_bytes = lds;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kDWaves, lds) == hipSuccess) p->blocks_per_cu = nb;
+  int total_steps = 0;
+  for (int s2 = 0; s2 < sch.nsets; ++s2) total_steps += sch.steps[s2];
+  char nm[128];
+  snprintf(nm, sizeof(nm), "fft256c_kernel<%d> fbank lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, lds, p->blocks_per_cu, sch.nsets, total_steps);
+  p->kernel_name = nm;
+  p->variant = 11;
+  return HIPFEAT_OK;
+}
+
 static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const float* h_mel, const float* h_dct, const float* h_lifter) {
   const hipfeat_config& c = p->cfg;
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
@@ -686,6 +761,13 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
   const int nrows = need <= 13 ? 13 : 16;
   const int ntiles = spec ? 0 : (M + 15) / 16;
   if (ntiles > 8) return HIPFEAT_OK;
+  if (!mfcc && !spec) {  // log-mel filterbank: the wave-autonomous kernel, unless the schedule or the LDS budget says no
+    const char* var = getenv("HIPFEAT_FFT256_VARIANT");
+    if (!(var && var[0] == 'b') && !getenv("HIPFEAT_NO_WAVE_AUTONOMOUS")) {  // HIPFEAT_FFT256_VARIANT=b: the 32-frame-tile kernel (tests compare the two)
+      hipfeat_status stc = setup_fft256c(p, h_window, h_mel, nrows);
+      if (stc != HIPFEAT_OK || p->variant == 11) return stc;
+    }
+  }
   WaveWork work[4];
   std::vector<float> mel_a((size_t)4 * kMelARegs * 64, 0.0f);
   std::memset(work, 0, sizeof(work));
@@ -1464,6 +1546,36 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(whisper_norm_kernel, dim3((unsigned)lay->batch), dim3(1024), 0, stream, lay->d_cuts, d_out, lay->out_row_stride,
                        (int32_t)c.num_filters, (int32_t)c.frame_shift);
+    HIP_TRY(hipGetLastError());
+    return HIPFEAT_OK;
+  }
+  if (plan->variant == 11) {
+    Fft512cParams fp{};
+    fp.wave = d_wave;
+    fp.out = d_out;
+    fp.cuts = lay->d_cuts;
+    fp.shared_consts = plan->d_c_shared;
+    fp.out_stride = lay->out_row_stride;
+    fp.num_cuts = (int32_t)lay->batch;
+    fp.uniform_bpc = lay->uniform_bpc;
+    fp.frames_per_block = plan->fpb;
+    fp.rounds = plan->c_rounds;
+    fp.N = c.frame_length;
+    fp.shift = c.frame_shift;
+    fp.npad_left = plan->npad_left;
+    fp.M = c.num_filters;
+    fp.flags = c.remove_dc_offset ? F_REMOVE_DC : 0;
+    fp.preemph = c.preemph_coeff;
+    fp.mel_floor = c.mel_floor;
+    fp.shared_floats = plan->c_shared_floats;
+    fp.wtab_off = plan->c_wtab_off;
+    fp.ltab_off = plan->c_ltab_off;
+    fp.xs_floats = plan->c_xs_floats;
+    DeviceGuard g(plan->device);
+    const dim3 grid((unsigned)lay->total_blocks), block(64 * kDWaves);
+    set_lds_poison(plan->fast_lds_bytes);
+    if (plan->nrows == 13) hipLaunchKernelGGL(fft256c_kernel<13>, grid, block, plan->fast_lds_bytes, stream, fp);
+    else hipLaunchKernelGGL(fft256c_kernel<16>, grid, block, plan->fast_lds_bytes, stream, fp);
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }

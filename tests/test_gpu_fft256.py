@@ -39,7 +39,7 @@ def test_fft256_fast_path_matches_oracle_and_generic(kind, cfg, monkeypatch):
     # low level + DC offset; without DC removal a large offset only measures float32 leakage noise (reference floor 3e-4)
     xs[1] = (xs[1] * 0.01 + (0.2 if cfg.get("remove_dc_offset", True) else 0.0)).astype(np.float32)
     fast = _make(kind, cfg)
-    assert "fft256_kernel" in fast.kernel_name, fast.kernel_name
+    assert "fft256_kernel" in fast.kernel_name or "fft256c_kernel" in fast.kernel_name, fast.kernel_name
     monkeypatch.setenv("HIPFEAT_FORCE_GENERIC", "1")
     slow = _make(kind, cfg)
     assert "generic" in slow.kernel_name  # (the plan is created lazily, on first use)
@@ -77,3 +77,29 @@ def test_fft256_tripwire_tone_and_collated():
     assert np.abs(y - truth).max() <= max(2e-3, 3 * np.abs(want - truth).max())
     col, lens = ex.extract_collated([x, x[:4000]], 8000)
     assert col.shape == (2, 100, 40) and lens.tolist() == [100, 50] and torch.equal(col[0], torch.from_numpy(y).cuda())
+
+
+@pytest.mark.parametrize("cfg,kernel", [(dict(sampling_rate=8000), "fft256c_kernel<13>"), (dict(sampling_rate=8000, num_filters=40), "fft256c_kernel<13>"),
+                                        (dict(sampling_rate=8000, num_filters=23), "fft256_kernel<13,0>"),  # one set of 12 steps: outside the 2 x 8 schedule
+                                        (dict(sampling_rate=16000, frame_length=0.016, frame_shift=0.008, num_filters=64), "fft256_kernel<16,0>"),  # 8 spans of 7 x 128 + 256 samples: over the LDS budget of two workgroups per CU
+                                        (dict(sampling_rate=8000, frame_length=0.032, frame_shift=0.01, num_filters=64), "fft256c_kernel<16>")])
+def test_wave_autonomous_and_tile_kernels_agree(cfg, kernel, monkeypatch):
+    """fft256c (wave-autonomous, 4 x 4 x 1 matrix-core filterbank) against fft256 (32-frame tiles) on ragged batches, and the choice of kernel."""
+    sr = cfg["sampling_rate"]
+    rng = np.random.RandomState(3)
+    xs = [(rng.rand(n).astype(np.float32) - 0.5) * a for n, a in [(sr, 1.0), (10 * sr, 0.5), (2561, 1.0), (2560, 0.1), (30 * sr + 7, 0.9), (sr // 4, 1e-3)]]
+    new = _make("fbank", cfg)
+    assert new.kernel_name.startswith(kernel), new.kernel_name
+    monkeypatch.setenv("HIPFEAT_FFT256_VARIANT", "b")
+    old = _make("fbank", cfg)
+    assert old.kernel_name.startswith("fft256_kernel")
+    monkeypatch.delenv("HIPFEAT_FFT256_VARIANT")
+    fields = {k: v for k, v in cfg.items() if k in K.RefConfig.__dataclass_fields__}
+    ref32 = K.RefExtractor(K.RefConfig(kind="fbank", **fields), np.float32)
+    for x, a, b in zip(xs, new.extract_batch([torch.from_numpy(x) for x in xs], sr), old.extract_batch(xs, sr)):
+        a = a.cpu().numpy()
+        want = ref32.extract(x)
+        assert a.shape == b.shape == want.shape
+        assert np.abs(a - b).max() <= 2e-3, (len(x), np.abs(a - b).max())
+        assert np.linalg.norm(a - want) / np.linalg.norm(want) <= 1e-4, len(x)
+        assert np.array_equal(new.extract(x, sr), a)  # batch == per cut, bit for bit
