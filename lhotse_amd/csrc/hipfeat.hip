@@ -115,6 +115,10 @@ struct hipfeat_plan {
   // fft512 wave-autonomous fbank kernel (variant 7)
   float* d_c_shared = nullptr;  // LDS image: FFT constants | 4x4-block filterbank weights | lane tables
   int c_shared_floats = 0, c_wtab_off = 0, c_ltab_off = 0, c_xs_floats = 0, c_rounds = 0, c_mode = 0;
+  // wave-autonomous kernels: frames per workgroup = fpb_unit (frames of one round of all waves) x rounds, rounds chosen per LAYOUT between 2
+  // and c_rounds_max: long launches take many rounds per workgroup (the constant tables and the first, un-overlapped span are paid once per
+  // workgroup: 16 instead of 8 rounds is + 4 % on the bench workload), short ones few (enough workgroups to fill the chip)
+  int fpb_unit = 0, c_rounds_max = 0;
   // fft1024 wave-autonomous fbank kernel (variant 8; shares d_c_shared / c_* with variant 7)
   int w_nsets = 0, w_steps[kWMaxSets] = {}, w_step0[kWMaxSets] = {};
   // fft2048 wave-autonomous fbank kernel (variant 10; shares d_c_shared / c_* / w_* with variants 7 and 8)
@@ -152,7 +156,7 @@ struct hipfeat_layout {
   int64_t total_blocks = 0;
   int64_t out_row_stride = 0;
   int uniform_bpc = 0;
-  int fpb = 0;
+  int fpb = 0, fpb_unit = 0;
   CutDesc* d_cuts = nullptr;
   bool owns = true;
   std::vector<int64_t> num_frames;
@@ -460,6 +464,8 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
   p->nrows = nrows;
   p->c_rounds = 8;  // 8 waves x 8 rounds x 4 frames = 256 frames per workgroup
   p->fpb = kCWaves * p->c_rounds * 4;
+  p->fpb_unit = kCWaves * 4;
+  p->c_rounds_max = 16;
   p->fast_lds_bytes = lds;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kCWaves, lds) == hipSuccess) p->blocks_per_cu = nb;
@@ -656,6 +662,8 @@ static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, con
   p->nrows = nrows;
   p->c_rounds = 8;
   p->fpb = kWWaves * p->c_rounds * 4;
+  p->fpb_unit = kWWaves * 4;
+  p->c_rounds_max = 32;
   p->fast_lds_bytes = lds;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kWWaves, lds) == hipSuccess) p->blocks_per_cu = nb;
@@ -736,6 +744,8 @@ static hipfeat_status setup_fft256c(hipfeat_plan* p, const float* h_window, cons
   p->nrows = nrows;
   p->c_rounds = 4;  // 8 waves x 4 rounds x 8 frames = 256 frames per workgroup
   p->fpb = kDWaves * p->c_rounds * 8;
+  p->fpb_unit = kDWaves * 8;
+  p->c_rounds_max = 16;
   p->fast_lds_bytes = lds;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kDWaves, lds) == hipSuccess) p->blocks_per_cu = nb;
@@ -1097,6 +1107,8 @@ static hipfeat_status setup_fft2048c(hipfeat_plan* p, const float* h_window, con
   p->x_waves = waves;
   p->c_rounds = 8;
   p->fpb = waves * p->c_rounds * 2;
+  p->fpb_unit = waves * 2;
+  p->c_rounds_max = 64;
   p->fast_lds_bytes = lds;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * waves, lds) == hipSuccess) p->blocks_per_cu = nb;
@@ -1158,6 +1170,8 @@ static hipfeat_status setup_whisper3(hipfeat_plan* p, const float* h_window, con
   p->w_nsets = nsets;
   p->c_rounds = 8;  // 8 waves x 8 rounds x 4 frames = 256 frames per workgroup
   p->fpb = kW3Waves * p->c_rounds * 4;
+  p->fpb_unit = kW3Waves * 4;
+  p->c_rounds_max = 16;
   p->fast_lds_bytes = lds;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kW3Waves, lds) == hipSuccess) p->blocks_per_cu = nb;
@@ -1362,12 +1376,27 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
     d.num_samples = (int32_t)S;
     d.padded_len = (int32_t)P;
     d.num_frames = (int32_t)T;
-    if (blocks > INT32_MAX - (1 << 24)) return fail(HIPFEAT_ERR_INVALID, "batch too large for one launch");
-    d.first_block = (int32_t)blocks;
-    const int64_t nb = (T + plan->fpb - 1) / plan->fpb;
-    blocks += nb;
     row += T;
     lay->num_frames[(size_t)b] = T;
+  }
+  // frames per workgroup: fixed by the plan, or (wave-autonomous kernels) the largest number of rounds that still yields enough
+  // workgroups to fill the chip four times over
+  int fpb = plan->fpb;
+  if (plan->fpb_unit > 0) {
+    const int64_t want = 4LL * 256 * std::max(plan->blocks_per_cu, 1);
+    int rounds = plan->c_rounds_max;
+    for (; rounds > 2; rounds >>= 1) {
+      int64_t nb = 0;
+      for (int64_t b = 0; b < batch; ++b) nb += (lay->num_frames[(size_t)b] + (int64_t)plan->fpb_unit * rounds - 1) / ((int64_t)plan->fpb_unit * rounds);
+      if (nb >= want) break;
+    }
+    fpb = plan->fpb_unit * rounds;
+  }
+  for (int64_t b = 0; b < batch; ++b) {
+    if (blocks > INT32_MAX - (1 << 24)) return fail(HIPFEAT_ERR_INVALID, "batch too large for one launch");
+    descs[(size_t)b].first_block = (int32_t)blocks;
+    const int64_t nb = (lay->num_frames[(size_t)b] + fpb - 1) / fpb;
+    blocks += nb;
     if (uniform == -1) uniform = (int)nb;
     else if (uniform != (int)nb) uniform = 0;
   }
@@ -1376,7 +1405,8 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
   lay->total_blocks = blocks;
   lay->out_row_stride = out_row_stride;
   lay->uniform_bpc = uniform > 0 ? uniform : 0;
-  lay->fpb = plan->fpb;
+  lay->fpb = fpb;
+  lay->fpb_unit = plan->fpb_unit;
   lay->device = plan->device;
   return HIPFEAT_OK;
 }
@@ -1445,7 +1475,7 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
                              hipStream_t stream) {
   if (lay->total_blocks == 0) return HIPFEAT_OK;
   if (!d_wave || !d_out) return fail(HIPFEAT_ERR_INVALID, "wave/out pointer is NULL");
-  if (lay->fpb != plan->fpb || lay->device != plan->device)
+  if ((plan->fpb_unit > 0 ? (lay->fpb_unit != plan->fpb_unit || lay->fpb % plan->fpb_unit != 0) : lay->fpb != plan->fpb) || lay->device != plan->device)
     return fail(HIPFEAT_ERR_INVALID, "layout was created for a different plan");
   const hipfeat_config& c = plan->cfg;
   if (plan->variant == 5) {
@@ -1501,8 +1531,8 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     wp.num_cuts = (int32_t)lay->batch;
     wp.uniform_bpc = lay->uniform_bpc;
     wp.total_blocks = (int32_t)lay->total_blocks;
-    wp.frames_per_block = plan->fpb;
-    wp.rounds = plan->c_rounds;
+    wp.frames_per_block = lay->fpb;
+    wp.rounds = lay->fpb / plan->fpb_unit;
     wp.M = c.num_filters;
     wp.mel_floor = c.mel_floor;
     wp.shared_floats = plan->c_shared_floats;
@@ -1558,8 +1588,8 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.out_stride = lay->out_row_stride;
     fp.num_cuts = (int32_t)lay->batch;
     fp.uniform_bpc = lay->uniform_bpc;
-    fp.frames_per_block = plan->fpb;
-    fp.rounds = plan->c_rounds;
+    fp.frames_per_block = lay->fpb;
+    fp.rounds = lay->fpb / plan->fpb_unit;
     fp.N = c.frame_length;
     fp.shift = c.frame_shift;
     fp.npad_left = plan->npad_left;
@@ -1589,8 +1619,8 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.out_stride = lay->out_row_stride;
     fp.num_cuts = (int32_t)lay->batch;
     fp.uniform_bpc = lay->uniform_bpc;
-    fp.frames_per_block = plan->fpb;
-    fp.rounds = plan->c_rounds;
+    fp.frames_per_block = lay->fpb;
+    fp.rounds = lay->fpb / plan->fpb_unit;
     fp.waves = plan->x_waves;
     fp.N = c.frame_length;
     fp.shift = c.frame_shift;
@@ -1629,8 +1659,8 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.out_stride = lay->out_row_stride;
     fp.num_cuts = (int32_t)lay->batch;
     fp.uniform_bpc = lay->uniform_bpc;
-    fp.frames_per_block = plan->fpb;
-    fp.rounds = plan->c_rounds;
+    fp.frames_per_block = lay->fpb;
+    fp.rounds = lay->fpb / plan->fpb_unit;
     fp.N = c.frame_length;
     fp.shift = c.frame_shift;
     fp.npad_left = plan->npad_left;
@@ -1662,8 +1692,8 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.out_stride = lay->out_row_stride;
     fp.num_cuts = (int32_t)lay->batch;
     fp.uniform_bpc = lay->uniform_bpc;
-    fp.frames_per_block = plan->fpb;
-    fp.rounds = plan->c_rounds;
+    fp.frames_per_block = lay->fpb;
+    fp.rounds = lay->fpb / plan->fpb_unit;
     fp.N = c.frame_length;
     fp.shift = c.frame_shift;
     fp.npad_left = plan->npad_left;
