@@ -480,3 +480,24 @@ def test_plans_sharing_a_kernel_with_different_lds_footprints():
     for got, cfg in ((a1, dict(num_filters=40, num_ceps=40)), (b, dict(num_filters=23, num_ceps=13))):
         want = RefExtractor(RefConfig(kind="mfcc", **cfg), np.float64).extract(x)
         assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-4
+
+
+@pytest.mark.parametrize("sr", [8000, 16000, 24000, 48000])
+def test_rounds_per_workgroup_do_not_change_the_bits(sr):
+    """The wave-autonomous kernels take many rounds per workgroup in long launches and few in short ones (a property of the layout):
+    a cut gives the same bits alone, in a small batch and in a launch of thousands of cuts."""
+    from _hip import make_hip
+
+    ex = make_hip("fbank", {"sampling_rate": sr})
+    assert "c_kernel" in ex.kernel_name, ex.kernel_name
+    g = torch.Generator(device="cuda").manual_seed(sr)
+    n = 3 * sr + 123
+    big = torch.rand(2500, n, device="cuda", generator=g) - 0.5
+    all_ = ex.extract_batch(big, sr)
+    few = ex.extract_batch(big[:7], sr)
+    one = ex.extract_batch(big[1234:1235], sr)
+    assert torch.equal(all_[:7], few) and torch.equal(all_[1234:1235].reshape(one.shape), one)
+    long_cut = torch.rand(1, 600 * sr // 10, device="cuda", generator=g) - 0.5  # one minute: one cut, many workgroups
+    a = ex.extract_batch(long_cut, sr)
+    b = ex.extract_batch(torch.cat([long_cut, long_cut]), sr)
+    assert torch.equal(a.reshape(b[0].shape), b[0]) and torch.equal(b[0], b[1])
