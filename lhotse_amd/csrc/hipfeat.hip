@@ -385,7 +385,8 @@ static const void* fft512c_pick(int nrows, int N, bool launch, dim3 grid, dim3 b
 }
 static const void* fft512c_dispatch(int mode, int nrows, int N, bool launch, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const Fft512cParams* fp) {
   return mode == 0 ? fft512c_pick<0>(nrows, N, launch, grid, block, lds, stream, fp)
-                   : (mode == 1 ? fft512c_pick<1>(nrows, N, launch, grid, block, lds, stream, fp) : fft512c_pick<2>(nrows, N, launch, grid, block, lds, stream, fp));
+                   : (mode == 1 ? fft512c_pick<1>(nrows, N, launch, grid, block, lds, stream, fp)
+                                : (mode == 2 ? fft512c_pick<2>(nrows, N, launch, grid, block, lds, stream, fp) : fft512c_pick<3>(nrows, N, launch, grid, block, lds, stream, fp)));
 }
 
 // Returns HIPFEAT_OK with p->variant == 7 when the configuration takes the wave-autonomous kernel, HIPFEAT_OK with the
@@ -397,7 +398,7 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
   if (mfcc && (M > 4 * kCDctChunks || c.num_ceps > 64 || !h_dct)) return HIPFEAT_OK;
   // mode 0: 2 accumulator sets x 16 steps (many narrow filters); modes 1 / 2 (MFCC): 1 set x 32 steps (few, wide filters)
   Mel4Schedule sch;
-  int mode = mfcc ? 2 : 0;
+  int mode = mfcc ? (M <= 4 * kCDctChunksSmall ? 3 : 2) : 0;  // MFCC: 3 = at most 24 filters (6 chunks of DCT operands + split-step twiddles in registers)
   if (mfcc || !build_mel4_schedule(h_mel, M, p->K, kCPRowStride, kCMaxSets, kCMaxSteps, sch)) {
     if (!build_mel4_schedule(h_mel, M, p->K, kCPRowStride, 1, 2 * kCMaxSteps, sch)) return HIPFEAT_OK;
     if (!mfcc) mode = 1;
@@ -454,10 +455,11 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
   if ((st = upload(&p->d_c_shared, img.data(), img.size())) != HIPFEAT_OK) return st;
   if (mfcc) {  // DCT operands in matrix-core lane order: [chunk of 4 filters][lane = cepstral coefficient][filter in the chunk], then the lifter
     const int C = c.num_ceps;
-    std::vector<float> dt((size_t)kCDctChunks * 256 + 64, 0.0f);
+    const int dch = mode == 3 ? kCDctChunksSmall : kCDctChunks;
+    std::vector<float> dt((size_t)dch * 256 + 64, 0.0f);
     for (int m = 0; m < M; ++m)
       for (int cc = 0; cc < C; ++cc) dt[((size_t)(m / 4) * 64 + cc) * 4 + (m & 3)] = h_dct[(size_t)m * C + cc];
-    for (int cc = 0; cc < 64; ++cc) dt[(size_t)kCDctChunks * 256 + cc] = (c.apply_lifter && h_lifter && cc < C) ? h_lifter[cc] : 1.0f;
+    for (int cc = 0; cc < 64; ++cc) dt[(size_t)dch * 256 + cc] = (c.apply_lifter && h_lifter && cc < C) ? h_lifter[cc] : 1.0f;
     if ((st = upload(&p->d_dct_consts, dt.data(), dt.size())) != HIPFEAT_OK) return st;
   }
   p->c_mode = mode;

@@ -36,6 +36,7 @@ constexpr int kCMaxSteps = 16;                             // MFMA steps per set
 constexpr int kCWaves = 8;                                 // waves per workgroup
 constexpr int kCLmStride = 48;                             // MFCC: floats per log-mel row in LDS (<= 40 filters; rows 3 bank quads apart)
 constexpr int kCDctChunks = 10;                            // MFCC: DCT steps / 4 (<= 40 filters), operands resident in registers
+constexpr int kCDctChunksSmall = 6;                        // MFCC with <= 24 filters (mode 3): leaves room for the split-step twiddles
 
 struct Fft512cParams {
   const float* wave;
@@ -69,7 +70,8 @@ __device__ __forceinline__ int mul24(int a, int b) { return (int)__umul24((unsig
 
 // NROWS: pass-1 rows that can hold samples; NFULL: rows known to lie entirely inside the frame (N >= 32 NFULL): no length masks there;
 // MODE 0: log-mel filterbank on 2 accumulator sets x 16 steps (many narrow filters: the 80-filter default); 1: log-mel on 1 set x 32
-// steps (few, wide filters: 23 / 40); 2: MFCC = mode 1 + the DCT as a second run of 4 x 4 x 1 blocks (Wav2MFCC, layers.py:708-724)
+// steps (few, wide filters: 23 / 40); 2: MFCC = mode 1 + the DCT as a second run of 4 x 4 x 1 blocks (Wav2MFCC, layers.py:708-724);
+// 3: MFCC with <= 24 filters (the 23-filter default): 6 instead of 10 chunks of DCT operands, and the split-step twiddles in registers
 template <int NROWS, int NFULL, int MODE>
 __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -135,21 +137,26 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
   // Both twiddle tables of this lane (15 + 8 complex values) live in registers for the whole kernel where the register budget of 4 waves
   // per SIMD allows it (not in MFCC mode, whose DCT operands take that room): 24 LDS reads less per round, + 4.9 % (same-call A/B).  The
   // window on top of that does not fit (10 spilled registers, - 2.5 %).
-  constexpr bool kRegTw = MODE != 2 && NROWS <= 13;  // (16 live input rows leave no room either: 24 spilled registers)
-  v2 twpreg[kRegTw ? 16 : 1], twsreg[kRegTw ? 8 : 1];
+  constexpr bool kMfcc = MODE == 2 || MODE == 3;
+  constexpr int DCH = MODE == 3 ? kCDctChunksSmall : kCDctChunks;
+  constexpr bool kRegTw = !kMfcc && NROWS <= 13;  // (16 live input rows leave no room either: 24 spilled registers)
+  constexpr bool kRegTws = kRegTw || (MODE == 3 && NROWS <= 13);  // the split-step twiddles alone
+  v2 twpreg[kRegTw ? 16 : 1], twsreg[kRegTws ? 8 : 1];
   if (kRegTw) {
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) twpreg[k1] = ctwp[k1 * 16 + (lane & 15)];
+  }
+  if (kRegTws) {
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) twsreg[k2] = ctws[k2 * 16 + (lane & 15)];
   }
   // MFCC: the DCT operands of this lane (its cepstral coefficient x every filter) and its lifter value stay in registers
-  f32x4 dw[MODE == 2 ? kCDctChunks : 1];
+  f32x4 dw[kMfcc ? DCH : 1];
   float lift = 1.0f;
-  if (MODE == 2) {
+  if (kMfcc) {
 #pragma unroll
-    for (int c4 = 0; c4 < kCDctChunks; ++c4) dw[c4] = *reinterpret_cast<const f32x4*>(p.dct_tab + (c4 * 64 + lane) * 4);
-    lift = p.dct_tab[kCDctChunks * 256 + lane];
+    for (int c4 = 0; c4 < DCH; ++c4) dw[c4] = *reinterpret_cast<const f32x4*>(p.dct_tab + (c4 * 64 + lane) * 4);
+    lift = p.dct_tab[DCH * 256 + lane];
   }
 #ifdef HIPFEAT_PHASE_TIMERS
   unsigned long long hfc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hfc_last = __builtin_readcyclecounter();
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         v2 tw[4];  // split-step twiddles of 4 bin pairs per burst
-        if (kRegTw) {
+        if (kRegTws) {
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) tw[rr] = twsreg[4 * h + rr];
         } else {
@@ -395,11 +402,11 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4 -- the odd slot of a pair takes its left neighbour's partial sum
         v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8 -- the last slot of a group of 3 or 4 takes the first slot(s)'
         v = fast_log(fmaxf(v, p.mel_floor));
-        if (MODE == 2) lm[i] = v;
+        if (kMfcc) lm[i] = v;
         else if (col < p.M && i < nf) orow[i * p.out_stride + col] = v;
       }
     }
-    if (MODE == 2) {
+    if (kMfcc) {
       // ---- DCT on the matrix cores: block = (4 frames) x (4 cepstral coefficients) x (1 filter); all 16 blocks walk the filters together.
       // The power rows are dead (every operand of the filterbank sits in registers): the four log-mel rows overwrite their start.
       float* lmrow = myreg;
@@ -411,12 +418,12 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      f32x4 al[kCDctChunks];  // A operand: lane (block b, frame i) = log-mel of frame i, four filters per read (the same for every block)
+      f32x4 al[DCH];  // A operand: lane (block b, frame i) = log-mel of frame i, four filters per read (the same for every block)
 #pragma unroll
-      for (int c4 = 0; c4 < kCDctChunks; ++c4) al[c4] = *reinterpret_cast<const f32x4*>(lmrow + (lane_o & 3) * kCLmStride + 4 * c4);
+      for (int c4 = 0; c4 < DCH; ++c4) al[c4] = *reinterpret_cast<const f32x4*>(lmrow + (lane_o & 3) * kCLmStride + 4 * c4);
       f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c4 = 0; c4 < kCDctChunks; ++c4) {
+      for (int c4 = 0; c4 < DCH; ++c4) {
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
           d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(al[c4][i], dw[c4][i], d0, 0, 0, 0);
