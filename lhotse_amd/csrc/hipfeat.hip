@@ -685,9 +685,9 @@ static const void* fft256_entry() {
 }
 
 // fft256 wave-autonomous log-mel kernel (kernel_fft256c.hpp); shares d_c_shared / c_* with the other wave-autonomous kernels
-template <int NROWS>
+template <int NROWS, int NFULL>
 static const void* fft256c_entry() {
-  return reinterpret_cast<const void*>(&fft256c_kernel<NROWS>);
+  return reinterpret_cast<const void*>(&fft256c_kernel<NROWS, NFULL>);
 }
 
 static hipfeat_status setup_fft256c(hipfeat_plan* p, const float* h_window, const float* h_mel, int nrows) {
@@ -738,7 +738,8 @@ static hipfeat_status setup_fft256c(hipfeat_plan* p, const float* h_window, cons
   p->c_xs_floats = (7 * shift + 16 * nrows + 3) & ~3;
   const size_t lds = ((size_t)p->c_shared_floats + (size_t)kDWaves * (p->c_xs_floats + kDRegion)) * sizeof(float);
   if (lds > 80 * 1024 || (p->c_xs_floats >> 8) > 6) return HIPFEAT_OK;  // two workgroups of 8 waves per CU or nothing
-  const void* fn = nrows == 13 ? fft256c_entry<13>() : fft256c_entry<16>();
+  // 25 ms at 8 kHz (N = 200: 12 full rows of 16 samples + a partial one) gets the instance without length masks on the full rows
+  const void* fn = nrows == 13 ? (N >= 192 ? fft256c_entry<13, 12>() : fft256c_entry<13, 0>()) : fft256c_entry<16, 0>();
   hipError_t e = ensure_dynamic_lds(fn, lds);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft256c) failed: %s", hipGetErrorName(e));
   hipfeat_status st;
@@ -1606,8 +1607,9 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(64 * kDWaves);
     set_lds_poison(plan->fast_lds_bytes);
-    if (plan->nrows == 13) hipLaunchKernelGGL(fft256c_kernel<13>, grid, block, plan->fast_lds_bytes, stream, fp);
-    else hipLaunchKernelGGL(fft256c_kernel<16>, grid, block, plan->fast_lds_bytes, stream, fp);
+    if (plan->nrows == 13 && c.frame_length >= 192) hipLaunchKernelGGL((fft256c_kernel<13, 12>), grid, block, plan->fast_lds_bytes, stream, fp);
+    else if (plan->nrows == 13) hipLaunchKernelGGL((fft256c_kernel<13, 0>), grid, block, plan->fast_lds_bytes, stream, fp);
+    else hipLaunchKernelGGL((fft256c_kernel<16, 0>), grid, block, plan->fast_lds_bytes, stream, fp);
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }

@@ -23,8 +23,8 @@ constexpr int kDRegion = 8 * kDPRowStride;        // 1152 dwords per wave = 8 ex
 constexpr int kDSets = 2, kDSteps = 8;            // accumulator sets x MFMA steps per set
 constexpr int kDWaves = 8;                        // waves per workgroup
 
-// NROWS: pass-1 rows (of 16 samples) that can hold samples
-template <int NROWS>
+// NROWS: pass-1 rows (of 16 samples) that can hold samples; NFULL: rows known to lie entirely inside the frame (N >= 16 NFULL): no length masks there
+template <int NROWS, int NFULL>
 __global__ __launch_bounds__(64 * kDWaves, 4) void fft256c_kernel(const Fft512cParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   HF_POISON_LDS(smem);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64 * kDWaves, 4) void fft256c_kernel(const Fft512cP
         if (r + 1 < p.rounds && f0 + 8 * kDWaves < cd.num_frames) stage_span(f0 + 8 * kDWaves, (unsigned)lane_o * 4u);
 
 #pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) {
+        for (int n1 = NFULL; n1 < NROWS; ++n1) {
           if (16 * (n1 + 1) > N) {  // samples at or beyond N are not part of the frame
             const int m0 = 16 * n1 + 2 * q;
             if (m0 >= N) z[n1].x = 0.f;
