@@ -38,7 +38,10 @@ from .layers import HipWav2LogFilterBank, HipWav2LogSpec, HipWav2MFCC, HipWav2Sp
 
 from .storage import HipArchiveReader, HipArchiveWriter, compute_and_store_features_batch  # noqa: F401,E402
 
+from .sharding import compute_and_store_features_sharded  # noqa: F401,E402
+
 __all__ = [
+    "compute_and_store_features_sharded",
     "compute_and_store_features_batch",
     "HipArchiveWriter",
     "HipArchiveReader",

@@ -328,9 +328,15 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
           const v2 sp = m * HF_CJ + Z[k2];
           const v2 dm = m * HF_NCJ + Z[k2];
           const v2 tt = cmul2(dm, tw[rr]);
-          const v2 xp = sp + tt, xm = sp - tt;
-          pown[16 * k2] = xp.x * xp.x + xp.y * xp.y;
-          ppar[16 * (15 - k2)] = xm.x * xm.x + xm.y * xm.y;
+          // the bin pair (k, 256 - k) side by side: re2 = (Re X[k], Re X[256-k]) = sp.x +- tt.x, im2 likewise; |X|^2 of both bins in two
+          // packed instructions (the broadcasts are op_sel modifiers) instead of two multiplies and two multiply-adds
+          v2 re2, im2, pw;
+          asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(re2) : "v"(tt), "v"(HF_CJ), "v"(sp));
+          asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(im2) : "v"(tt), "v"(HF_CJ), "v"(sp));
+          pw = re2 * re2;
+          pw = im2 * im2 + pw;
+          pown[16 * k2] = pw.x;
+          ppar[16 * (15 - k2)] = pw.y;
         }
       }
       if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
@@ -373,37 +379,66 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
     }
     HFC_T(5);  // operand reads of the mel phase issued (not yet waited for)
     float lm[4];  // MODE 2: the lane's log-mel values of the four frames
+    {
+      // Two independent accumulation chains, issued alternately: a 4 x 4 x 1 block issues in 8 clk but its result is ready for the
+      // next link of the SAME chain only after 16 -- set after set (what the per-set loop compiled to) ran at half the matrix-core rate.
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (MODE == 0) {
+      for (int c4 = 0; c4 < (S * T) / 8; ++c4) {
 #pragma unroll
-        for (int c4 = 0; c4 < T / 4; ++c4) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s][c4][i], bv[s][c4][i], acc, 0, 0, 0);
-        }
-      } else {  // one set of 32 steps: two accumulation chains
-        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c4 = 0; c4 < T / 4; ++c4) {
-#pragma unroll
-          for (int i = 0; i < 4; i += 2) {
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s][c4][i], bv[s][c4][i], acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s][c4][i + 1], bv[s][c4][i + 1], acc1, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+          if (MODE == 0) {
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0][c4][i], bv[0][c4][i], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[S - 1][c4][i], bv[S - 1][c4][i], acc[1], 0, 0, 0);
+          } else {  // one set of 32 steps: even chunks on chain 0, odd chunks on chain 1
+            acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0][2 * c4][i], bv[0][2 * c4][i], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0][2 * c4 + 1][i], bv[0][2 * c4 + 1][i], acc[1], 0, 0, 0);
           }
         }
-        acc += acc1;
       }
-      const int col = lt_col[s];
-      const float m4 = lt_m4[s], m8 = lt_m8[s];
+      if (MODE != 0) acc[0] += acc[1];
+      // Reduction of the pieces of a split filter group, floor, log: every value of the round first, then the stores of a set under ONE
+      // lane mask (the per-value `if` of the first version cost eight exec-mask round trips per round).  The row_shr adds are
+      // v_fmac_f32 with a DPP source operand; s_nop 7 covers the matrix-core -> VALU read hazard hipcc cannot see through inline asm.
+      float val[S][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = acc[i];
-        v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4 -- the odd slot of a pair takes its left neighbour's partial sum
-        v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8 -- the last slot of a group of 3 or 4 takes the first slot(s)'
-        v = fast_log(fmaxf(v, p.mel_floor));
-        if (kMfcc) lm[i] = v;
-        else if (col < p.M && i < nf) orow[i * p.out_stride + col] = v;
+      for (int s = 0; s < S; ++s) {
+        float v0 = acc[s][0], v1 = acc[s][1], v2_ = acc[s][2], v3 = acc[s][3];
+        asm volatile(
+            "s_nop 7\n\t"
+            "v_fmac_f32_dpp %0, %0, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %1, %1, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %2, %2, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %3, %3, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %0, %0, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %1, %1, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %2, %2, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_fmac_f32_dpp %3, %3, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_max_f32 %0, %0, %6\n\tv_max_f32 %1, %1, %6\n\tv_max_f32 %2, %2, %6\n\tv_max_f32 %3, %3, %6"  // (no canonicalising v_max(x, x) in front)
+            : "+v"(v0), "+v"(v1), "+v"(v2_), "+v"(v3)
+            : "v"(lt_m4[s]), "v"(lt_m8[s]), "v"(p.mel_floor));
+        val[s][0] = fast_log(v0);
+        val[s][1] = fast_log(v1);
+        val[s][2] = fast_log(v2_);
+        val[s][3] = fast_log(v3);
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int col = lt_col[s];
+        if (kMfcc) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lm[i] = val[s][i];
+        } else if (col < p.M) {
+          float* o = orow + col;
+          if (nf == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i * p.out_stride] = val[s][i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              if (i < nf) o[i * p.out_stride] = val[s][i];
+          }
+        }
       }
     }
     if (kMfcc) {

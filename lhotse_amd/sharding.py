@@ -78,3 +78,171 @@ def all_reduce_stats(num_cuts: int, elapsed: float, device=None) -> Tuple[int, f
     except ImportError:  # pragma: no cover
         pass
     return num_cuts, elapsed
+
+
+# ---- the sharded extraction driver --------------------------------------------------------------------------------------
+class _Rendezvous:
+    """The two barriers of the sharded driver (everybody has extracted / rank 0 has combined).  In order of preference: the caller's
+    process group (RCCL or gloo); a gloo group created here from torchrun's MASTER_ADDR / MASTER_PORT (host-side only -- the barrier
+    carries no data, so it does not need RCCL) and destroyed again; marker files next to the shards for ranks that were only given
+    RANK / WORLD_SIZE.  Marker names carry a run token shared by the ranks of one launch, so that the markers of an earlier run in the
+    same directory cannot satisfy this one."""
+
+    def __init__(self, marker_dir, rank: int, world: int, timeout: float):
+        self.dir, self.rank, self.world, self.timeout = marker_dir, rank, world, timeout
+        self.dist = None
+        self.owns_group = False
+        if world == 1:
+            return
+        try:
+            import datetime
+
+            import torch.distributed as dist
+
+            if dist.is_available():
+                if dist.is_initialized():
+                    self.dist = dist
+                elif "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ:
+                    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout))
+                    self.dist, self.owns_group = dist, True
+        except ImportError:  # pragma: no cover
+            pass
+        self.token = os.environ.get("HIPFEAT_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or f"ppid{os.getppid()}"
+
+    def barrier(self, tag: str) -> None:
+        import time
+        from pathlib import Path
+
+        if self.world == 1:
+            return
+        if self.dist is not None:
+            self.dist.barrier()
+            return
+        d = Path(self.dir)
+        (d / f".{tag}-{self.token}-{self.rank}").write_text("done")
+        deadline = time.time() + self.timeout
+        while not all((d / f".{tag}-{self.token}-{r}").exists() for r in range(self.world)):
+            if time.time() > deadline:
+                missing = [r for r in range(self.world) if not (d / f".{tag}-{self.token}-{r}").exists()]
+                raise TimeoutError(f"sharded extraction: ranks {missing} did not reach '{tag}' within {self.timeout:.0f} s")
+            time.sleep(0.05)
+
+    def close(self) -> None:
+        if self.owns_group:
+            self.dist.destroy_process_group()
+            self.owns_group = False
+
+
+def shard_paths(storage_path, manifest_path, rank: int):
+    """(storage, manifest) of one rank: `<storage_path>/feats-<rank>` as the reference names its per-job storages
+    (lhotse/cut/set.py:2141-2153) and `cuts-<rank>.jsonl.gz` next to the combined manifest."""
+    from pathlib import Path
+
+    sp = Path(storage_path)
+    mp = Path(manifest_path)
+    return sp / f"feats-{rank}", mp.parent / f"{mp.name.split('.')[0]}-{rank}.jsonl.gz"
+
+
+def combine_shard_manifests(cuts, manifest_path, shard_manifests: Sequence, owner) -> "object":
+    """Merge the per-rank manifests into ONE manifest in the order of `cuts` (the reference's `combine` concatenates job after job,
+    lhotse/cut/set.py:2194; restoring the input order makes the result independent of the number of GPUs).  Streaming: every shard
+    manifest is read once, in step with one pass over the input ids; cuts a rank dropped (audio that failed to load) are skipped.
+    `owner(i, cut)` = rank that owned input cut i."""
+    from lhotse import CutSet
+    from lhotse.serialization import load_manifest_lazy
+
+    readers = [iter(load_manifest_lazy(p)) for p in shard_manifests]
+    heads = [next(r, None) for r in readers]
+    with CutSet.open_writer(manifest_path, overwrite=True) as w:
+        for i, cut in enumerate(cuts):
+            r = owner(i, cut)
+            h = heads[r]
+            if h is not None and h.id == cut.id:
+                w.write(h)
+                heads[r] = next(readers[r], None)
+    left = [h.id for h in heads if h is not None]
+    if left:
+        raise RuntimeError(f"sharded extraction: shard manifests hold cuts that are not in the input, or are out of order: {left[:3]}")
+    return w.open_manifest()
+
+
+def compute_and_store_features_sharded(
+    cuts,
+    extractor,
+    storage_path,
+    manifest_path,
+    batch_duration: float = 600.0,
+    num_workers: int = 4,
+    collate: bool = False,
+    augment_fn=None,
+    storage_type=None,
+    overwrite: bool = False,
+    balance: str = "round_robin",
+    rank: int = None,
+    world: int = None,
+    barrier_timeout: float = 3600.0,
+):
+    """Feature extraction of one CutSet over the GPUs of a node: the multi-GPU form of ``compute_and_store_features_batch``.
+
+    Every rank calls this with the SAME arguments (one process per GPU: ``torchrun --nproc-per-node 8 script.py``).  Rank *r* of *W*
+    (``rank_and_world()``: process group, else RANK / WORLD_SIZE) takes its shard of the cuts -- ``balance="round_robin"``: cuts
+    r, r+W, ... exactly as the reference's ``CutSet(LazySlicer(self.data, k=i, n=num_jobs))`` (lhotse/cut/set.py:2158-2160), lazily;
+    ``balance="duration"``: duration-balanced shards for mixed-length corpora (needs one pass over the durations) -- runs the bulk
+    batch driver on GPU ``LOCAL_RANK`` into its own storage ``<storage_path>/feats-r`` and manifest ``cuts-r.jsonl.gz`` (per-shard
+    resume included: an interrupted run continues where each rank stopped), and after a barrier rank 0 merges the shard manifests into
+    ``manifest_path`` in input order.  NO collective touches the data path; the barrier is the only communication.
+
+    Returns the combined CutSet on rank 0 and the rank's own shard CutSet elsewhere."""
+    from pathlib import Path
+
+    from lhotse import CutSet
+    from lhotse.lazy import LazySlicer
+
+    from .storage import compute_and_store_features_batch
+
+    if rank is None or world is None:
+        rank, world = rank_and_world()
+    if balance not in ("round_robin", "duration"):
+        raise ValueError(f"balance must be 'round_robin' or 'duration', got {balance!r}")
+    if manifest_path is None:
+        raise ValueError("sharded extraction needs a manifest_path: the shards meet on disk")
+    manifest_path = Path(manifest_path)
+    storage_path = Path(storage_path)
+    storage_path.mkdir(parents=True, exist_ok=True)
+    manifest_path.parent.mkdir(parents=True, exist_ok=True)
+    # one GPU per rank: a bare "cuda" device becomes this rank's GPU (LOCAL_RANK as torchrun sets it)
+    dev = str(getattr(extractor.config, "device", "cuda"))
+    if dev == "cuda" and world > 1:
+        extractor.to(f"cuda:{int(os.environ.get('LOCAL_RANK', rank))}")
+
+    if balance == "round_robin":
+        mine = CutSet(LazySlicer(cuts.data, k=rank, n=world)) if world > 1 else cuts
+
+        def owner(i, cut):
+            return i % world
+
+    else:
+        parts = shard_by_duration([c.duration for c in cuts], world)
+        owner_of = {}
+        for r, idx in enumerate(parts):
+            for i in idx:
+                owner_of[i] = r
+        keep = set(parts[rank])
+        mine = CutSet.from_cuts(c for i, c in enumerate(cuts) if i in keep) if world > 1 else cuts
+
+        def owner(i, cut):
+            return owner_of[i]
+
+    sub_storage, sub_manifest = shard_paths(storage_path, manifest_path, rank)
+    meet = _Rendezvous(manifest_path.parent, rank, world, barrier_timeout)
+    try:
+        out = compute_and_store_features_batch(mine, extractor, sub_storage, manifest_path=sub_manifest, batch_duration=batch_duration,
+                                               num_workers=num_workers, collate=collate, augment_fn=augment_fn, storage_type=storage_type,
+                                               overwrite=overwrite)
+        meet.barrier("extracted")
+        if rank == 0:
+            out = combine_shard_manifests(cuts, manifest_path, [shard_paths(storage_path, manifest_path, r)[1] for r in range(world)], owner)
+        meet.barrier("combined")
+    finally:
+        meet.close()
+    return out

@@ -203,11 +203,45 @@ _FEATURE_FIELD_ORDER = ("type", "num_frames", "num_features", "frame_shift", "sa
                         "storage_path", "storage_key", "recording_id", "channels")
 
 
-def _mono_cut_dict(cut, feats: Dict, rec_cache: Dict[int, Dict]) -> Optional[Dict]:
+_PLAIN_SCALARS = (str, int, float, bool, type(None))
+_NOT_PLAIN = object()
+
+
+def _plain_copy(v):
+    """A copy of ``v`` if it is made of JSON scalars, lists / tuples and str-keyed dicts only (what ``dataclasses.asdict`` would
+    hand back unchanged, None leaves included: lhotse/utils.py:166-182 filters dataclass fields, not plain dicts); else _NOT_PLAIN."""
+    if isinstance(v, _PLAIN_SCALARS):
+        return v
+    if type(v) in (list, tuple):
+        out = [_plain_copy(x) for x in v]
+        return _NOT_PLAIN if any(x is _NOT_PLAIN for x in out) else type(v)(out)
+    if type(v) is dict:
+        out = {}
+        for k, x in v.items():
+            x = _plain_copy(x)
+            if x is _NOT_PLAIN or not isinstance(k, str):
+                return _NOT_PLAIN
+            out[k] = x
+        return out
+    return _NOT_PLAIN
+
+
+# how many cuts took the template path / lhotse's own serialiser (tests assert that the fast path really runs behind lhotse's sampler,
+# which attaches a `dataloading_info` custom field to every cut: lhotse/dataset/sampling/base.py:473-487)
+TEMPLATE_STATS = {"template": 0, "fallback": 0}
+_REC_CACHE_MAX = 4096
+
+
+def _mono_cut_dict(cut, feats: Dict, rec_cache: Dict[str, Tuple[object, Dict]]) -> Optional[Dict]:
     """``fastcopy(cut, features=Features(...)).to_dict()`` for a MonoCut (lhotse/cut/data.py:90-98) assembled from parts; the
-    recording's dict is built once per Recording object.  None = leave this cut to lhotse's own serialiser."""
+    recording's dict is built once per Recording OBJECT (the cache is keyed by the recording id and holds the object it was built
+    from: an ``id()`` key alone would be reused by CPython for another object once a lazily loaded batch is freed).
+    None = leave this cut to lhotse's own serialiser."""
+    custom = None
     if cut.custom is not None:
-        return None  # custom fields may hold nested manifests
+        custom = _plain_copy(cut.custom)  # e.g. {"dataloading_info": {...}}; manifests / arrays in custom fields go the slow way
+        if custom is _NOT_PLAIN:
+            return None
     feats = dict(feats)
     feats["recording_id"] = cut.recording_id
     feats["channels"] = cut.channel
@@ -217,10 +251,14 @@ def _mono_cut_dict(cut, feats: Dict, rec_cache: Dict[int, Dict]) -> Optional[Dic
     d["features"] = feats
     rec = cut.recording
     if rec is not None:
-        rd = rec_cache.get(id(rec))
-        if rd is None:
-            rd = rec_cache[id(rec)] = _recording_dict(rec)
-        d["recording"] = rd
+        entry = rec_cache.get(rec.id)
+        if entry is None or entry[0] is not rec:
+            if len(rec_cache) >= _REC_CACHE_MAX:
+                rec_cache.clear()
+            entry = rec_cache[rec.id] = (rec, _recording_dict(rec))
+        d["recording"] = entry[1]
+    if custom is not None:
+        d["custom"] = custom
     d["type"] = "MonoCut"
     return d
 
@@ -269,18 +307,29 @@ def compute_and_store_features_batch(
     from lhotse.utils import compute_num_frames, fastcopy
     from torch.utils.data import DataLoader
 
-    storage_type = storage_type or HipArchiveWriter
+    storage_type = storage_type or HipArchiveWriter  # NB manifests that name "hip_archive" need `import lhotse_amd` to be read back
+    if getattr(storage_type, "name", None) == "numpy_files":  # lhotse/cut/set.py:2285-2288
+        storage_path = Path(storage_path)
+        if storage_path.exists() and storage_path.is_file():
+            storage_path = storage_path.with_name(f"{storage_path.name}_storage")
     frame_shift = extractor.frame_shift
     manifest = CutSet.open_writer(manifest_path, overwrite=overwrite)
-    sampler = SimpleCutSampler(cuts, max_duration=batch_duration)
+    # rank / world pinned: under torchrun lhotse's samplers would otherwise split (and pad with duplicated cuts) what they are given once
+    # more (lhotse/dataset/sampling/base.py:152-163); sharding over GPUs is explicit here (lhotse_amd.compute_and_store_features_sharded)
+    sampler = SimpleCutSampler(cuts, max_duration=batch_duration, world_size=1, rank=0)
     sampler.filter(lambda cut: cut.id not in manifest.ignore_ids)  # resume: skip what the manifest already holds
     loader = DataLoader(UnsupervisedWaveformDataset(collate=collate), batch_size=None, sampler=sampler, num_workers=num_workers)
-    rec_cache: Dict[int, Dict] = {}
+    rec_cache: Dict[str, Tuple[object, Dict]] = {}
 
     def save(writer, batch_cuts, host: np.ndarray, frames: List[int], template: Dict) -> None:
         # the frame-count contract of validate_features (qa.py:286-301), for the whole batch
         for c, t in zip(batch_cuts, frames):
-            if not isinstance(c, PaddingCut) and compute_num_frames(c.duration, frame_shift, c.sampling_rate) != t:
+            if isinstance(c, PaddingCut):
+                continue
+            hop = round(frame_shift * c.sampling_rate, ndigits=12)  # qa.py:286-291: the hop must be a whole number of samples
+            if not float(hop).is_integer():
+                raise AssertionError(f"cut {c.id}: frame_shift {frame_shift} s is {hop} samples at {c.sampling_rate} Hz (not an integer)")
+            if compute_num_frames(c.duration, frame_shift, c.sampling_rate) != t:
                 raise AssertionError(f"cut {c.id}: {t} frames for {c.duration} s at frame_shift {frame_shift} (lhotse expects "
                                      f"{compute_num_frames(c.duration, frame_shift, c.sampling_rate)})")
         stored = [i for i, c in enumerate(batch_cuts) if not isinstance(c, PaddingCut)]
@@ -296,7 +345,9 @@ def compute_and_store_features_batch(
                 manifest.write(fastcopy(c, num_frames=frames[i], num_features=host.shape[1], frame_shift=frame_shift))
                 continue
             fd = _features_dict(template, c, frames[i], keys[i])
-            out = _mono_cut_dict(c, fd, rec_cache) if type(c) is MonoCut else None
+            # (an in-memory manifest -- no manifest_path -- keeps the objects it is given: no templates there)
+            out = _mono_cut_dict(c, fd, rec_cache) if type(c) is MonoCut and manifest_path is not None else None
+            TEMPLATE_STATS["fallback" if out is None else "template"] += 1
             if out is None:  # mixed cuts, custom fields: lhotse's own objects (lhotse/cut/set.py:2335-2363)
                 fm = Features(recording_id=c.id if isinstance(c, MixedCut) else c.recording_id, channels=0 if isinstance(c, MixedCut) else c.channel,
                               **{k: v for k, v in fd.items()})

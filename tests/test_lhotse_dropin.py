@@ -355,6 +355,41 @@ def test_bulk_save_driver_equals_the_reference_driver(tmp_path, cutset, cpu_devi
         assert a.features.storage_type == "numpy_files" and np.allclose(a.load_features(), b.load_features(), atol=2e-3)
 
 
+def test_template_manifests_behind_lazy_cuts_and_loader_workers(tmp_path, cutset, cpu_device):
+    """with lazily loaded cuts (fresh Recording objects per batch, addresses reused by CPython) and DataLoader workers the
+    per-recording cache of the template path must never hand one cut another cut's recording, and the template path must be the one
+    that runs behind lhotse's sampler (which attaches a `dataloading_info` custom field to every cut)."""
+    import lhotse_amd as LA
+    from lhotse import CutSet, NumpyFilesWriter
+
+    many = CutSet.from_cuts(c.with_id(f"{c.id}-{k}") for k in range(8) for c in cutset)  # 40 cuts over 5 recordings
+    many.to_file(tmp_path / "in.jsonl.gz")
+    lazy = CutSet.from_jsonl_lazy(tmp_path / "in.jsonl.gz")
+    ex = LA.HipFbank()
+    ref = list(lazy.compute_and_store_features_batch(extractor=ex, storage_path=tmp_path / "ref", manifest_path=tmp_path / "ref.jsonl.gz",
+                                                     batch_duration=2.0, num_workers=1, storage_type=NumpyFilesWriter))
+    before = dict(LA.storage.TEMPLATE_STATS)
+    ours = list(LA.compute_and_store_features_batch(lazy, extractor=ex, storage_path=tmp_path / "ours", manifest_path=tmp_path / "ours.jsonl.gz",
+                                                    batch_duration=2.0, num_workers=1))
+    assert LA.storage.TEMPLATE_STATS["template"] - before["template"] == 40 and LA.storage.TEMPLATE_STATS["fallback"] == before["fallback"]
+    assert [c.id for c in ours] == [c.id for c in ref] and len(ours) == 40
+    for a, b in zip(ours, ref):
+        da, db = a.to_dict(), b.to_dict()
+        for k in ("storage_type", "storage_path", "storage_key"):
+            da["features"].pop(k), db["features"].pop(k)
+        assert da == db and da["recording"]["id"] == a.id.split("-")[0].replace("cut", "rec")
+        assert da["custom"]["dataloading_info"]["world_size"] == 1
+        assert np.array_equal(a.load_features(), b.load_features())
+    # a custom field that is itself a manifest goes through lhotse's own serialiser
+    c0 = many[0]
+    c0.custom = {"other_recording": c0.recording}
+    LA.compute_and_store_features_batch(CutSet.from_cuts([c0]), extractor=ex, storage_path=tmp_path / "c", manifest_path=tmp_path / "c.jsonl.gz",
+                                        num_workers=0)
+    assert LA.storage.TEMPLATE_STATS["fallback"] == before["fallback"] + 1
+    back = list(CutSet.from_file(tmp_path / "c.jsonl.gz"))[0]
+    assert back.custom["other_recording"].id == c0.recording.id and back.has_features
+
+
 def test_archive_backend_round_trip_without_lhotse_objects(tmp_path):
     """The archive itself: packed batch appends, self-describing keys, positioned partial reads, append mode."""
     import lhotse_amd as LA
