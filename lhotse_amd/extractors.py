@@ -269,6 +269,13 @@ class _Plan:
             return np.where(s < self.n, 0, 1 + (s - self.n) // self.shift).astype(np.int64)
         return (s + self.shift // 2) // self.shift
 
+    def frame_counts(self, lengths: np.ndarray, padded: Optional[np.ndarray]) -> np.ndarray:
+        """Rows every item of a batch yields (a1 of SURVEY 8a; with `padded` the rows an item keeps of a zero-padded batch row)."""
+        lengths = _lib.i64(lengths)
+        if padded is None:
+            return self.num_frames_many(lengths)
+        return np.minimum((lengths + self.batch_hop // 2) // self.batch_hop, self.num_frames_many(_lib.i64(padded)))
+
     def run(self, wave: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray, padded: Optional[np.ndarray]) -> Tuple[torch.Tensor, np.ndarray]:
         """wave: float32 tensor on self.device holding every cut; returns the packed
         (sum T_b, F) feature matrix (same device, same stream) and the per-cut frame counts."""
@@ -401,16 +408,64 @@ class _HostStaging:
         ev.record(torch.cuda.current_stream(device))
 
     def fetch(self, dev_tensor: torch.Tensor) -> torch.Tensor:
-        """Device tensor -> fresh CPU tensor (D2H through the pinned buffer, then one host copy)."""
-        n = dev_tensor.numel()
-        with self.lock:
-            if self._out is None or self._out.numel() < n:
-                self._out = torch.empty(max(n, 1 << 20), dtype=torch.float32, pin_memory=True)
-            view = self._out[:n].view(dev_tensor.shape)
-            view.copy_(dev_tensor, non_blocking=False)
-            fresh = torch.empty(dev_tensor.shape, dtype=torch.float32)
-            _parallel_copy(fresh.view(-1).numpy(), [(0, self._out[:n].numpy())])
+        """Device tensor -> fresh CPU tensor: ONE D2H copy straight into page-locked memory that torch's caching host allocator hands
+        out (and takes back when the caller drops the result) -- no bounce buffer, no second host copy."""
+        fresh = torch.empty(dev_tensor.shape, dtype=dev_tensor.dtype, pin_memory=True)
+        fresh.copy_(dev_tensor, non_blocking=True)
+        torch.cuda.current_stream(dev_tensor.device).synchronize()
         return fresh
+
+
+class _HostPipeline:
+    """extract_batch on HOST inputs with HOST outputs (what lhotse's batch driver and its save thread see, cut/set.py:2393-2398): the batch
+    is cut into a few chunks and every chunk goes H2D -> kernel on one side stream and D2H on a second one, so that the upload of chunk
+    n+1, the launch of chunk n and the download of chunk n-1 overlap (PCIe is full duplex; the kernel is ~100x faster than either copy).
+    Page-locked inputs are DMA sources as they are; pageable ones are packed chunk by chunk into the ping-pong pinned staging buffers
+    while the previous chunk is on the wire.  The result is ONE fresh pinned tensor holding the packed (sum T_b, F) matrix."""
+
+    TARGET_CHUNKS = int(os.environ.get("HIPFEAT_PIPE_CHUNKS", "4"))
+    MIN_CHUNK_BYTES = 2 << 20
+    MAX_CHUNK_BYTES = 48 << 20
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.s_in = torch.cuda.Stream(device=device)
+        self.s_out = torch.cuda.Stream(device=device)
+        self.lock = threading.Lock()  # one batch at a time per extractor: the two streams are the pipeline
+
+    @classmethod
+    def chunk_bounds(cls, nbytes: np.ndarray) -> List[Tuple[int, int]]:
+        """Consecutive item ranges of roughly equal input bytes: about TARGET_CHUNKS per batch, within [MIN, MAX] bytes each."""
+        total = int(nbytes.sum())
+        target = min(max(total // cls.TARGET_CHUNKS, cls.MIN_CHUNK_BYTES), cls.MAX_CHUNK_BYTES)
+        bounds, a, acc = [], 0, 0
+        for i, b in enumerate(nbytes.tolist()):
+            acc += int(b)
+            if acc >= target:
+                bounds.append((a, i + 1))
+                a, acc = i + 1, 0
+        if a < len(nbytes):
+            bounds.append((a, len(nbytes)))
+        return bounds
+
+    def run(self, plan, bounds: Sequence[Tuple[int, int]], frames: np.ndarray, upload) -> torch.Tensor:
+        """`upload(a, b)` (called with s_in current) puts items a..b-1 on the device and returns what `plan.run` needs for them."""
+        rows = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
+        host = torch.empty((int(rows[-1]), plan.feature_dim), dtype=torch.float32, pin_memory=True)
+        with self.lock, torch.cuda.device(self.device):
+            for a, b in bounds:
+                with torch.cuda.stream(self.s_in):
+                    wave, offs, lens, padded = upload(a, b)
+                    out, got = plan.run(wave, offs, lens, padded)
+                    done = torch.cuda.Event()
+                    done.record(self.s_in)
+                assert np.array_equal(got, frames[a:b]), "frame counts of the chunk differ from the batch plan"
+                with torch.cuda.stream(self.s_out):
+                    self.s_out.wait_event(done)
+                    host[int(rows[a]) : int(rows[b])].copy_(out, non_blocking=True)
+                    out.record_stream(self.s_out)
+            self.s_out.synchronize()
+        return host
 
 
 _SHARED_STAGING: Dict[int, "_HostStaging"] = {}
@@ -497,6 +552,7 @@ class _HipExtractor(FeatureExtractor):
         st["_plan"] = None  # the device handle is per process
         st["_staging"] = None
         st.pop("_lock", None)
+        st.pop("_pipeline", None)
         return st
 
     def _drop_plan(self):
@@ -547,6 +603,71 @@ class _HipExtractor(FeatureExtractor):
         if dev_tensor.device.type != "cuda":
             return dev_tensor
         return self._stage().fetch(dev_tensor)
+
+    def _pipe(self) -> "_HostPipeline":
+        pipe = self.__dict__.get("_pipeline")
+        if pipe is None:
+            with self._lazy_lock():
+                pipe = self.__dict__.get("_pipeline")
+                if pipe is None:
+                    pipe = self.__dict__["_pipeline"] = _HostPipeline(self.plan.device)
+        return pipe
+
+    def _host_items_to_host(self, items: Sequence[ArrayLike], padded_len: Optional[int]) -> Tuple[torch.Tensor, np.ndarray]:
+        """Host waveforms in, packed host feature matrix out, through the chunked H2D / kernel / D2H pipeline."""
+        plan = self.plan
+        lens = np.array([int(x.shape[0]) for x in items], dtype=np.int64)
+        padded = None if padded_len is None else np.full(len(items), padded_len, dtype=np.int64)
+        frames = plan.frame_counts(lens, padded)
+        if int(frames.min(initial=1)) <= 0:  # let the library word the error (and raise it) as for a single launch
+            return self._extract_items_host_fallback(items, padded_len)
+        bounds = _HostPipeline.chunk_bounds(lens * (2 if _is_pcm16(items[0]) else 4))
+
+        def upload(a, b):
+            wave, offs, ln = self._pack(items[a:b])
+            return wave, offs, ln, None if padded is None else padded[a:b]
+
+        return self._pipe().run(plan, bounds, frames, upload), frames
+
+    def _extract_items_host_fallback(self, items, padded_len):
+        packed, frames = self._extract_items(items, padded_len)
+        return self._to_host(packed), frames
+
+    def _host_rows_to_host(self, wave2d: torch.Tensor, lens: np.ndarray, zero_pad: bool) -> Tuple[torch.Tensor, np.ndarray]:
+        """A padded (B, Smax) HOST tensor (float32 or int16 PCM) + lengths in, packed host feature matrix out.  Page-locked tensors are
+        the DMA source themselves; pageable rows are packed chunk by chunk into pinned staging while the previous chunk is on the wire."""
+        plan, dev = self.plan, self.plan.device
+        smax = int(wave2d.shape[1])
+        padded = np.full(len(lens), smax, dtype=np.int64) if zero_pad else None
+        frames = plan.frame_counts(lens, padded)
+        pcm = wave2d.dtype == torch.int16
+        pinned = wave2d.is_pinned()
+        if int(frames.min(initial=1)) <= 0:
+            bounds = [(0, len(lens))]
+        else:
+            bounds = _HostPipeline.chunk_bounds(np.full(len(lens), smax * (2 if pcm else 4), dtype=np.int64))
+        stage = None if pinned else self._stage()
+
+        def upload(a, b):
+            src = wave2d[a:b].reshape(-1)
+            n = src.numel()
+            d = torch.empty(n, dtype=src.dtype, device=dev)
+            if pinned:
+                d.copy_(src, non_blocking=True)
+            else:
+                with stage.lock:
+                    host, slot = stage.input(n if not pcm else (n + 1) // 2)
+                    hv = host.view(torch.int16) if pcm else host
+                    _parallel_copy(hv.numpy(), [(0, src.numpy())])
+                    d.copy_(hv[:n], non_blocking=True)
+                    stage.sent(slot, dev)
+            if pcm:
+                f = torch.empty(n, dtype=torch.float32, device=dev)
+                plan.lib.check("hipfeat_pcm16_to_float", d.data_ptr(), f.data_ptr(), n, int(torch.cuda.current_stream(dev).cuda_stream))
+                d = f
+            return d, np.arange(b - a, dtype=np.int64) * smax, lens[a:b], None if padded is None else padded[a:b]
+
+        return self._pipe().run(plan, bounds, frames, upload), frames
 
     def _pack(self, items: Sequence[ArrayLike]) -> Tuple[torch.Tensor, np.ndarray, np.ndarray]:
         """Concatenate 1-D waveforms into one device buffer (one H2D copy for host inputs).  Every
@@ -656,30 +777,31 @@ class _HipExtractor(FeatureExtractor):
         with torch.no_grad():
             if lengths is not None:
                 assert isinstance(samples, torch.Tensor), "If `lengths` is provided, `samples` must be a batched and padded torch.Tensor."
-                if samples.dtype != torch.float32:
-                    raise TypeError(f"extract_batch(): expected float32 samples, got {samples.dtype}")
+                if samples.dtype not in (torch.float32, torch.int16):
+                    raise TypeError(f"extract_batch(): expected float32 (or int16 PCM) samples, got {samples.dtype}")
                 lens = np.asarray(lengths.cpu() if isinstance(lengths, torch.Tensor) else lengths).astype(np.int64).reshape(-1)
                 assert samples.ndim == 2 and samples.shape[0] == len(lens)
                 smax = int(samples.shape[1])
                 assert int(lens.max(initial=0)) <= smax
                 dev = self.plan.device
                 wave = samples.contiguous()
-                if wave.device != dev:
-                    if wave.device.type == "cpu" and dev.type == "cuda":
-                        stage = self._stage()
-                        with stage.lock:
-                            host, slot = stage.input(wave.numel())
-                            _parallel_copy(host.numpy(), [(0, wave.view(-1).numpy())])
-                            dwave = torch.empty(wave.shape, dtype=torch.float32, device=dev)
-                            dwave.copy_(host[: wave.numel()].view(wave.shape), non_blocking=True)
-                            stage.sent(slot, dev)
-                        wave = dwave
-                    else:
-                        wave = wave.to(dev)
-                offs = np.arange(len(lens), dtype=np.int64) * smax
-                padded = np.full(len(lens), smax, dtype=np.int64) if zero_pad else None
+                host_done = False
                 try:
-                    packed, frames = self.plan.run(wave.reshape(-1), offs, lens, padded)
+                    if wave.device.type == "cpu" and dev.type == "cuda":
+                        packed, frames = self._host_rows_to_host(wave, lens, zero_pad)
+                        host_done = True
+                    else:
+                        if wave.device != dev:
+                            wave = wave.to(dev)
+                        if wave.dtype == torch.int16:
+                            with torch.cuda.device(dev):
+                                f = torch.empty(wave.shape, dtype=torch.float32, device=dev)
+                                self.plan.lib.check("hipfeat_pcm16_to_float", wave.data_ptr(), f.data_ptr(), wave.numel(),
+                                                    int(torch.cuda.current_stream(dev).cuda_stream))
+                            wave = f
+                        offs = np.arange(len(lens), dtype=np.int64) * smax
+                        padded = np.full(len(lens), smax, dtype=np.int64) if zero_pad else None
+                        packed, frames = self.plan.run(wave.reshape(-1), offs, lens, padded)
                 except _lib.HipFeatError as e:
                     if e.status == _lib.ERR_TOO_SHORT:
                         raise ValueError(str(e)) from e
@@ -697,12 +819,24 @@ class _HipExtractor(FeatureExtractor):
                 # the reference squeezes every item (extractors.py:519-522)
                 items = [x if (x.ndim == 1 and x.dtype in (torch.float32, np.float32, torch.int16, np.int16)) else _as_1d_float(x.squeeze() if x.ndim > 1 else x, "extract_batch()") for x in items]
                 pmax = max(int(x.shape[0]) for x in items) if zero_pad else None
-                packed, frames = self._extract_items(items, pmax)
+                host_done = False
+                to_host = not input_is_torch or self._cpu_outputs
+                on_host = all(not isinstance(x, torch.Tensor) or x.device.type == "cpu" for x in items)
+                if to_host and on_host and self.plan.device.type == "cuda":
+                    try:
+                        packed, frames = self._host_items_to_host(items, pmax)
+                    except _lib.HipFeatError as e:
+                        if e.status == _lib.ERR_TOO_SHORT:
+                            raise ValueError(str(e)) from e
+                        raise
+                    host_done = True
+                else:
+                    packed, frames = self._extract_items(items, pmax)
 
-            if not input_is_torch:
-                packed = self._to_host(packed).numpy()
-            elif self._cpu_outputs:
+            if not host_done and (not input_is_torch or self._cpu_outputs):
                 packed = self._to_host(packed)
+            if not input_is_torch:
+                packed = packed.numpy()
             bounds = np.concatenate([[0], np.cumsum(frames)])
             result = [packed[int(bounds[i]) : int(bounds[i + 1])] for i in range(len(frames))]
 

@@ -273,9 +273,13 @@ def _batch_features_on_host(extractor, waves, sampling_rate: int, lengths) -> Tu
         zero_pad = getattr(extractor.config, "edge_rule", "reflect") == "batch_zero_pad"
         pmax = max(int(x.shape[0]) for x in items) if zero_pad else None
         with torch.no_grad():
-            packed, frames = extractor._extract_items(items, pmax)
-            host = extractor._to_host(packed).numpy()
-        return host, [int(t) for t in frames]
+            on_host = all(not isinstance(x, torch.Tensor) or x.device.type == "cpu" for x in items)
+            if on_host and hasattr(extractor, "_host_items_to_host") and extractor.plan.device.type == "cuda":
+                host, frames = extractor._host_items_to_host(items, pmax)  # chunked H2D / kernel / D2H pipeline, one pinned result
+            else:
+                packed, frames = extractor._extract_items(items, pmax)
+                host = extractor._to_host(packed)
+        return host.numpy(), [int(t) for t in frames]
     with torch.no_grad():
         feats = extractor.extract_batch(waves, sampling_rate=sampling_rate, lengths=lengths)
     if isinstance(feats, (np.ndarray, torch.Tensor)) and feats.ndim == 2:
