@@ -227,3 +227,53 @@ class HipResample(AudioTransform):
         old_offset = _compute_num_samples(offset, self.source_sampling_rate) / self.source_sampling_rate
         old_duration = None if duration is None else _compute_num_samples(duration, self.source_sampling_rate) / self.source_sampling_rate
         return old_offset, old_duration
+
+
+# ---- speed perturbation of a packed mini-batch, in place of the host loop of config 5 -------------------------------------------
+def perturbed_tail_floats(lengths: np.ndarray, factors: Sequence[float], sampling_rate: int) -> int:
+    """Floats the resampled cuts of a mini-batch need behind its inputs (every resampled cut starts on a 16-byte boundary)."""
+    total = 0
+    for f in sorted(set(float(x) for x in factors)):
+        if f == 1.0:
+            continue
+        idx = np.nonzero(np.asarray(factors, dtype=np.float64) == f)[0]
+        orig, new = constants.sinc_resample_kernel(round(sampling_rate * f), sampling_rate)[2:4]
+        out = np.ceil((new * _lib.i64(lengths)[idx] / orig).astype(np.float32)).astype(np.int64)
+        total += int(((out + 3) & ~3).sum())
+    return total
+
+
+def perturb_speed_in_arena(arena: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray, factors: Sequence[float], sampling_rate: int,
+                           tail_start: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Mixed-factor speed perturbation of a device-resident packed mini-batch (``PerturbSpeed`` picks one factor per cut,
+    lhotse/dataset/cut_transforms/perturb_speed.py:8-47; the arithmetic is ``Speed``, lhotse/augmentation/torchaudio.py:26-42).
+
+    ``arena`` is ONE float32 device buffer: the cuts at ``offsets`` / ``lengths`` in its front part, free space from ``tail_start`` on
+    (``perturbed_tail_floats`` says how much).  Cuts with factor 1 stay where they are; the others are resampled -- one launch per
+    distinct factor -- into the tail.  Returns the per-cut (offsets, lengths) of the perturbed batch inside the same arena, i.e. exactly
+    what ``hipfeat_extract*`` takes next: no copy of the unperturbed cuts, no host round trip, no second buffer."""
+    assert arena.dtype == torch.float32 and arena.is_contiguous() and arena.ndim == 1
+    offsets, lengths = _lib.i64(offsets).copy(), _lib.i64(lengths).copy()
+    fac = np.asarray(factors, dtype=np.float64)
+    assert len(fac) == len(lengths)
+    tail = (int(tail_start) + 3) & ~3
+    dev = arena.device
+    for f in sorted(set(fac.tolist())):
+        if f == 1.0:
+            continue
+        idx = np.nonzero(fac == f)[0]
+        r = get_or_create_resampler(round(sampling_rate * f), sampling_rate, dev)
+        out_lens = r.output_lengths(lengths[idx])
+        out_offs = np.zeros(len(idx), dtype=np.int64)
+        np.cumsum(((out_lens + 3) & ~3)[:-1], out=out_offs[1:])
+        out_offs += tail
+        end = int(out_offs[-1] + out_lens[-1])
+        if end > arena.numel():
+            raise ValueError(f"arena too small: {arena.numel()} floats, the perturbed cuts need {end} (see perturbed_tail_floats)")
+        in_offs, in_lens = np.ascontiguousarray(offsets[idx]), np.ascontiguousarray(lengths[idx])  # (named: they must outlive the call)
+        with torch.cuda.device(dev):
+            r.lib.check("hipfeat_resample", r.handle, arena.data_ptr(), _lib.addr(in_offs), _lib.addr(in_lens), int(len(idx)), arena.data_ptr(),
+                        _lib.addr(out_offs), int(torch.cuda.current_stream(dev).cuda_stream))
+        offsets[idx], lengths[idx] = out_offs, out_lens
+        tail = (end + 3) & ~3
+    return offsets, lengths

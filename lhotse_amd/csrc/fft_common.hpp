@@ -148,6 +148,42 @@ __device__ __forceinline__ void fft8(const v2* x, v2* X) {
   }
 }
 
+// Epilogue of a 4 x 4 x 1 filterbank accumulator (lane = 4 slot + filter, register = frame): the pieces of a filter group that the
+// schedule split over adjacent slots are summed across the DPP row (v += m4 * v[lane - 4], then v += m8 * v[lane - 8], zeros shifted in)
+// and the result is floored.  The row_shr adds are v_fmac_f32 with a DPP source operand (hipcc emits a v_mov_b32_dpp plus a v_fma for the
+// intrinsic form), the floor is a bare v_max (no canonicalising v_max(x, x) in front); `s_nop 7` covers the matrix-core -> VALU read
+// hazard and the VALU-write -> DPP-read hazard of whatever precedes the block, which hipcc cannot see through inline asm; inside the
+// block a register is read through DPP no sooner than three instructions after it was written.
+__device__ __forceinline__ void mel4_reduce_floor(const f32x4 acc, float m4, float m8, float floor_, float (&v)[4]) {
+  float v0 = acc[0], v1 = acc[1], v2_ = acc[2], v3 = acc[3];
+  asm volatile(
+      "s_nop 7\n\t"
+      "v_fmac_f32_dpp %0, %0, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %1, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %2, %2, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %3, %3, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %0, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %1, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %2, %2, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %3, %3, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_max_f32 %0, %0, %6\n\tv_max_f32 %1, %1, %6\n\tv_max_f32 %2, %2, %6\n\tv_max_f32 %3, %3, %6"
+      : "+v"(v0), "+v"(v1), "+v"(v2_), "+v"(v3)
+      : "v"(m4), "v"(m8), "v"(floor_));
+  v[0] = v0, v[1] = v1, v[2] = v2_, v[3] = v3;
+}
+// the rows of one accumulator set under ONE lane mask (the caller tests `col < M` once); nf < ROWS only in the last round of a cut
+template <int ROWS>
+__device__ __forceinline__ void mel4_store(float* o, int64_t stride, int nf, const float* v) {
+  if (nf >= ROWS) {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) o[i * stride] = v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < ROWS - 1; ++i)
+      if (i < nf) o[i * stride] = v[i];
+  }
+}
+
 // natural log of a normal positive float: v_log_f32 (log2, 1 ulp) times ln 2.  The argument is
 // >= mel_floor (1.19e-7), so the denormal path of the library logf is never needed.
 __device__ __forceinline__ float fast_log(float x) {

@@ -345,14 +345,11 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
           }
         }
         const f32x4 acc = acc0 + acc1;
+        float val[4];
+        mel4_reduce_floor(acc, m4, m8, p.mel_floor, val);  // fft_common.hpp: row_shr:4 / row_shr:8 multiply-adds, floor
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = acc[i];
-          v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4
-          v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8
-          v = __builtin_amdgcn_logf(fmaxf(v, p.mel_floor)) * log_scale;
-          if (col < p.M && i < nf) orow[i * p.out_stride + col] = v;
-        }
+        for (int i = 0; i < 4; ++i) val[i] = __builtin_amdgcn_logf(val[i]) * log_scale;
+        if (col < p.M) mel4_store<4>(orow + col, p.out_stride, nf, val);
       }
     }
     HFC_T(6);  // mel phase: operand reads, MFMAs, reduction, log, stores

@@ -384,14 +384,11 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
           }
         }
         const f32x4 acc = acc0 + acc1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {  // rows 2, 3 of a block repeat the two frames
-          float v = acc[i];
-          v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4
-          v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8
-          v = __builtin_amdgcn_logf(fmaxf(v, p.mel_floor)) * log_scale;
-          if (col < p.M && i < nf) orow[i * p.out_stride + col] = v;
-        }
+        float val[4];  // rows 2, 3 of a block repeat the two frames
+        mel4_reduce_floor(acc, m4, m8, p.mel_floor, val);  // fft_common.hpp: row_shr:4 / row_shr:8 multiply-adds, floor
+        val[0] = __builtin_amdgcn_logf(val[0]) * log_scale;
+        val[1] = __builtin_amdgcn_logf(val[1]) * log_scale;
+        if (col < p.M) mel4_store<2>(orow + col, p.out_stride, nf, val);
       }
     }
     HFC_T(6);  // mel phase: operand reads, MFMAs, reduction, log, stores

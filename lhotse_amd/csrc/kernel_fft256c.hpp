@@ -263,17 +263,18 @@ __global__ __launch_bounds__(64 * kDWaves, 4) void fft256c_kernel(const Fft512cP
           acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s][1][c4][i], bv[s][c4][i], acc1, 0, 0, 0);
         }
       }
+      // (fft_common.hpp::mel4_reduce_floor / mel4_store: fused DPP multiply-adds, one lane mask per set instead of one per value)
+      float val[8];
+      {
+        float v4[4];
+        mel4_reduce_floor(acc0, m4, m8, p.mel_floor, v4);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+        for (int i = 0; i < 4; ++i) val[i] = fast_log(v4[i]);
+        mel4_reduce_floor(acc1, m4, m8, p.mel_floor, v4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = h == 0 ? acc0[i] : acc1[i];
-          v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4 -- the odd slot of a pair takes its left neighbour's partial sum
-          v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8 -- the last slot of a group of 3 or 4 takes the first slot(s)'
-          v = fast_log(fmaxf(v, p.mel_floor));
-          if (col < p.M && 4 * h + i < nf) orow[(4 * h + i) * p.out_stride + col] = v;
-        }
+        for (int i = 0; i < 4; ++i) val[4 + i] = fast_log(v4[i]);
       }
+      if (col < p.M) mel4_store<8>(orow + col, p.out_stride, nf, val);
     }
     // the next round's exchange writes follow this round's power-row reads in the wave's own LDS queue (in order)
   }

@@ -397,30 +397,14 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         }
       }
       if (MODE != 0) acc[0] += acc[1];
-      // Reduction of the pieces of a split filter group, floor, log: every value of the round first, then the stores of a set under ONE
-      // lane mask (the per-value `if` of the first version cost eight exec-mask round trips per round).  The row_shr adds are
-      // v_fmac_f32 with a DPP source operand; s_nop 7 covers the matrix-core -> VALU read hazard hipcc cannot see through inline asm.
+      // Reduction of the pieces of a split filter group, floor, log (fft_common.hpp::mel4_reduce_floor): every value of the round first,
+      // then the stores of a set under ONE lane mask (the per-value `if` of the first version cost eight exec-mask round trips per round).
       float val[S][4];
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        float v0 = acc[s][0], v1 = acc[s][1], v2_ = acc[s][2], v3 = acc[s][3];
-        asm volatile(
-            "s_nop 7\n\t"
-            "v_fmac_f32_dpp %0, %0, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_fmac_f32_dpp %1, %1, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_fmac_f32_dpp %2, %2, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_fmac_f32_dpp %3, %3, %4 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_fmac_f32_dpp %0, %0, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_fmac_f32_dpp %1, %1, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_fmac_f32_dpp %2, %2, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_fmac_f32_dpp %3, %3, %5 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-            "v_max_f32 %0, %0, %6\n\tv_max_f32 %1, %1, %6\n\tv_max_f32 %2, %2, %6\n\tv_max_f32 %3, %3, %6"  // (no canonicalising v_max(x, x) in front)
-            : "+v"(v0), "+v"(v1), "+v"(v2_), "+v"(v3)
-            : "v"(lt_m4[s]), "v"(lt_m8[s]), "v"(p.mel_floor));
-        val[s][0] = fast_log(v0);
-        val[s][1] = fast_log(v1);
-        val[s][2] = fast_log(v2_);
-        val[s][3] = fast_log(v3);
+        mel4_reduce_floor(acc[s], lt_m4[s], lt_m8[s], p.mel_floor, val[s]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) val[s][i] = fast_log(val[s][i]);
       }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
@@ -429,15 +413,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
 #pragma unroll
           for (int i = 0; i < 4; ++i) lm[i] = val[s][i];
         } else if (col < p.M) {
-          float* o = orow + col;
-          if (nf == 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i * p.out_stride] = val[s][i];
-          } else {
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-              if (i < nf) o[i * p.out_stride] = val[s][i];
-          }
+          mel4_store<4>(orow + col, p.out_stride, nf, val[s]);
         }
       }
     }

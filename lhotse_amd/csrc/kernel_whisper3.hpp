@@ -276,12 +276,11 @@ __global__ __launch_bounds__(64 * kW3Waves, 4) void whisper3_kernel(const Whispe
         asm volatile("" ::: "memory");  // not before this set's MFMAs have been issued: the registers are theirs until then
         load_set(s2 & 1, s2 + 2);
       }
+      float red[4];
+      mel4_reduce_floor(acc, m4, m8, p.mel_floor, red);  // fft_common.hpp: row_shr:4 / row_shr:8 multiply-adds, floor
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float v = acc[i];
-        v = fmaf(dpp_mov<0x114>(v), m4, v);  // row_shr:4
-        v = fmaf(dpp_mov<0x118>(v), m8, v);  // row_shr:8
-        v = fast_log(fmaxf(v, p.mel_floor)) * 0.4342944819032518f;
+        const float v = fast_log(red[i]) * 0.4342944819032518f;
         if (col < p.M && i < nf) {
           // fused normalisation: y = (v + 4) / 4 right away (zeros in the padding row), the clamp follows in section 6; agent-scope
           // store = written through to memory, where the workgroup that finishes the cut may have to read it

@@ -18,9 +18,20 @@ from typing import Any, Dict, List
 U = "uniform"
 
 
-def _c(name: str, kind: str, cfg: Dict[str, Any], inputs: List, mode: str = "extract", rows: int = 0) -> Dict[str, Any]:
+def _c(name: str, kind: str, cfg: Dict[str, Any], inputs: List, mode: str = "extract", rows: int = 0, sample: int = 0) -> Dict[str, Any]:
     # rows > 0: only the first/last `rows` rows of each output are stored (long inputs)
-    return dict(name=name, kind=kind, cfg=cfg, inputs=[list(i) for i in inputs], mode=mode, rows=rows)
+    # sample > 0: `sample` rows per output at seeded random positions (plus the first and last four) are stored
+    return dict(name=name, kind=kind, cfg=cfg, inputs=[list(i) for i in inputs], mode=mode, rows=rows, sample=sample)
+
+
+def _realistic(sr: int, base_seed: int) -> List:
+    """20 inputs per sampling rate (VERDICT r2 task 4): speech-like signals of 0.6-3 s, a third of them 60 dB down."""
+    out = []
+    for i in range(20):
+        kind = ("voiced", "voiced", "speechlike", "voiced_quiet", "speechlike_quiet", "voiced")[i % 6]
+        secs = 0.6 + 0.12 * ((i * 7) % 21)
+        out.append((kind, int(secs * sr) + 13 * i, base_seed + i))
+    return out
 
 
 CASES: List[Dict[str, Any]] = [
@@ -90,6 +101,18 @@ CASES: List[Dict[str, Any]] = [
     # items of a zero-padded batch with round() = 276 (lhotse/utils.py:424-434): 9213 and 15264 samples give one row less
     _c("batch_fractional_hop", "fbank", {"sampling_rate": 22050, "frame_shift": 0.0125, "num_filters": 40},
        [(U, 22050, 101), (U, 9213, 102), (U, 15264, 103)], mode="batch"),
+    # ---- round 3: realistic signals through the DEFAULT-rate instance of every wave-autonomous kernel, full 10 s cuts ----
+    _c("fbank80_10s_full", "fbank", {}, [(U, 160000, 110)]),                       # every row of a 10 s cut (fft512c<13>)
+    _c("voiced_10s_full", "fbank", {}, [("voiced", 160000, 111)]),
+    _c("voiced_quiet_10s", "fbank", {}, [("voiced_quiet", 160000, 112)], sample=96),
+    _c("real16k", "fbank", {}, _realistic(16000, 200), sample=40),                  # fft512c<13>
+    _c("real8k", "fbank", {"sampling_rate": 8000}, _realistic(8000, 300), sample=40),    # fft256c<13>
+    _c("real24k", "fbank", {"sampling_rate": 24000}, _realistic(24000, 400), sample=40),  # fft1024c<20>
+    _c("real48k", "fbank", {"sampling_rate": 48000}, _realistic(48000, 500), sample=40),  # fft2048c<19,0>
+    _c("real16k_mfcc", "mfcc", {"num_filters": 40, "num_ceps": 40}, _realistic(16000, 600)[:8], sample=40),
+    _c("voiced_10s_8k", "fbank", {"sampling_rate": 8000}, [("voiced", 80000, 113), ("voiced_quiet", 80000, 114)], sample=96),
+    _c("voiced_10s_24k", "fbank", {"sampling_rate": 24000}, [("voiced", 240000, 115), ("speechlike_quiet", 240000, 116)], sample=96),
+    _c("voiced_10s_48k", "fbank", {"sampling_rate": 48000}, [("voiced", 480000, 117), ("voiced_quiet", 480000, 118)], sample=96),
 ]
 
 

@@ -81,3 +81,62 @@ class TorchFbank:
         pow_spec = torch.fft.rfft(x, dim=-1).abs() ** 2
         mel = torch.matmul(pow_spec, self.fb)
         return torch.max(mel, self.eps).log()[0].numpy()
+
+
+class TorchMfcc(TorchFbank):
+    """Mfcc.extract (lhotse/features/kaldi/extractors.py:222-245) = Wav2MFCC (layers.py:708-724): the log-mel above with the MFCC's
+    own filterbank, then `@ dct`, then `* lifter` -- the CPU baseline of bench.py --config mfcc40_libri.  Pinned by
+    tests/test_oracle.py::test_torch_mfcc_baseline_equals_golden against the reference's own output (golden `mfcc40x40`)."""
+
+    def __init__(self, num_filters: int = 40, num_ceps: int = 40, cepstral_lifter: int = 22):
+        cfg = K.RefConfig(kind="mfcc", num_filters=num_filters, num_ceps=num_ceps, cepstral_lifter=cepstral_lifter)
+        self.device = torch.device("cpu")
+        self.cfg = cfg
+        self.n, self.shift, self.fft = K.window_sizes(cfg)
+        self.window = torch.hann_window(self.n, periodic=False).pow(0.85)
+        self.fb = torch.from_numpy(np.ascontiguousarray(K.mel_matrix(cfg, np.float32).astype(np.float32)))
+        self.eps = torch.tensor(torch.finfo(torch.float32).eps)
+        self.dct = torch.from_numpy(np.ascontiguousarray(K.dct_matrix(num_ceps, num_filters, np.float32).astype(np.float32)))  # (M, C)
+        self.lifter = torch.from_numpy(K.lifter(num_ceps, cepstral_lifter, np.float32).astype(np.float32))
+
+    @torch.no_grad()
+    def extract(self, samples: np.ndarray) -> np.ndarray:
+        c = self.cfg
+        x = self.strided(torch.from_numpy(np.asarray(samples, dtype=np.float32)).reshape(1, -1))
+        x = x - torch.mean(x, dim=2, keepdim=True)
+        off = torch.nn.functional.pad(x, (1, 0), mode="replicate")
+        x = x - c.preemph_coeff * off[:, :, :-1]
+        x = x * self.window
+        x = torch.nn.functional.pad(x.unsqueeze(1), [0, self.fft - self.n], mode="constant", value=0.0).squeeze(1)
+        pow_spec = torch.fft.rfft(x, dim=-1).abs() ** 2
+        mel = torch.max(torch.matmul(pow_spec, self.fb), self.eps).log()
+        mfcc = torch.matmul(mel, self.dct)  # layers.py:717
+        if c.cepstral_lifter > 0:
+            mfcc = mfcc * self.lifter       # layers.py:718-719
+        return mfcc[0].numpy()
+
+
+class TorchSpeed:
+    """Speed.__call__ (lhotse/augmentation/torchaudio.py:26-83) -> ResampleTensor.forward (augmentation/resample.py:284-315) with the
+    reference's own torch calls: F.pad, conv1d(stride=orig) with the cached sinc kernel, transpose/reshape, trim to
+    ceil(new * length / orig).  The kernel values come from oracle/resample_ref.sinc_kernel (bit-identical to the reference's cached
+    buffer: tests/test_resample_oracle.py); the CPU baseline of bench.py --config onthefly."""
+
+    def __init__(self, sampling_rate: int, factor: float):
+        from . import resample_ref as R
+
+        self.orig_freq, self.new_freq = round(sampling_rate * factor), sampling_rate
+        k, self.width, self.orig, self.new = R.sinc_kernel(self.orig_freq, self.new_freq)
+        self.kernel = torch.from_numpy(np.ascontiguousarray(k))[:, None, :]  # (new, 1, kw)
+        self._len = R.resampled_length
+
+    @torch.no_grad()
+    def __call__(self, samples: np.ndarray) -> np.ndarray:
+        if self.orig_freq == self.new_freq:
+            return samples
+        w = torch.from_numpy(np.asarray(samples, dtype=np.float32)).reshape(1, -1)
+        length = w.shape[1]
+        w = torch.nn.functional.pad(w, (self.width, self.width + self.orig))
+        y = torch.nn.functional.conv1d(w[:, None], self.kernel, stride=self.orig)
+        y = y.transpose(1, 2).reshape(1, -1)
+        return y[0, : self._len(length, self.orig, self.new)].numpy()

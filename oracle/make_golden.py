@@ -113,7 +113,13 @@ def main():
         for i, o in enumerate(outs):
             arrays[f"shape{i}"] = np.array(o.shape, dtype=np.int64)
             arrays[f"sum{i}"] = np.array(o.astype(np.float64).sum())
-            if rows and o.shape[0] > 2 * rows:
+            sample = case.get("sample", 0)
+            if sample and o.shape[0] > sample + 8:
+                pick = np.random.RandomState(1000 + i).choice(o.shape[0] - 8, size=sample, replace=False) + 4
+                sel = np.unique(np.concatenate([np.arange(4), pick, np.arange(o.shape[0] - 4, o.shape[0])]))
+                arrays[f"rows{i}"] = sel.astype(np.int64)
+                arrays[f"sel{i}"] = o[sel]
+            elif rows and o.shape[0] > 2 * rows:
                 arrays[f"head{i}"] = o[:rows]
                 arrays[f"tail{i}"] = o[-rows:]
             else:

@@ -37,6 +37,8 @@ def golden_rows(z: Dict[str, np.ndarray], i: int, got: np.ndarray):
     assert tuple(got.shape) == shape, f"shape {got.shape} != golden {shape}"
     if f"out{i}" in z:
         return got, z[f"out{i}"]
+    if f"rows{i}" in z:
+        return got[z[f"rows{i}"]], z[f"sel{i}"]
     h, t = z[f"head{i}"], z[f"tail{i}"]
     return np.concatenate([got[: len(h)], got[-len(t) :]]), np.concatenate([h, t])
 

@@ -148,3 +148,36 @@ def test_torch_baseline_equals_golden():
                 assert np.array_equal(got, want), (name, i)
             else:
                 assert np.abs(got - want).max() <= 1e-5, (name, i)
+
+
+def test_torch_mfcc_baseline_equals_golden():
+    """The CPU baseline of `bench.py --config mfcc40_libri` (oracle/kaldi_torch.TorchMfcc: Wav2MFCC's own torch calls) against the
+    reference's output for Mfcc(num_filters=40, num_ceps=40)."""
+    from _golden import golden_rows, load_case
+    from oracle.kaldi_torch import TorchMfcc
+
+    tm = TorchMfcc(40, 40, 22)
+    case, waves, z = load_case("mfcc40x40")
+    assert case["cfg"].get("num_filters") == 40 and case["cfg"].get("num_ceps") == 40
+    for i, w in enumerate(waves):
+        got, want = golden_rows(z, i, tm.extract(w))
+        assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), i
+
+
+def test_torch_speed_baseline_equals_golden():
+    """The CPU baseline of `bench.py --config onthefly` (oracle/kaldi_torch.TorchSpeed: ResampleTensor's own torch calls) against the
+    reference's Speed outputs (tests/golden/resample_speed09 / speed11)."""
+    import os
+
+    from oracle.kaldi_torch import TorchSpeed
+    from oracle.make_golden_resample import CASES
+    from oracle.signals import make_signal
+
+    for name, mode, a, b, inputs in CASES:
+        if mode != "speed":
+            continue
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+        sp = TorchSpeed(a, b)
+        for i, (kind, num, seed) in enumerate(inputs):
+            y = sp(make_signal(kind, num, seed))
+            assert y.shape == z[f"out{i}"].shape and np.abs(y - z[f"out{i}"]).max() <= 5e-6
