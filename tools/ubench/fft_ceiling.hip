@@ -188,9 +188,13 @@ __global__ __launch_bounds__(64 * kWaves, 4) void ceiling_kernel(float* sink, in
         const v2 sp = m * HF_CJ + Z[k2];
         const v2 dm = m * HF_NCJ + Z[k2];
         const v2 tt = cmul2(dm, twsreg[k2]);
-        const v2 xp = sp + tt, xm = sp - tt;
-        pown[16 * k2] = xp.x * xp.x + xp.y * xp.y;
-        ppar[16 * (15 - k2)] = xm.x * xm.x + xm.y * xm.y;
+        v2 re2, im2, pw;  // the bin pair (k, 256 - k) side by side, as in the product
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(re2) : "v"(tt), "v"(HF_CJ), "v"(sp));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(im2) : "v"(tt), "v"(HF_CJ), "v"(sp));
+        pw = re2 * re2;
+        pw = im2 * im2 + pw;
+        pown[16 * k2] = pw.x;
+        ppar[16 * (15 - k2)] = pw.y;
       }
       if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
     }
@@ -209,22 +213,22 @@ __global__ __launch_bounds__(64 * kWaves, 4) void ceiling_kernel(float* sink, in
           bv[s][c4] = *reinterpret_cast<const f32x4*>(wb + c4 * 256);
         }
       }
+      // as the product since round 3: the two sets as two interleaved accumulation chains, then mel4_reduce_floor (fft_common.hpp)
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av[s][c4][i], bv[s][c4][i], acc, 0, 0, 0);
-        }
-        const float m4 = ltab[s * 256 + 4 * lane_o + 2], m8 = ltab[s * 256 + 4 * lane_o + 3];
+      for (int c4 = 0; c4 < 4; ++c4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float v = acc[i];
-          v = fmaf(dpp_mov<0x114>(v), m4, v);
-          v = fmaf(dpp_mov<0x118>(v), m8, v);
-          fold += fast_log(fmaxf(v, 1.1920929e-07f));
+          acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[0][c4][i], bv[0][c4][i], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[1][c4][i], bv[1][c4][i], acc[1], 0, 0, 0);
         }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float val[4];
+        mel4_reduce_floor(acc[s], ltab[s * 256 + 4 * lane_o + 2], ltab[s * 256 + 4 * lane_o + 3], 1.1920929e-07f, val);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fold += fast_log(val[i]);
       }
     } else {
       fold += myreg[lane_o];  // one LDS read keeps the power rows observable
