@@ -349,29 +349,45 @@ class _Plan:
 # --------------------------------------------------------------------------------------
 _COPY_POOL: Optional[ThreadPoolExecutor] = None
 _COPY_PIECE = 1 << 20  # floats per task (4 MiB)
+_COPY_THREADS = max(2, min(12, (os.cpu_count() or 2) // 2))
+_PACK_RUN = 1 << 20    # floats per pack-and-upload run of pack_to_device, at least (4 MiB)
 
 
 def _parallel_copy(dst: np.ndarray, pieces: Sequence[Tuple[int, np.ndarray]]) -> None:
-    """dst[o : o + len(src)] = src for every (o, src), spread over a few host threads.  numpy
-    releases the GIL inside the copies; one thread moves only ~2-5 GB/s, far below PCIe."""
+    """dst[o : o + len(src)] = src for every (o, src), spread over a few host threads.  numpy releases the GIL inside the copies; one
+    thread moves only ~5-10 GB/s, far below PCIe.  The pieces are dealt into ONE task per thread (runs of whole pieces, long pieces cut
+    at 4 MiB): submitting a future per piece costs ~25 us each in the submitting thread, which for a 600 s mini-batch of ~40 cuts was
+    more than the copies themselves."""
     global _COPY_POOL
     tasks = []
+    total = 0
     for o, src in pieces:
         n = src.shape[0]
         for a in range(0, n, _COPY_PIECE):
             tasks.append((o + a, src[a : a + _COPY_PIECE]))
-    if len(tasks) <= 2:
+        total += n
+    if len(tasks) <= 2 or total < (1 << 18):
         for o, src in tasks:
             dst[o : o + src.shape[0]] = src
         return
     if _COPY_POOL is None:
-        _COPY_POOL = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 2) // 2)), thread_name_prefix="hipfeat-copy")
+        _COPY_POOL = ThreadPoolExecutor(max_workers=_COPY_THREADS, thread_name_prefix="hipfeat-copy")
+    groups, acc, share = [[]], 0, total / min(_COPY_THREADS, len(tasks))
+    for t in tasks:
+        if acc >= share and len(groups) < _COPY_THREADS:
+            groups.append([])
+            acc = 0
+        groups[-1].append(t)
+        acc += t[1].shape[0]
 
-    def run(t):
-        o, src = t
-        dst[o : o + src.shape[0]] = src
+    def run(group):
+        for o, src in group:
+            dst[o : o + src.shape[0]] = src
 
-    list(_COPY_POOL.map(run, tasks))
+    futures = [_COPY_POOL.submit(run, g) for g in groups[1:]]
+    run(groups[0])  # the calling thread takes a share too
+    for f in futures:
+        f.result()
 
 
 class _HostStaging:
@@ -495,9 +511,21 @@ def pack_to_device(items: Sequence[ArrayLike], device: torch.device, stage: Opti
             if isinstance(x, torch.Tensor):
                 x = x.detach().cpu().contiguous().numpy()
             pieces.append((int(o), np.ascontiguousarray(x)))
-        _parallel_copy(host.numpy(), pieces)
         wave = torch.empty(total, dtype=torch.float32, device=device)
-        wave.copy_(host[:total], non_blocking=True)
+        hv = host.numpy()
+        # pack and upload in a few runs of items: while the DMA engine moves run i out of the pinned buffer the host threads are already
+        # copying run i+1 into it (the pack, not PCIe, is the slower of the two)
+        run_floats = max(_PACK_RUN, (total + 3) // 4)
+        a = 0
+        while a < len(pieces):
+            b, first = a, pieces[a][0]
+            while b < len(pieces) and pieces[b][0] + pieces[b][1].shape[0] - first <= run_floats:
+                b += 1
+            b = max(b, a + 1)
+            _parallel_copy(hv, pieces[a:b])
+            end = pieces[b - 1][0] + pieces[b - 1][1].shape[0]
+            wave[first:end].copy_(host[first:end], non_blocking=True)
+            a = b
         stage.sent(slot, device)
     return wave, offs, lens
 
