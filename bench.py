@@ -170,7 +170,7 @@ def load_profile_constants(kernel_name: str):
         return {}
 
 
-def compare(got, want, truth):
+def compare(got, want, truth, log_mel=True):
     """Error figures of one cut: rel_l2 / max_abs vs the float32 oracle, values inside rtol 1e-4 + atol 1e-3, and BOTH float32
     implementations against the float64 oracle (max and mean square), so that an element-wise number can be read in context."""
     import numpy as np
@@ -189,6 +189,10 @@ def compare(got, want, truth):
         "floor_sq": float((fl ** 2).sum()),
         "own_sq": float((own ** 2).sum()),
         # the elements behind a max_abs above the suite's bar: how many, and how far above log(mel floor) the largest of them sits
+        # the same comparison in the LINEAR domain with the reference's own floor constant as absolute tolerance: the reference clamps
+        # every mel energy at eps = 1.19e-7 (layers.py:536-538, 577), i.e. treats differences below eps as nothing
+        "lin_bad": (int((np.abs(np.exp(got.astype(np.float64)) - np.exp(want.astype(np.float64))) > 1e-4 * np.exp(want.astype(np.float64)) + 1.1920929e-07).sum())
+                    if log_mel else 0),
         "over": int((d > 2e-3).sum()),
         "over_ref_max": float(want[d > 2e-3].max()) if bool((d > 2e-3).any()) else None,
     }
@@ -206,6 +210,7 @@ def fold(stats):
         "hip_vs_f64_max_abs": max(s["own_abs"] for s in stats),
         "oracle_f32_vs_f64_rms": (sum(s["floor_sq"] for s in stats) / n) ** 0.5,
         "hip_vs_f64_rms": (sum(s["own_sq"] for s in stats) / n) ** 0.5,
+        "lin_bad": sum(max(s["lin_bad"], 0) for s in stats),
         "n_over_2e-3": sum(s["over"] for s in stats),
         "over_ref_value_max": max([s["over_ref_max"] for s in stats if s["over_ref_max"] is not None], default=None),
         "n_values": n,
@@ -366,7 +371,7 @@ class Mfcc40Libri:
             got = self.out[int(self.rows[i]) : int(self.rows[i + 1])].cpu().numpy()
             want, truth = o32.extract(x), o64.extract(x)
             assert got.shape == want.shape, (got.shape, want.shape)
-            stats.append(compare(got, want, truth))
+            stats.append(compare(got, want, truth, log_mel=False))  # cepstra: no linear-domain reading
         return fold(stats)
 
     def extra(self, args):
@@ -682,7 +687,7 @@ def main():
             local = par
             par = {k: float(v) for k, v in zip(keys, mx[:-1])}
             par.update(frac_within=-float(mx[-1]), n=int(cnt.item()))
-            par.update({k: local[k] for k in ("n_over_2e-3", "over_ref_value_max", "n_values")})  # (rank 0's own sample)
+            par.update({k: local[k] for k in ("n_over_2e-3", "over_ref_value_max", "n_values", "lin_bad")})  # (rank 0's own sample)
         # element-wise bar: the suite's 2e-3 (log units), or 3 x the reference arithmetic's OWN float32 error against float64 on the same
         # cuts where that is larger -- measured the same way for both (each against the float64 oracle), DESIGN section 2
         abs_bar = max(2e-3, 3.0 * par["oracle_f32_vs_f64_max_abs"])
@@ -699,6 +704,7 @@ def main():
             "frac_within_rtol1e-4_atol1e-3": par["frac_within"],
             "values_over_2e-3": {"count": par["n_over_2e-3"], "of": par["n_values"], "largest_reference_value_among_them": par["over_ref_value_max"],
                                  "log_mel_floor": -15.942385},  # elements over the bar sit within a few nats of the log(eps) clamp: DESIGN section 2
+            "linear_domain_outside_rtol1e-4_atol_eps": par["lin_bad"],  # values with |exp(hip) - exp(ref32)| > 1e-4 exp(ref32) + eps (the reference's own mel floor)
             "n": par["n"],
             "oracle_f32_vs_f64_rel_l2_max": float(f"{par['oracle_f32_vs_f64_rel_l2_max']:.3e}"),
             "pass_rel_l2": ok_rel,
