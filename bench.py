@@ -578,6 +578,8 @@ def init_dist(backend: str, dev):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")  # (BENCH_FORCE_DIST without a launcher: a group of one)
+    os.environ.setdefault("WORLD_SIZE", "1")
     if backend == "nccl":
         try:
             dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=120))
