@@ -631,8 +631,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
-    if args.dist_backend == "gloo":  # self-test mode: all ranks may share one GPU
-        local_rank = local_rank % torch.cuda.device_count()
+    # one GPU per rank; ranks wrap around when fewer devices are visible (a launcher that narrows *_VISIBLE_DEVICES per rank, or the
+    # gloo self-test where all ranks share the one GPU of the box)
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist, backend_used = None, None

@@ -213,7 +213,15 @@ def compute_and_store_features_sharded(
     # one GPU per rank: a bare "cuda" device becomes this rank's GPU (LOCAL_RANK as torchrun sets it)
     dev = str(getattr(extractor.config, "device", "cuda"))
     if dev == "cuda" and world > 1:
-        extractor.to(f"cuda:{int(os.environ.get('LOCAL_RANK', rank))}")
+        index = int(os.environ.get("LOCAL_RANK", rank))
+        try:
+            import torch
+
+            if torch.cuda.is_available():  # a launcher may narrow the visible devices per rank
+                index %= torch.cuda.device_count()
+        except ImportError:  # pragma: no cover
+            pass
+        extractor.to(f"cuda:{index}")
 
     if balance == "round_robin":
         mine = CutSet(LazySlicer(cuts.data, k=rank, n=world)) if world > 1 else cuts
