@@ -123,9 +123,9 @@ __global__ __launch_bounds__(64 * kWaves, 4) void ceiling_kernel(float* sink, in
         const float nc = -c, mu1 = (1.0f - c) * mu;
 #pragma unroll
         for (int n1 = 0; n1 < kNRows; ++n1) {
-          v2 t;
-          t.x = fmaf(nc, pv[n1], z[n1].x);
-          t.y = fmaf(nc, z[n1].x, z[n1].y);
+          v2 t;  // two plain v_fma_f32, as the product (kernel_fft512c.hpp)
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.x) : "s"(nc), "v"(pv[n1]), "v"(z[n1].x));
+          asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.y) : "s"(nc), "v"(z[n1].x), "v"(z[n1].y));
           z[n1] = (t - v2{mu1, mu1}) * win[n1];
         }
       } else {
