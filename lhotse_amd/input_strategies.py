@@ -1,6 +1,7 @@
 """
 ``HipOnTheFlyFeatures`` -- lhotse's ``OnTheFlyFeatures`` input strategy (lhotse/dataset/input_strategies.py:351-476)
-with the extraction + collation step fused on the GPU.
+with the extraction + collation step fused on the GPU and, since round 3, the speed
+perturbation of ``PerturbSpeed``-ed cuts moved there too.
 
 The reference computes a list of per-cut feature matrices and then ``collate_matrices(..., padding_value=LOG_EPSILON)``
 copies each of them into a fresh padded tensor (lhotse/dataset/collation.py:506-535).  Here the kernels write every
@@ -8,49 +9,180 @@ cut straight into its slot of the ``(B, Tmax, F)`` tensor and only the padding r
 (``hipfeat_extract_collated``); audio reading, wave transforms, ``return_audio`` / ``fault_tolerant`` outputs and the
 supervision helpers are inherited unchanged.
 
+Speed perturbation.  ``PerturbSpeed`` (lhotse/dataset/cut_transforms/perturb_speed.py:8-47) turns a cut into one whose
+recording carries a ``Speed(factor)`` transform; the resampling itself then happens on the CPU inside
+``Recording.load_audio`` (lhotse/audio/recording.py:431-490), one torch ``conv1d`` per cut, before the strategy ever
+sees the samples -- it is what an on-the-fly pipeline spends its time in once the features are on the GPU.  With
+``gpu_speed_perturb=True`` (default) a cut whose recording's ONLY transform is that ``Speed`` is read WITHOUT it -- the
+very segment of the original file ``load_audio`` would read, through the same ``reverse_timestamps`` /
+``AudioSource.load_audio`` calls -- and the batch is perturbed on the device, mixed factors and all, in the arena the
+feature launch reads from (``lhotse_amd.augmentation.perturb_speed_in_arena``).  Sample counts follow
+``assert_and_maybe_fix_num_samples`` (truncate; the rare cut that would need reflect-padding takes the reference's own
+path), values agree with the CPU ``Speed`` to the resampler's 1e-5.  Every other cut (mixed cuts, other or several
+transforms, multi-channel) is loaded exactly as before.
+
 Needs lhotse (it consumes ``CutSet``s); importing this module without lhotse works, constructing the class does not.
 """
 from __future__ import annotations
 
-from typing import Optional, Union
+from math import gcd, isclose
+from typing import List, Optional, Tuple, Union
 
+import numpy as np
 import torch
 
 from .compat import HAVE_LHOTSE, LOG_EPSILON
 
 if HAVE_LHOTSE:  # pragma: no cover - authoring container only
+    from lhotse.audio.utils import suppress_audio_loading_errors  # type: ignore
     from lhotse.dataset.collation import collate_vectors, read_audio_from_cuts  # type: ignore
     from lhotse.dataset.input_strategies import OnTheFlyFeatures, _get_executor  # type: ignore
+    from lhotse.utils import compute_num_samples  # type: ignore
+
+    def deferred_speed_factor(cut) -> Optional[float]:
+        """The factor of the cut's ``Speed`` transform if that is all that stands between the file and the samples (a mono cut over
+        a recording whose transform list is exactly ``[Speed(factor)]``, no video); None = load it the reference's way."""
+        if type(cut).__name__ != "MonoCut" or not cut.has_recording:
+            return None
+        rec = cut.recording
+        tf = rec.transforms
+        if not tf or len(tf) != 1 or getattr(rec, "has_video", False):
+            return None
+        t = tf[0]
+        name = t.get("name") if isinstance(t, dict) else type(t).__name__
+        if name != "Speed":
+            return None
+        factor = t["kwargs"]["factor"] if isinstance(t, dict) else t.factor
+        return float(factor)
+
+    def read_unperturbed(cut, factor: float) -> np.ndarray:
+        """The segment of the ORIGINAL audio that ``Recording.load_audio`` reads for this cut before it applies ``Speed(factor)``
+        (lhotse/audio/recording.py:412-467): same backward pass over the timestamps, same per-source reads."""
+        from lhotse.augmentation import Speed  # the reference's own class: its reverse_timestamps is the contract
+
+        rec = cut.recording
+        offset, duration = cut.start, cut.duration
+        if duration is not None and isclose(duration, rec.duration, abs_tol=1e-3):
+            duration = None  # (recording.py:415-417)
+        offset_aug, duration_aug = Speed(factor=factor).reverse_timestamps(offset=offset, duration=duration, sampling_rate=rec.sampling_rate)
+        per_source = []
+        for source in rec.sources:
+            if cut.channel not in source.channels:
+                continue
+            samples = source.load_audio(offset=offset_aug, duration=duration_aug, force_opus_sampling_rate=rec.sampling_rate)
+            drop = [i for i, cid in enumerate(source.channels) if cid != cut.channel]
+            if drop:
+                samples = np.delete(samples, drop, axis=0)
+            per_source.append(samples)
+        audio = rec._stack_audio_channels(per_source)
+        return np.ascontiguousarray(audio.reshape(-1), dtype=np.float32)
+
+    def _read_one(cut, gpu_speed: bool, suppress_errors: bool) -> Optional[Tuple[torch.Tensor, float, int]]:
+        """(samples, factor still to be applied, samples the cut must end up with) or None when the read failed and errors are suppressed."""
+        with suppress_audio_loading_errors(enabled=suppress_errors):
+            factor = deferred_speed_factor(cut) if gpu_speed else None
+            if factor is not None and factor != 1.0:
+                raw = read_unperturbed(cut, factor)
+                want = compute_num_samples(cut.duration, cut.sampling_rate)
+                src, dst = round(cut.sampling_rate * factor), cut.sampling_rate
+                g = gcd(src, dst)
+                got = int(np.ceil(np.float32((dst // g) * len(raw) / (src // g))))  # resample.py:309
+                if got >= want:  # the usual case: equal, or a sample or two to truncate (assert_and_maybe_fix_num_samples, recording.py:1032-1070)
+                    return torch.from_numpy(raw), factor, want
+                # (the cut would need reflect-padding: the reference's own path)
+            audio = cut.load_audio()
+            if audio.shape[0] == 1:
+                audio = audio.squeeze(0)  # collapse channel dim if mono (collation.py:674-675)
+            return torch.from_numpy(audio), 1.0, int(audio.shape[-1])
+        return None
+
+    def _perturb_in_arena(arena, offsets, lengths, factors, sampling_rate, tail_start):
+        """(indirection for the CPU stand-in of the tests)"""
+        from .augmentation import perturb_speed_in_arena
+
+        return perturb_speed_in_arena(arena, offsets, lengths, factors, sampling_rate, tail_start)
 
     class HipOnTheFlyFeatures(OnTheFlyFeatures):
-        """Same constructor as ``OnTheFlyFeatures`` plus ``return_device``: ``None`` keeps the padded feature
-        tensor on the extractor's GPU (ready for the training step), ``"cpu"`` hands back a host tensor like the
-        reference does."""
+        """Same constructor as ``OnTheFlyFeatures`` plus ``return_device`` (``None`` keeps the padded feature tensor on the
+        extractor's GPU, ready for the training step; ``"cpu"`` hands back a host tensor like the reference does) and
+        ``gpu_speed_perturb`` (see the module docstring)."""
 
-        def __init__(self, extractor, *args, return_device: Optional[Union[str, torch.device]] = None, **kwargs) -> None:
+        def __init__(self, extractor, *args, return_device: Optional[Union[str, torch.device]] = None, gpu_speed_perturb: bool = True,
+                     **kwargs) -> None:
             if not hasattr(extractor, "extract_collated"):
                 raise TypeError("HipOnTheFlyFeatures needs a Hip* extractor (with extract_collated)")
             super().__init__(extractor, *args, **kwargs)
             self.return_device = return_device
+            self.gpu_speed_perturb = gpu_speed_perturb
+
+        def _read(self, cuts, pool, recording_field):
+            """read_audio_from_cuts (lhotse/dataset/collation.py:541-600) with the Speed of eligible cuts left for the device."""
+            if recording_field is not None or not self.gpu_speed_perturb or not any(deferred_speed_factor(c) not in (None, 1.0) for c in cuts):
+                audios, ok = read_audio_from_cuts(cuts, executor=pool, suppress_errors=self.fault_tolerant, recording_field=recording_field)
+                return audios, [1.0] * len(audios), [int(a.shape[-1]) for a in audios], ok
+            from functools import partial
+
+            from lhotse import CutSet
+
+            cuts = list(cuts)
+            map_fn = map if pool is None else pool.map
+            audios, factors, wants, ok = [], [], [], []
+            for cut, res in zip(cuts, map_fn(partial(_read_one, gpu_speed=True, suppress_errors=self.fault_tolerant), cuts)):
+                if res is None:
+                    continue
+                audios.append(res[0]), factors.append(res[1]), wants.append(res[2]), ok.append(cut)
+            return audios, factors, wants, CutSet.from_cuts(ok)
 
         def __call__(self, cuts, recording_field: Optional[str] = None):
-            """Only the middle step differs from the parent: ``extract_batch`` + ``collate_matrices`` become ONE fused launch
-            (``extract_collated``).  The parent offers no hook between reading the audio and collating the features, so the two
-            ends of its pipeline are invoked here through the same public helpers it uses."""
+            """Only the middle of the parent's pipeline differs: ``extract_batch`` + ``collate_matrices`` become ONE fused launch, and
+            pending speed factors are applied to the packed batch on the device in front of it.  The parent offers no hook between
+            reading the audio and collating the features, so the two ends of its pipeline are invoked here through the same public
+            helpers it uses."""
             pool = _get_executor(self.num_workers, executor_type=self._executor_type)
-            audios, cuts = read_audio_from_cuts(cuts, executor=pool, suppress_errors=self.fault_tolerant, recording_field=recording_field)
+            audios, factors, wants, cuts = self._read(cuts, pool, recording_field)
             for transform in self.wave_transforms:
+                if any(f != 1.0 for f in factors):
+                    raise ValueError("wave_transforms run on the loaded samples, before the device applies the pending speed factors: "
+                                     "use gpu_speed_perturb=False together with wave_transforms")
                 audios = [transform(a) for a in audios]
             rates = {c.sampling_rate for c in cuts}
             assert len(rates) == 1, f"one launch per batch needs a single sampling rate, got {sorted(rates)}"
-            feats, feat_lens = self.extractor.extract_collated(audios, sampling_rate=rates.pop(), padding_value=LOG_EPSILON)
+            sr = rates.pop()
+            perturbed = None
+            if any(f != 1.0 for f in factors):
+                feats, feat_lens, perturbed = self._perturb_and_extract(audios, factors, wants, sr)
+            else:
+                feats, feat_lens = self.extractor.extract_collated(audios, sampling_rate=sr, padding_value=LOG_EPSILON)
             result = [feats if self.return_device is None else feats.to(self.return_device), feat_lens]
             if self.return_audio:  # (B, Tmax) zero-padded samples + their lengths, as the parent returns them
-                flat = [a.reshape(-1) for a in audios]
+                flat = [a.reshape(-1) for a in (perturbed if perturbed is not None else audios)]
                 result += [collate_vectors(flat, padding_value=0), torch.tensor([len(a) for a in flat], dtype=torch.int64)]
             if self.fault_tolerant:  # the cuts that survived audio loading
                 result.append(cuts)
             return tuple(result)
+
+        def _perturb_and_extract(self, audios: List[torch.Tensor], factors: List[float], wants: List[int], sr: int):
+            """Pack the (partly unperturbed) batch, resample the cuts with a pending factor into the tail of the same buffer, extract."""
+            from .augmentation import perturbed_tail_floats
+            from .extractors import _as_1d_float
+
+            ex = self.extractor
+            ex._check_sr(sr)
+            items = [_as_1d_float(a.squeeze() if a.ndim > 1 else a, "HipOnTheFlyFeatures") for a in audios]
+            with torch.no_grad():
+                packed, offs, lens = ex._pack(items)
+                front = int(packed.numel())
+                arena = torch.empty(((front + 3) & ~3) + perturbed_tail_floats(lens, factors, sr), dtype=torch.float32, device=packed.device)
+                arena[:front].copy_(packed, non_blocking=True)
+                po, pl = _perturb_in_arena(arena, offs, lens, factors, sr, front)
+                pl = np.minimum(pl, np.asarray(wants, dtype=np.int64))  # a sample or two to truncate (recording.py:1058-1060)
+                zero_pad = getattr(ex.config, "edge_rule", "reflect") == "batch_zero_pad"  # as extract_collated
+                padded = np.full(len(pl), int(pl.max()), dtype=np.int64) if zero_pad else None
+                feats, frames = ex.plan.run_collated(arena, po, pl, padded, float(LOG_EPSILON))
+            perturbed = None
+            if self.return_audio:
+                perturbed = [arena[int(o) : int(o) + int(n)].cpu() for o, n in zip(po, pl)]
+            return feats, torch.from_numpy(np.asarray(frames, dtype=np.int64)), perturbed
 
 else:
 

@@ -455,3 +455,53 @@ def test_layer_forward_equals_the_reference_layer(lhotse_mod, cpu_device, ours, 
         layer(x.clone().requires_grad_(True))
     with pytest.raises(TypeError):
         layer(x.double())
+
+
+def test_on_the_fly_features_with_speed_perturbed_cuts(cutset, cpu_device, monkeypatch):
+    """PerturbSpeed-ed cuts through HipOnTheFlyFeatures: the Speed transform of eligible cuts is applied to the packed batch (on the
+    device; here: an oracle-backed stand-in of the resampler) instead of inside Recording.load_audio -- same features, same lengths,
+    same padded audio as the reference strategy over lhotse's own CPU Speed (lhotse/audio/recording.py:431-490)."""
+    import lhotse_amd as LA
+    import lhotse_amd.input_strategies as IS
+    from lhotse import CutSet
+    from lhotse.dataset import OnTheFlyFeatures
+    from lhotse.features import Fbank
+    from lhotse.utils import LOG_EPSILON
+    from oracle import resample_ref as R
+
+    def cpu_perturb(arena, offsets, lengths, factors, sampling_rate, tail_start):  # perturb_speed_in_arena on the host
+        offsets, lengths = np.asarray(offsets, dtype=np.int64).copy(), np.asarray(lengths, dtype=np.int64).copy()
+        tail = (int(tail_start) + 3) & ~3
+        for i, f in enumerate(factors):
+            if f == 1.0:
+                continue
+            y = R.speed(arena[int(offsets[i]) : int(offsets[i]) + int(lengths[i])].numpy(), sampling_rate, float(f))
+            arena[tail : tail + len(y)] = torch.from_numpy(y)
+            offsets[i], lengths[i] = tail, len(y)
+            tail = (tail + len(y) + 3) & ~3
+        return offsets, lengths
+
+    monkeypatch.setattr(IS, "_perturb_in_arena", cpu_perturb)
+    calls = {"raw": 0}
+    real_read = IS.read_unperturbed
+    monkeypatch.setattr(IS, "read_unperturbed", lambda cut, f: (calls.__setitem__("raw", calls["raw"] + 1), real_read(cut, f))[1])
+
+    mixed = CutSet.from_cuts(list(cutset.perturb_speed(1.1)) + list(cutset) + list(cutset.perturb_speed(0.9))
+                             + [c.truncate(offset=0.13, duration=0.41) for c in cutset.perturb_speed(0.9)][:2])
+    ref_f, ref_l, ref_a, ref_al = OnTheFlyFeatures(Fbank(), return_audio=True)(mixed)
+    f, l, a, al = LA.HipOnTheFlyFeatures(LA.HipFbank(LA.HipFbankConfig(edge_rule="batch_zero_pad")), return_audio=True, num_workers=2)(mixed)
+    assert calls["raw"] == 12  # every speed-perturbed cut was read WITHOUT its transform
+    assert torch.equal(l, ref_l) and torch.equal(al, ref_al) and f.shape == ref_f.shape and a.shape == ref_a.shape
+    assert torch.allclose(a, ref_a, atol=1e-5)  # the resampler's summation order only
+    assert torch.allclose(f, ref_f, atol=5e-3)
+    for i, n in enumerate(l.tolist()):
+        assert torch.all(f[i, n:] == LOG_EPSILON)
+    # switched off, or with wave transforms, the reference's own loading path is taken
+    f2, l2 = LA.HipOnTheFlyFeatures(LA.HipFbank(LA.HipFbankConfig(edge_rule="batch_zero_pad")), gpu_speed_perturb=False)(mixed)
+    assert calls["raw"] == 12 and torch.equal(l2, ref_l) and torch.allclose(f2, ref_f, atol=2e-3)
+    with pytest.raises(ValueError, match="gpu_speed_perturb=False"):
+        LA.HipOnTheFlyFeatures(LA.HipFbank(), wave_transforms=[lambda x: x])(mixed)
+    # cuts whose recording carries anything but exactly one Speed are not touched
+    assert IS.deferred_speed_factor(list(cutset)[0]) is None
+    assert IS.deferred_speed_factor(list(cutset.perturb_speed(1.1).perturb_volume(2.0))[0]) is None
+    assert IS.deferred_speed_factor(list(cutset.perturb_speed(1.1))[0]) == 1.1
