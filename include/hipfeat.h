@@ -197,6 +197,12 @@ HIPFEAT_API hipfeat_status hipfeat_extract_collated(const hipfeat_plan* plan, co
 /* int16 PCM -> float32 in [-1, 1): x / 32768, exactly what the audio backends hand to the reference
  * (so features are bit-identical to the float32 path); lets the host send half the bytes over PCIe. */
 HIPFEAT_API hipfeat_status hipfeat_pcm16_to_float(const int16_t* d_pcm, float* d_wave, int64_t num_samples, void* stream);
+/* float32 -> IEEE binary16 (round to nearest even) on the device, in front of the device -> host copy of a feature batch that is going to
+ * be STORED in half precision: the reference's default feature storage is lossy as well (lilcom, lhotse/features/io.py:981-1061,
+ * features/compression.py:18-37: the fixture it ships is exact to 2^-6); binary16 keeps log-domain features (|x| < 32) to 2^-6 ... 2^-7
+ * absolute and halves both the PCIe traffic and the file.  lilcom's own bit stream is third-party and not reproduced.  No plan: launches
+ * on the calling thread's current device. */
+HIPFEAT_API hipfeat_status hipfeat_float_to_half(const float* d_in, uint16_t* d_out, int64_t n, void* stream);
 
 /* ---- "next" row: post-feature transforms on the collated (B, T, F) batch ------- */
 /* GlobalMVN.forward: (x - means) / stds, and .inverse: x * stds + means, over `rows` rows of `feature_dim` floats

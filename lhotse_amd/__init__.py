@@ -36,7 +36,7 @@ from .signal_transforms import HipGlobalMVN, HipSpecAugment  # noqa: F401,E402
 
 from .layers import HipWav2LogFilterBank, HipWav2LogSpec, HipWav2MFCC, HipWav2Spec  # noqa: F401,E402
 
-from .storage import HipArchiveReader, HipArchiveWriter, compute_and_store_features_batch  # noqa: F401,E402
+from .storage import HipArchiveF16Writer, HipArchiveReader, HipArchiveWriter, compute_and_store_features_batch  # noqa: F401,E402
 
 from .sharding import compute_and_store_features_sharded  # noqa: F401,E402
 
@@ -44,6 +44,7 @@ __all__ = [
     "compute_and_store_features_sharded",
     "compute_and_store_features_batch",
     "HipArchiveWriter",
+    "HipArchiveF16Writer",
     "HipArchiveReader",
     "HipWhisperFbank",
     "HipLibrosaFbank",

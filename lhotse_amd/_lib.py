@@ -54,6 +54,7 @@ _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
          "int64_t*", "void*"],
     ),
     "hipfeat_pcm16_to_float": ("int", ["const int16_t*", "float*", "int64_t", "void*"]),
+    "hipfeat_float_to_half": ("int", ["const float*", "uint16_t*", "int64_t", "void*"]),
     "hipfeat_global_mvn": ("int", ["const float*", "float*", "const float*", "const float*", "int64_t", "int64_t", "int", "void*"]),
     "hipfeat_specaug": (
         "int",

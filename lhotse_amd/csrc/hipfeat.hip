@@ -1877,6 +1877,38 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_pcm16_to_float(const int16_t* d_pc
   return HIPFEAT_OK;
 }
 
+__global__ __launch_bounds__(256) void float_to_half_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n) {
+  // 8 values per lane per step (two 16-byte loads, one 16-byte store) when both buffers are 16-byte aligned; v_cvt_pkrtz would round
+  // towards zero, so the conversion is the scalar round-to-nearest-even one
+  const int64_t n8 = n >> 3;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(in) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  auto cvt = [](float x) -> unsigned { return (unsigned)__builtin_bit_cast(unsigned short, (_Float16)x); };
+  if (aligned) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+      const float4 a = reinterpret_cast<const float4*>(in)[2 * i], b = reinterpret_cast<const float4*>(in)[2 * i + 1];
+      uint4 o;
+      o.x = cvt(a.x) | (cvt(a.y) << 16);
+      o.y = cvt(a.z) | (cvt(a.w) << 16);
+      o.z = cvt(b.x) | (cvt(b.y) << 16);
+      o.w = cvt(b.z) | (cvt(b.w) << 16);
+      reinterpret_cast<uint4*>(out)[i] = o;
+    }
+    for (int64_t i = (n8 << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (uint16_t)cvt(in[i]);
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (uint16_t)cvt(in[i]);
+  }
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_float_to_half(const float* d_in, uint16_t* d_out, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!d_in || !d_out))) return fail(HIPFEAT_ERR_INVALID, "bad float_to_half arguments");
+  if (n == 0) return HIPFEAT_OK;
+  const int64_t blocks = std::min<int64_t>((n / 8 + 255) / 256 + 1, 256 * 32);
+  hipLaunchKernelGGL(float_to_half_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "float_to_half launch failed: %s", hipGetErrorName(e));
+  return HIPFEAT_OK;
+}
+
 // transient layout: descriptors staged through a pinned ring slot so the call stays asynchronous
 static hipfeat_status extract_transient(const hipfeat_plan* plan, const float* d_wave, const int64_t* h_wave_offsets,
                                         const int64_t* h_num_samples, const int64_t* h_padded_len, int64_t batch, float* d_out,

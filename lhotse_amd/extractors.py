@@ -464,15 +464,21 @@ class _HostPipeline:
             bounds.append((a, len(nbytes)))
         return bounds
 
-    def run(self, plan, bounds: Sequence[Tuple[int, int]], frames: np.ndarray, upload) -> torch.Tensor:
-        """`upload(a, b)` (called with s_in current) puts items a..b-1 on the device and returns what `plan.run` needs for them."""
+    def run(self, plan, bounds: Sequence[Tuple[int, int]], frames: np.ndarray, upload, half: bool = False) -> torch.Tensor:
+        """`upload(a, b)` (called with s_in current) puts items a..b-1 on the device and returns what `plan.run` needs for them.
+        `half`: the features are converted to binary16 on the device (hipfeat_float_to_half) and come back as a float16 tensor -- for
+        storage backends that keep half precision; half the download."""
         rows = np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
-        host = torch.empty((int(rows[-1]), plan.feature_dim), dtype=torch.float32, pin_memory=True)
+        host = torch.empty((int(rows[-1]), plan.feature_dim), dtype=torch.float16 if half else torch.float32, pin_memory=True)
         with self.lock, torch.cuda.device(self.device):
             for a, b in bounds:
                 with torch.cuda.stream(self.s_in):
                     wave, offs, lens, padded = upload(a, b)
                     out, got = plan.run(wave, offs, lens, padded)
+                    if half:
+                        out16 = torch.empty(out.shape, dtype=torch.float16, device=out.device)
+                        plan.lib.check("hipfeat_float_to_half", out.data_ptr(), out16.data_ptr(), out.numel(), int(self.s_in.cuda_stream))
+                        out = out16
                     done = torch.cuda.Event()
                     done.record(self.s_in)
                 assert np.array_equal(got, frames[a:b]), "frame counts of the chunk differ from the batch plan"
@@ -641,21 +647,23 @@ class _HipExtractor(FeatureExtractor):
                     pipe = self.__dict__["_pipeline"] = _HostPipeline(self.plan.device)
         return pipe
 
-    def _host_items_to_host(self, items: Sequence[ArrayLike], padded_len: Optional[int]) -> Tuple[torch.Tensor, np.ndarray]:
-        """Host waveforms in, packed host feature matrix out, through the chunked H2D / kernel / D2H pipeline."""
+    def _host_items_to_host(self, items: Sequence[ArrayLike], padded_len: Optional[int], half: bool = False) -> Tuple[torch.Tensor, np.ndarray]:
+        """Host waveforms in, packed host feature matrix out (float32, or float16 converted on the device with `half`), through the
+        chunked H2D / kernel / D2H pipeline."""
         plan = self.plan
         lens = np.array([int(x.shape[0]) for x in items], dtype=np.int64)
         padded = None if padded_len is None else np.full(len(items), padded_len, dtype=np.int64)
         frames = plan.frame_counts(lens, padded)
         if int(frames.min(initial=1)) <= 0:  # let the library word the error (and raise it) as for a single launch
-            return self._extract_items_host_fallback(items, padded_len)
+            host, frames = self._extract_items_host_fallback(items, padded_len)
+            return (host.to(torch.float16) if half else host), frames
         bounds = _HostPipeline.chunk_bounds(lens * (2 if _is_pcm16(items[0]) else 4))
 
         def upload(a, b):
             wave, offs, ln = self._pack(items[a:b])
             return wave, offs, ln, None if padded is None else padded[a:b]
 
-        return self._pipe().run(plan, bounds, frames, upload), frames
+        return self._pipe().run(plan, bounds, frames, upload, half=half), frames
 
     def _extract_items_host_fallback(self, items, padded_len):
         packed, frames = self._extract_items(items, padded_len)

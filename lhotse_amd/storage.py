@@ -50,15 +50,17 @@ def _archive_path(storage_path) -> Path:
     return p if p.suffix == ARCHIVE_SUFFIX else p.with_suffix(p.suffix + ARCHIVE_SUFFIX) if p.suffix else p.with_suffix(ARCHIVE_SUFFIX)
 
 
-def _parse_key(key: str) -> Tuple[int, int, int]:
-    off, rows, cols = key.split(":")
-    return int(off), int(rows), int(cols)
+def _parse_key(key: str) -> Tuple[int, int, int, str]:
+    """``"<byte offset>:<rows>:<cols>"`` (float32 rows) or ``"<byte offset>:<rows>:<cols>:f16"`` (binary16 rows)."""
+    parts = key.split(":")
+    return int(parts[0]), int(parts[1]), int(parts[2]), ("<f2" if len(parts) > 3 and parts[3] == "f16" else "<f4")
 
 
 class _ArchiveWriterImpl:
-    """Append-only flat file of float32 rows; keys are ``"<byte offset>:<rows>:<cols>"``."""
+    """Append-only flat file of float32 (or, ``np_dtype = "<f2"``, binary16) rows; keys are ``"<byte offset>:<rows>:<cols>[:f16]"``."""
 
     name = "hip_archive"
+    np_dtype = "<f4"
 
     def __init__(self, storage_path, mode: str = "w", *args, **kwargs):
         assert mode in ("w", "a"), mode
@@ -73,14 +75,16 @@ class _ArchiveWriterImpl:
         return str(self._path)
 
     def write(self, key: str, value: np.ndarray) -> str:
-        value = np.ascontiguousarray(value, dtype="<f4")
+        value = np.ascontiguousarray(value)
         assert value.ndim == 2, value.shape
         return self.write_packed(value, [value.shape[0]])[0]
 
     def write_packed(self, matrix: np.ndarray, frames: Sequence[int]) -> List[str]:
-        """Append the packed ``(sum(frames), F)`` matrix of a batch with ONE write; returns one key per item."""
-        matrix = np.ascontiguousarray(matrix, dtype="<f4")
+        """Append the packed ``(sum(frames), F)`` matrix of a batch with ONE write; returns one key per item.  A matrix that already
+        has the archive's dtype (the driver converts to binary16 on the device) is written as it is."""
+        matrix = np.ascontiguousarray(matrix, dtype=self.np_dtype)
         cols = int(matrix.shape[1])
+        item, tag = matrix.dtype.itemsize, (":f16" if matrix.dtype.itemsize == 2 else "")
         assert int(sum(frames)) == matrix.shape[0], (sum(frames), matrix.shape)
         with self._lock:
             base = self._offset
@@ -88,8 +92,8 @@ class _ArchiveWriterImpl:
             self._offset += matrix.nbytes
         keys, off = [], base
         for t in frames:
-            keys.append(f"{off}:{int(t)}:{cols}")
-            off += int(t) * cols * 4
+            keys.append(f"{off}:{int(t)}:{cols}{tag}")
+            off += int(t) * cols * item
         return keys
 
     def flush(self):
@@ -116,19 +120,19 @@ class _ArchiveReaderImpl:
         self._lock = threading.Lock()
 
     def read(self, key: str, left_offset_frames: int = 0, right_offset_frames: Optional[int] = None) -> np.ndarray:
-        off, rows, cols = _parse_key(key)
+        off, rows, cols, dt = _parse_key(key)
         lo = max(0, int(left_offset_frames))
         hi = rows if right_offset_frames is None else min(rows, int(right_offset_frames))
         n = max(0, hi - lo)
-        out = np.empty((n, cols), dtype="<f4")
+        out = np.empty((n, cols), dtype=dt)
         if n:
             with self._lock:
                 if self._fd is None:
                     self._fd = os.open(self._path, os.O_RDONLY)
-            got = os.preadv(self._fd, [memoryview(out).cast("B")], off + lo * cols * 4)
+            got = os.preadv(self._fd, [memoryview(out).cast("B")], off + lo * cols * out.dtype.itemsize)
             if got != out.nbytes:
                 raise IOError(f"{self._path}: short read for key {key!r} ({got} of {out.nbytes} bytes)")
-        return out
+        return out if dt == "<f4" else out.astype("<f4")  # lhotse's readers hand out float32
 
     def __del__(self):
         try:
@@ -153,6 +157,19 @@ if HAVE_LHOTSE:
 
         name = "hip_archive"
 
+    @register_writer
+    class HipArchiveF16Writer(_ArchiveWriterImpl, FeaturesWriter):
+        """``"hip_archive_f16"``: the same archive with binary16 rows -- half the file, and with the Hip* extractors half the
+        device -> host traffic (the batch driver converts on the device).  Lossy like the reference's default lilcom storage: log-domain
+        features (|x| < 32) keep 2^-6 ... 2^-7 absolute, the error of the lilcom fixture the reference ships."""
+
+        name = "hip_archive_f16"
+        np_dtype = "<f2"
+
+    @register_reader
+    class HipArchiveF16Reader(_ArchiveReaderImpl, FeaturesReader):
+        name = "hip_archive_f16"
+
 else:  # usable on their own (tests, tools) without lhotse
 
     class HipArchiveWriter(_ArchiveWriterImpl):
@@ -160,6 +177,12 @@ else:  # usable on their own (tests, tools) without lhotse
 
     class HipArchiveReader(_ArchiveReaderImpl):
         pass
+
+    class HipArchiveF16Writer(_ArchiveWriterImpl):
+        name = "hip_archive_f16"
+        np_dtype = "<f2"
+
+    HipArchiveF16Reader = HipArchiveReader
 
 
 # ---- manifest templates ---------------------------------------------------------------------------------------------------
@@ -263,8 +286,9 @@ def _mono_cut_dict(cut, feats: Dict, rec_cache: Dict[str, Tuple[object, Dict]]) 
     return d
 
 
-def _batch_features_on_host(extractor, waves, sampling_rate: int, lengths) -> Tuple[np.ndarray, List[int]]:
-    """Packed ``(sum T_b, F)`` host matrix + per-cut frame counts (one D2H transfer for the Hip* extractors)."""
+def _batch_features_on_host(extractor, waves, sampling_rate: int, lengths, half: bool = False) -> Tuple[np.ndarray, List[int]]:
+    """Packed ``(sum T_b, F)`` host matrix + per-cut frame counts (one D2H transfer for the Hip* extractors).  `half`: binary16,
+    converted on the device in front of the transfer when the extractor's pipeline is available (on the host otherwise)."""
     if lengths is None and hasattr(extractor, "_extract_items") and hasattr(extractor, "_to_host"):
         from .extractors import _as_1d_float
 
@@ -275,7 +299,7 @@ def _batch_features_on_host(extractor, waves, sampling_rate: int, lengths) -> Tu
         with torch.no_grad():
             on_host = all(not isinstance(x, torch.Tensor) or x.device.type == "cpu" for x in items)
             if on_host and hasattr(extractor, "_host_items_to_host") and extractor.plan.device.type == "cuda":
-                host, frames = extractor._host_items_to_host(items, pmax)  # chunked H2D / kernel / D2H pipeline, one pinned result
+                host, frames = extractor._host_items_to_host(items, pmax, half=half)  # chunked H2D / kernel / D2H pipeline, one pinned result
             else:
                 packed, frames = extractor._extract_items(items, pmax)
                 host = extractor._to_host(packed)
@@ -379,7 +403,7 @@ def compute_and_store_features_batch(
             assert all(c.sampling_rate == sr for c in batch_cuts)
             if augment_fn is not None:
                 waves = [augment_fn(w, c.sampling_rate) for c, w in zip(batch_cuts, waves)]
-            host, frames = _batch_features_on_host(extractor, waves, sr, lens)
+            host, frames = _batch_features_on_host(extractor, waves, sr, lens, half=getattr(writer, "np_dtype", "<f4") == "<f2")
             if template is None:
                 template = {"type": extractor.name, "num_features": int(host.shape[1]), "frame_shift": frame_shift, "sampling_rate": sr,
                             "storage_type": writer.name, "storage_path": str(writer.storage_path)}

@@ -122,3 +122,27 @@ def test_too_short_item_raises_value_error_from_inside_the_pipeline(many_chunks)
     with pytest.raises(ValueError):
         ex.extract_batch(waves, 16000)
     assert len(ex.extract_batch(_waves(7, 6), 16000)) == 6  # the extractor is usable afterwards
+
+
+def test_float_to_half_on_the_device_and_the_half_pipeline(many_chunks):
+    """hipfeat_float_to_half = IEEE round-to-nearest-even (numpy's astype(float16)), and the pipeline's `half` mode hands back exactly the
+    binary16 rounding of what the float32 mode hands back."""
+    from lhotse_amd import _lib
+
+    lib = _lib.load()
+    rs = np.random.RandomState(0)
+    x = np.concatenate([rs.randn(100003).astype(np.float32) * 10, np.float32([0.0, -0.0, 65504.0, 65520.0, 1e-8, 6e-5, -23.025851, 1e9, -1e9]),
+                        (np.arange(4096, dtype=np.float32) + 0.5) / 1024.0])  # ties, subnormals, overflow to inf
+    for off in (0, 1, 3):  # aligned and unaligned starts
+        d = torch.from_numpy(x).cuda()[off:]
+        o = torch.empty(d.numel(), dtype=torch.float16, device="cuda")
+        lib.check("hipfeat_float_to_half", d.data_ptr(), o.data_ptr(), d.numel(), int(torch.cuda.current_stream().cuda_stream))
+        with np.errstate(over="ignore"):
+            want = x[off:].astype(np.float16)
+        assert np.array_equal(o.cpu().numpy().view(np.uint16), want.view(np.uint16))
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cuda:0"))
+    waves = _waves(9, 21)
+    f32, frames = ex._host_items_to_host(waves, None)
+    f16, frames16 = ex._host_items_to_host(waves, None, half=True)
+    assert f16.dtype == torch.float16 and np.array_equal(frames, frames16)
+    assert torch.equal(f16, f32.to(torch.float16))

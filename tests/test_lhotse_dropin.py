@@ -411,6 +411,29 @@ def test_archive_backend_round_trip_without_lhotse_objects(tmp_path):
     assert k4.startswith(str(sum(m.nbytes for m in mats)) + ":") and np.array_equal(LA.HipArchiveReader(path).read(k4), mats[0] * 2)
 
 
+def test_half_precision_archive(tmp_path, cutset, cpu_device):
+    """`hip_archive_f16`: binary16 rows (the reference's default storage, lilcom, is lossy too: its shipped fixture is exact to 2^-6);
+    written through the same driver, read back as float32 by lhotse's own `Features.load` -- whole and partial reads."""
+    import lhotse_amd as LA
+    from lhotse.features.io import get_reader, get_writer
+
+    assert get_writer("hip_archive_f16") is LA.HipArchiveF16Writer and get_reader("hip_archive_f16").name == "hip_archive_f16"
+    ex = LA.HipFbank()
+    full = list(LA.compute_and_store_features_batch(cutset, extractor=ex, storage_path=tmp_path / "f32", manifest_path=tmp_path / "f32.jsonl.gz",
+                                                    batch_duration=3.0, num_workers=0))
+    half = list(LA.compute_and_store_features_batch(cutset, extractor=ex, storage_path=tmp_path / "f16", manifest_path=tmp_path / "f16.jsonl.gz",
+                                                    batch_duration=3.0, num_workers=0, storage_type=LA.HipArchiveF16Writer))
+    assert [c.id for c in half] == [c.id for c in full]
+    for a, b in zip(half, full):
+        assert a.features.storage_type == "hip_archive_f16" and a.features.storage_key.endswith(":f16")
+        x, y = a.load_features(), b.load_features()
+        assert x.dtype == np.float32 and x.shape == y.shape
+        assert np.array_equal(x, y.astype(np.float16).astype(np.float32))  # exactly the binary16 rounding of the float32 features
+        assert np.abs(x - y).max() <= 2.0 ** -6
+        assert np.array_equal(a.features.load(start=a.start + 0.2, duration=0.3), x[20:50])
+    assert os.path.getsize(half[0].features.storage_path) * 2 == os.path.getsize(full[0].features.storage_path)
+
+
 LAYER_PAIRS = [("HipWav2Spec", "Wav2Spec"), ("HipWav2LogSpec", "Wav2LogSpec"), ("HipWav2LogFilterBank", "Wav2LogFilterBank"), ("HipWav2MFCC", "Wav2MFCC")]
 
 
