@@ -183,6 +183,18 @@ __device__ __forceinline__ void mel4_store(float* o, int64_t stride, int nf, con
       if (i < nf) o[i * stride] = v[i];
   }
 }
+// the same with the row base wave-uniform and the column as a 32-bit lane offset: global_store_dword voffset, vdata, s[base:base+1]
+template <int ROWS>
+__device__ __forceinline__ void mel4_store_saddr(float* row0, unsigned col, int64_t stride, int nf, const float* v) {
+  const unsigned off = col * 4u;
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    if (i < nf) {  // nf is wave-uniform
+      const float* base = row0 + i * stride;
+      asm volatile("global_store_dword %0, %1, %2" : : "v"(off), "v"(v[i]), "s"(base) : "memory");
+    }
+  }
+}
 
 // natural log of a normal positive float: v_log_f32 (log2, 1 ulp) times ln 2.  The argument is
 // >= mel_floor (1.19e-7), so the denormal path of the library logf is never needed.

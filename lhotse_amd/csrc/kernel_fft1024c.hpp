@@ -349,7 +349,7 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
         mel4_reduce_floor(acc, m4, m8, p.mel_floor, val);  // fft_common.hpp: row_shr:4 / row_shr:8 multiply-adds, floor
 #pragma unroll
         for (int i = 0; i < 4; ++i) val[i] = __builtin_amdgcn_logf(val[i]) * log_scale;
-        if (col < p.M) mel4_store<4>(orow + col, p.out_stride, nf, val);
+        if (col < p.M) mel4_store_saddr<4>(orow, (unsigned)col, p.out_stride, nf, val);
       }
     }
     HFC_T(6);  // mel phase: operand reads, MFMAs, reduction, log, stores

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
         mel4_reduce_floor(acc, m4, m8, p.mel_floor, val);  // fft_common.hpp: row_shr:4 / row_shr:8 multiply-adds, floor
         val[0] = __builtin_amdgcn_logf(val[0]) * log_scale;
         val[1] = __builtin_amdgcn_logf(val[1]) * log_scale;
-        if (col < p.M) mel4_store<2>(orow + col, p.out_stride, nf, val);
+        if (col < p.M) mel4_store_saddr<2>(orow, (unsigned)col, p.out_stride, nf, val);
       }
     }
     HFC_T(6);  // mel phase: operand reads, MFMAs, reduction, log, stores

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * kDWaves, 4) void fft256c_kernel(const Fft512cP
 #pragma unroll
         for (int i = 0; i < 4; ++i) val[4 + i] = fast_log(v4[i]);
       }
-      if (col < p.M) mel4_store<8>(orow + col, p.out_stride, nf, val);
+      if (col < p.M) mel4_store_saddr<8>(orow, (unsigned)col, p.out_stride, nf, val);
     }
     // the next round's exchange writes follow this round's power-row reads in the wave's own LDS queue (in order)
   }

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
 #pragma unroll
           for (int i = 0; i < 4; ++i) lm[i] = val[s][i];
         } else if (col < p.M) {
-          mel4_store<4>(orow + col, p.out_stride, nf, val[s]);
+          mel4_store_saddr<4>(orow, (unsigned)col, p.out_stride, nf, val[s]);
         }
       }
     }
