@@ -121,6 +121,7 @@ struct hipfeat_plan {
   int fpb_unit = 0, c_rounds_max = 0;
   // fft1024 wave-autonomous fbank kernel (variant 8; shares d_c_shared / c_* with variant 7)
   int w_nsets = 0, w_steps[kWMaxSets] = {}, w_step0[kWMaxSets] = {};
+  int w_fixed = 0;  // fft1024c / fft2048c: instance with a compile-time mel schedule (fft1024c_fixed_id)
   // fft2048 wave-autonomous fbank kernel (variant 10; shares d_c_shared / c_* / w_* with variants 7 and 8)
   float* d_x_twp = nullptr;  // [32][32] v2 W_1024^(q k1)
   int x_waves = 0, x_tws_off = 0, x_tw32_off = 0;
@@ -587,9 +588,18 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
 // --------------------------------------------------------------------------------------
 // fft1024 wave-autonomous fbank kernel (kernel_fft1024c.hpp): 22.05 / 24 / 32 kHz Kaldi log-mel
 // --------------------------------------------------------------------------------------
-template <int NROWS>
+template <int NROWS, int S0 = 0, int S1 = 0, int S2 = 0>
 static const void* fft1024c_entry() {
-  return reinterpret_cast<const void*>(&fft1024c_kernel<NROWS>);
+  return reinterpret_cast<const void*>(&fft1024c_kernel<NROWS, S0, S1, S2>);
+}
+// instances with the mel schedule as compile-time constants (kernel_fft1024c.hpp): 1 = <20, 24,16,8> (24 kHz), 2 = <26, 24,16,8> (32 kHz),
+// 3 = <20, 24,24,8> (22.05 kHz); 0 = generic
+static int fft1024c_fixed_id(int nrows, int nsets, const int* steps) {
+  if (nsets != 3 || getenv("HIPFEAT_NO_FIXED_SCHEDULE")) return 0;
+  if (nrows == 20 && steps[0] == 24 && steps[1] == 16 && steps[2] == 8) return 1;
+  if (nrows == 26 && steps[0] == 24 && steps[1] == 16 && steps[2] == 8) return 2;
+  if (nrows == 20 && steps[0] == 24 && steps[1] == 24 && steps[2] == 8) return 3;
+  return 0;
 }
 
 static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, const float* h_mel) {
@@ -649,9 +659,14 @@ static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, con
   p->c_xs_floats = (3 * shift + 32 * nrows + 3) & ~3;
   const size_t lds = ((size_t)p->c_shared_floats + (size_t)kWWaves * (p->c_xs_floats + kWRegion)) * sizeof(float);
   if (lds > 160 * 1024 || (p->c_xs_floats >> 8) > 10) return HIPFEAT_OK;
-  const void* fn = nrows == 20 ? fft1024c_entry<20>() : (nrows == 26 ? fft1024c_entry<26>() : fft1024c_entry<32>());
+  const int fixed = fft1024c_fixed_id(nrows, sch.nsets, sch.steps);
+  const void* fn = fixed == 1 ? fft1024c_entry<20, 24, 16, 8>()
+                   : fixed == 2 ? fft1024c_entry<26, 24, 16, 8>()
+                   : fixed == 3 ? fft1024c_entry<20, 24, 24, 8>()
+                   : nrows == 20 ? fft1024c_entry<20>() : (nrows == 26 ? fft1024c_entry<26>() : fft1024c_entry<32>());
   hipError_t e = ensure_dynamic_lds(fn, lds);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft1024c) failed: %s", hipGetErrorName(e));
+  p->w_fixed = fixed;
   hipfeat_status st;
   if ((st = upload(&p->d_c_shared, img.data(), img.size())) != HIPFEAT_OK) return st;
   p->w_nsets = sch.nsets;
@@ -670,7 +685,7 @@ static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, con
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kWWaves, lds) == hipSuccess) p->blocks_per_cu = nb;
   char nm[128];
-  snprintf(nm, sizeof(nm), "fft1024c_kernel<%d> fbank lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, lds, p->blocks_per_cu, sch.nsets, total_steps);
+  snprintf(nm, sizeof(nm), "fft1024c_kernel<%d> fbank%s lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, fixed ? " fixed-schedule" : "", lds, p->blocks_per_cu, sch.nsets, total_steps);
   p->kernel_name = nm;
   p->variant = 8;
   return HIPFEAT_OK;
@@ -1014,9 +1029,9 @@ static hipfeat_status setup_whisper2(hipfeat_plan* p, const float* h_mel) {
 }
 
 // fft2048 wave-autonomous fbank kernel (kernel_fft2048c.hpp): 44.1 / 48 kHz Kaldi filterbanks, librosa-style log-mel with n_fft 2048
-template <int NROWS, bool ODD>
+template <int NROWS, bool ODD, int S0 = 0, int S1 = 0, int S2 = 0>
 static const void* fft2048c_entry() {
-  return reinterpret_cast<const void*>(&fft2048c_kernel<NROWS, ODD>);
+  return reinterpret_cast<const void*>(&fft2048c_kernel<NROWS, ODD, S0, S1, S2>);
 }
 
 static hipfeat_status setup_fft2048c(hipfeat_plan* p, const float* h_window, const float* h_mel) {
@@ -1084,8 +1099,13 @@ static hipfeat_status setup_fft2048c(hipfeat_plan* p, const float* h_window, con
   while (waves > 0 && lds_of(waves) > 160 * 1024) --waves;
   if (waves < 4) return HIPFEAT_OK;
   const size_t lds = lds_of(waves);
-  const void* fn = odd ? (nrows == 18 ? fft2048c_entry<18, true>() : fft2048c_entry<32, true>())
-                       : (nrows == 19 ? fft2048c_entry<19, false>() : fft2048c_entry<32, false>());
+  // instance with the mel schedule as compile-time constants (kernel_fft2048c.hpp): the 80-filter Kaldi default at 44.1 / 48 kHz
+  const bool fixed = sch.nsets == 3 && sch.steps[0] == 52 && sch.steps[1] == 28 && sch.steps[2] == 16 && sch.step0[1] == 52 && sch.step0[2] == 80 &&
+                     (odd ? nrows == 18 : nrows == 19) && !getenv("HIPFEAT_NO_FIXED_SCHEDULE");
+  const void* fn = fixed ? (odd ? fft2048c_entry<18, true, 52, 28, 16>() : fft2048c_entry<19, false, 52, 28, 16>())
+                   : odd ? (nrows == 18 ? fft2048c_entry<18, true>() : fft2048c_entry<32, true>())
+                         : (nrows == 19 ? fft2048c_entry<19, false>() : fft2048c_entry<32, false>());
+  p->w_fixed = fixed ? 1 : 0;
   hipError_t e = ensure_dynamic_lds(fn, lds);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft2048c) failed: %s", hipGetErrorName(e));
   std::vector<float> twp((size_t)32 * 32 * 2);
@@ -1116,7 +1136,7 @@ static hipfeat_status setup_fft2048c(hipfeat_plan* p, const float* h_window, con
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * waves, lds) == hipSuccess) p->blocks_per_cu = nb;
   char nm[160];
-  snprintf(nm, sizeof(nm), "fft2048c_kernel<%d,%d> fbank waves=%d lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, (int)odd, waves, lds, p->blocks_per_cu, sch.nsets, total_steps);
+  snprintf(nm, sizeof(nm), "fft2048c_kernel<%d,%d> fbank%s waves=%d lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, (int)odd, fixed ? " fixed-schedule" : "", waves, lds, p->blocks_per_cu, sch.nsets, total_steps);
   p->kernel_name = nm;
   p->variant = 10;
   return HIPFEAT_OK;
@@ -1645,10 +1665,12 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     const dim3 grid((unsigned)lay->total_blocks), block(64 * plan->x_waves);
     set_lds_poison(plan->fast_lds_bytes);
     if (plan->x_odd) {
-      if (plan->nrows == 18) hipLaunchKernelGGL((fft2048c_kernel<18, true>), grid, block, plan->fast_lds_bytes, stream, fp);
+      if (plan->w_fixed) hipLaunchKernelGGL((fft2048c_kernel<18, true, 52, 28, 16>), grid, block, plan->fast_lds_bytes, stream, fp);
+      else if (plan->nrows == 18) hipLaunchKernelGGL((fft2048c_kernel<18, true>), grid, block, plan->fast_lds_bytes, stream, fp);
       else hipLaunchKernelGGL((fft2048c_kernel<32, true>), grid, block, plan->fast_lds_bytes, stream, fp);
     } else {
-      if (plan->nrows == 19) hipLaunchKernelGGL((fft2048c_kernel<19, false>), grid, block, plan->fast_lds_bytes, stream, fp);
+      if (plan->w_fixed) hipLaunchKernelGGL((fft2048c_kernel<19, false, 52, 28, 16>), grid, block, plan->fast_lds_bytes, stream, fp);
+      else if (plan->nrows == 19) hipLaunchKernelGGL((fft2048c_kernel<19, false>), grid, block, plan->fast_lds_bytes, stream, fp);
       else hipLaunchKernelGGL((fft2048c_kernel<32, false>), grid, block, plan->fast_lds_bytes, stream, fp);
     }
     HIP_TRY(hipGetLastError());
@@ -1681,7 +1703,10 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(64 * kWWaves);
     set_lds_poison(plan->fast_lds_bytes);
-    if (plan->nrows == 20) hipLaunchKernelGGL(fft1024c_kernel<20>, grid, block, plan->fast_lds_bytes, stream, fp);
+    if (plan->w_fixed == 1) hipLaunchKernelGGL((fft1024c_kernel<20, 24, 16, 8>), grid, block, plan->fast_lds_bytes, stream, fp);
+    else if (plan->w_fixed == 2) hipLaunchKernelGGL((fft1024c_kernel<26, 24, 16, 8>), grid, block, plan->fast_lds_bytes, stream, fp);
+    else if (plan->w_fixed == 3) hipLaunchKernelGGL((fft1024c_kernel<20, 24, 24, 8>), grid, block, plan->fast_lds_bytes, stream, fp);
+    else if (plan->nrows == 20) hipLaunchKernelGGL(fft1024c_kernel<20>, grid, block, plan->fast_lds_bytes, stream, fp);
     else if (plan->nrows == 26) hipLaunchKernelGGL(fft1024c_kernel<26>, grid, block, plan->fast_lds_bytes, stream, fp);
     else hipLaunchKernelGGL(fft1024c_kernel<32>, grid, block, plan->fast_lds_bytes, stream, fp);
     HIP_TRY(hipGetLastError());

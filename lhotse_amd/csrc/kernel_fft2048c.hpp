@@ -68,8 +68,12 @@ __device__ __forceinline__ void half_fft32(const v2 (&x)[32], v2 sg, const v2* t
   fft16(u, out);
 }
 
-template <int NROWS, bool ODD>
+// S0 / S1 / S2 != 0: the step counts of a three-set mel schedule as compile-time constants (the 80-filter Kaldi default at 44.1 / 48 kHz:
+// 52, 28, 16), as in kernel_fft1024c.hpp; any other filterbank runs the generic <NROWS, ODD, 0, 0, 0>.
+template <int NROWS, bool ODD, int S0 = 0, int S1 = 0, int S2 = 0>
 __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2048cParams p) {
+  constexpr bool kFixed = S0 != 0;
+  constexpr int kFixSteps[4] = {S0, S1, S2, 0}, kFixStep0[4] = {0, S0, S0 + S1, S0 + S1 + S2};
   extern __shared__ __attribute__((aligned(16))) float smem[];
   HF_POISON_LDS(smem);
   const v2* cwin = reinterpret_cast<const v2*>(smem);                 // [NROWS][32]
@@ -348,17 +352,20 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
     float* orow = p.out + (cd.out_row + f0) * p.out_stride;
 #pragma unroll
     for (int s = 0; s < kXMaxSets; ++s) {
-      if (s < p.nsets) {  // uniform
+      if (kFixed ? s < 3 : s < p.nsets) {  // uniform
         const float* lt = ltab + s * 256 + 4 * lane_o;
         const int poff = __builtin_bit_cast(int, lt[0]);
         const int col = __builtin_bit_cast(int, lt[1]);
         const float m4 = lt[2], m8 = lt[3];
         const float* pa = myreg + poff;
-        const float* wb = wtab + p.step0[s] * 64 + 4 * lane_o;
+        const float* wb = wtab + (kFixed ? kFixStep0[s < 4 ? s : 3] : p.step0[s]) * 64 + 4 * lane_o;
         // opaque per round: otherwise hipcc evaluates every "chunk c4 exists" test once per kernel, runs out of SGPRs for the results
         // and fetches them back with v_readlane in front of every chunk
-        int nsteps = p.steps[s];
-        asm volatile("" : "+s"(nsteps));
+        int nsteps = kFixSteps[s < 4 ? s : 3];
+        if (!kFixed) {
+          nsteps = p.steps[s];
+          asm volatile("" : "+s"(nsteps));
+        }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int blk8 = 0; blk8 < kXMaxSteps / 32; ++blk8) {

@@ -1,0 +1,33 @@
+"""GPU: the instances of fft1024c / fft2048c that carry the mel schedule of the 80-filter Kaldi defaults as compile-time constants
+(kernel_fft1024c.hpp, kernel_fft2048c.hpp) against the generic instances of the same kernels (HIPFEAT_NO_FIXED_SCHEDULE=1): the same
+instructions on the same operands in the same order, so the outputs are bit-identical.  (Both are checked against the oracle of
+Wav2LogFilterBank, lhotse/features/kaldi/layers.py:565-578, by the golden and ragged-batch tests of their sampling rates.)"""
+import numpy as np
+import pytest
+import torch
+
+from _hip import make_hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("sr,kernel", [(22050, "fft1024c_kernel<20>"), (24000, "fft1024c_kernel<20>"), (32000, "fft1024c_kernel<26>"),
+                                       (44100, "fft2048c_kernel<18,1>"), (48000, "fft2048c_kernel<19,0>")])
+def test_fixed_schedule_instances_equal_the_generic_ones(sr, kernel, monkeypatch):
+    fixed = make_hip("fbank", {"sampling_rate": sr})
+    assert fixed.kernel_name.startswith(kernel) and "fixed-schedule" in fixed.kernel_name, fixed.kernel_name
+    monkeypatch.setenv("HIPFEAT_NO_FIXED_SCHEDULE", "1")
+    generic = make_hip("fbank", {"sampling_rate": sr})
+    assert generic.kernel_name.startswith(kernel) and "fixed-schedule" not in generic.kernel_name, generic.kernel_name  # (builds the plan)
+    monkeypatch.delenv("HIPFEAT_NO_FIXED_SCHEDULE")
+    rng = np.random.default_rng(sr)
+    waves = [torch.from_numpy((rng.standard_normal(n) * a).astype(np.float32)) for n, a in
+             ((int(0.9 * sr), 0.1), (3 * sr + 17, 0.3), (sr // 20 + 1, 1e-3), (7 * sr + 5, 0.05))]
+    for a, b in zip(fixed.extract_batch(waves, sr), generic.extract_batch(waves, sr)):
+        assert a.shape == b.shape and a.shape[1] == 80
+        assert torch.equal(a, b)
+
+
+def test_other_filterbanks_run_the_generic_instance():
+    ex = make_hip("fbank", {"sampling_rate": 24000, "num_filters": 64})
+    assert ex.kernel_name.startswith("fft1024c_kernel<20>") and "fixed-schedule" not in ex.kernel_name, ex.kernel_name
