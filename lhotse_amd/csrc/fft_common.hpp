@@ -186,10 +186,6 @@ __device__ __forceinline__ void mel4_store(float* o, int64_t stride, int nf, con
 // the same with the row base wave-uniform and the column as a 32-bit lane offset: global_store_dword voffset, vdata, s[base:base+1]
 template <int ROWS>
 __device__ __forceinline__ void mel4_store_saddr(float* row0, unsigned col, int64_t stride, int nf, const float* v) {
-#ifdef HF_NO_SADDR  // A/B switch of tools/variants.py
-  mel4_store<ROWS>(row0 + col, stride, nf, v);
-  return;
-#endif
   const unsigned off = col * 4u;
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
