@@ -85,13 +85,17 @@ class _Rendezvous:
     """The two barriers of the sharded driver (everybody has extracted / rank 0 has combined).  In order of preference: the caller's
     process group (RCCL or gloo); a gloo group created here from torchrun's MASTER_ADDR / MASTER_PORT (host-side only -- the barrier
     carries no data, so it does not need RCCL) and destroyed again; marker files next to the shards for ranks that were only given
-    RANK / WORLD_SIZE.  Marker names carry a run token shared by the ranks of one launch, so that the markers of an earlier run in the
-    same directory cannot satisfy this one."""
+    RANK / WORLD_SIZE.  Marker names carry a run token shared by the ranks of one launch (HIPFEAT_RUN_ID, else torchrun's run id, else
+    the parent process id), so that the markers of an earlier run in the same directory cannot satisfy this one; ranks started by hand
+    from ONE shell share its pid across runs and should set HIPFEAT_RUN_ID.  A rank that fails leaves a ``failed`` marker, so that the
+    others stop waiting at once instead of after the timeout."""
 
-    def __init__(self, marker_dir, rank: int, world: int, timeout: float):
+    def __init__(self, marker_dir, rank: int, world: int, timeout: float, device_index=None):
         self.dir, self.rank, self.world, self.timeout = marker_dir, rank, world, timeout
         self.dist = None
         self.owns_group = False
+        self.device_index = device_index
+        self.token = os.environ.get("HIPFEAT_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or f"ppid{os.getppid()}"
         if world == 1:
             return
         try:
@@ -107,30 +111,51 @@ class _Rendezvous:
                     self.dist, self.owns_group = dist, True
         except ImportError:  # pragma: no cover
             pass
-        self.token = os.environ.get("HIPFEAT_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or f"ppid{os.getppid()}"
+
+    def _marker(self, tag: str, rank: int):
+        from pathlib import Path
+
+        return Path(self.dir) / f".{tag}-{self.token}-{rank}"
 
     def barrier(self, tag: str) -> None:
         import time
-        from pathlib import Path
 
         if self.world == 1:
             return
         if self.dist is not None:
-            self.dist.barrier()
+            if self.dist.get_backend() == "nccl" and self.device_index is not None:
+                self.dist.barrier(device_ids=[self.device_index])  # RCCL must not guess this rank's GPU
+            else:
+                self.dist.barrier()
             return
-        d = Path(self.dir)
-        (d / f".{tag}-{self.token}-{self.rank}").write_text("done")
+        self._marker(tag, self.rank).write_text("done")
         deadline = time.time() + self.timeout
-        while not all((d / f".{tag}-{self.token}-{r}").exists() for r in range(self.world)):
+        while not all(self._marker(tag, r).exists() for r in range(self.world)):
+            failed = [r for r in range(self.world) if self._marker("failed", r).exists()]
+            if failed:
+                raise RuntimeError(f"sharded extraction: ranks {failed} failed before '{tag}' (see their own tracebacks)")
             if time.time() > deadline:
-                missing = [r for r in range(self.world) if not (d / f".{tag}-{self.token}-{r}").exists()]
+                missing = [r for r in range(self.world) if not self._marker(tag, r).exists()]
                 raise TimeoutError(f"sharded extraction: ranks {missing} did not reach '{tag}' within {self.timeout:.0f} s")
             time.sleep(0.05)
+
+    def failed(self) -> None:
+        """Called on the way out of a failing rank (marker-file mode: process groups have their own timeouts)."""
+        if self.world > 1 and self.dist is None:
+            try:
+                self._marker("failed", self.rank).write_text("failed")
+            except OSError:  # pragma: no cover
+                pass
 
     def close(self) -> None:
         if self.owns_group:
             self.dist.destroy_process_group()
             self.owns_group = False
+        if self.world > 1 and self.dist is None:  # this rank's markers of the first barrier: everybody is past it once "combined" was reached
+            try:
+                self._marker("extracted", self.rank).unlink()
+            except OSError:
+                pass
 
 
 def shard_paths(storage_path, manifest_path, rank: int):
@@ -212,16 +237,19 @@ def compute_and_store_features_sharded(
     manifest_path.parent.mkdir(parents=True, exist_ok=True)
     # one GPU per rank: a bare "cuda" device becomes this rank's GPU (LOCAL_RANK as torchrun sets it)
     dev = str(getattr(extractor.config, "device", "cuda"))
+    device_index = None
     if dev == "cuda" and world > 1:
-        index = int(os.environ.get("LOCAL_RANK", rank))
+        device_index = int(os.environ.get("LOCAL_RANK", rank))
         try:
             import torch
 
             if torch.cuda.is_available():  # a launcher may narrow the visible devices per rank
-                index %= torch.cuda.device_count()
+                device_index %= torch.cuda.device_count()
         except ImportError:  # pragma: no cover
             pass
-        extractor.to(f"cuda:{index}")
+        extractor.to(f"cuda:{device_index}")
+    elif dev.startswith("cuda:"):
+        device_index = int(dev.split(":")[1])
 
     if balance == "round_robin":
         mine = CutSet(LazySlicer(cuts.data, k=rank, n=world)) if world > 1 else cuts
@@ -242,7 +270,7 @@ def compute_and_store_features_sharded(
             return owner_of[i]
 
     sub_storage, sub_manifest = shard_paths(storage_path, manifest_path, rank)
-    meet = _Rendezvous(manifest_path.parent, rank, world, barrier_timeout)
+    meet = _Rendezvous(manifest_path.parent, rank, world, barrier_timeout, device_index)
     try:
         out = compute_and_store_features_batch(mine, extractor, sub_storage, manifest_path=sub_manifest, batch_duration=batch_duration,
                                                num_workers=num_workers, collate=collate, augment_fn=augment_fn, storage_type=storage_type,
@@ -251,6 +279,9 @@ def compute_and_store_features_sharded(
         if rank == 0:
             out = combine_shard_manifests(cuts, manifest_path, [shard_paths(storage_path, manifest_path, r)[1] for r in range(world)], owner)
         meet.barrier("combined")
+    except BaseException:
+        meet.failed()
+        raise
     finally:
         meet.close()
     return out

@@ -8,14 +8,23 @@ import torch
 
 
 def import_lhotse():
-    """Put /root/reference on the path (with the three stub modules it needs) and bind lhotse_amd to the real lhotse."""
+    """Put /root/reference on the path (with the three stub modules it needs) and bind lhotse_amd to the real lhotse -- also when
+    another test module imported lhotse_amd first (its lhotse-dependent modules are then reloaded, in dependency order)."""
+    import importlib
+
     from oracle.make_golden import import_reference
 
     import_reference()
     import lhotse  # noqa: F401
+    import lhotse_amd
     import lhotse_amd.compat as compat
 
-    assert compat.HAVE_LHOTSE, "lhotse_amd was imported before lhotse became importable: import_lhotse() must come first in a fresh process"
+    if not compat.HAVE_LHOTSE:  # lhotse_amd was imported before the stubs were in place
+        importlib.reload(compat)
+        for name in ("extractors", "augmentation", "kaldifeat", "input_strategies", "whisper", "librosa_fbank", "layers", "storage", "sharding"):
+            importlib.reload(importlib.import_module(f"lhotse_amd.{name}"))
+        importlib.reload(lhotse_amd)
+    assert compat.HAVE_LHOTSE
     return lhotse
 
 

@@ -22,41 +22,9 @@ pytestmark = pytest.mark.reference
 
 @pytest.fixture(scope="module")
 def lhotse_mod():
-    from oracle.make_golden import import_reference
+    from _dropin_support import import_lhotse
 
-    import_reference()
-    import importlib
-
-    import lhotse
-    import lhotse_amd.compat as compat
-
-    if not compat.HAVE_LHOTSE:  # lhotse_amd was imported before the stubs were in place
-        import lhotse_amd
-        import lhotse_amd.extractors as ex
-
-        import lhotse_amd.augmentation as aug
-
-        importlib.reload(compat)
-        importlib.reload(ex)
-        importlib.reload(aug)
-        import lhotse_amd.kaldifeat as kf
-
-        importlib.reload(kf)
-        import lhotse_amd.input_strategies as ins
-        import lhotse_amd.whisper as wh
-
-        importlib.reload(ins)
-        importlib.reload(wh)
-        import lhotse_amd.librosa_fbank as lf
-        import lhotse_amd.layers as ly
-
-        importlib.reload(lf)
-        importlib.reload(ly)
-        import lhotse_amd.storage as st
-
-        importlib.reload(st)
-        importlib.reload(lhotse_amd)
-    return lhotse
+    return import_lhotse()
 
 
 @pytest.fixture()

@@ -116,3 +116,39 @@ def test_bench_launches_itself_for_n_gt_1(monkeypatch):
     with pytest.raises(AssertionError, match="needs a GPU"):
         bench.main()
     assert not seen
+
+
+def test_marker_file_rendezvous_meets_fails_fast_and_cleans_up(tmp_path, monkeypatch):
+    """The rendezvous of the sharded driver for ranks that were only given RANK / WORLD_SIZE (lhotse_amd/sharding.py::_Rendezvous):
+    both ranks pass once both markers exist; a failing rank releases the waiting one at once; markers of another run do not count."""
+    import threading
+    import time
+
+    from lhotse_amd.sharding import _Rendezvous
+
+    monkeypatch.delenv("MASTER_ADDR", raising=False)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setenv("HIPFEAT_RUN_ID", "run-a")
+    a, b = _Rendezvous(tmp_path, 0, 2, 5.0), _Rendezvous(tmp_path, 1, 2, 5.0)
+    assert a.dist is None and b.dist is None
+    t = threading.Thread(target=lambda: (time.sleep(0.2), b.barrier("extracted")))
+    t.start()
+    t0 = time.time()
+    a.barrier("extracted")
+    t.join()
+    assert 0.15 < time.time() - t0 < 3.0
+    a.close(), b.close()
+    assert not list(tmp_path.glob(".extracted-*"))  # every rank removed its marker of the first barrier
+    # markers of an earlier run ("run-a") do not satisfy a new one
+    (tmp_path / ".extracted-run-a-1").write_text("done")
+    monkeypatch.setenv("HIPFEAT_RUN_ID", "run-b")
+    c = _Rendezvous(tmp_path, 0, 2, 0.3)
+    with pytest.raises(TimeoutError, match=r"ranks \[1\] did not reach 'extracted'"):
+        c.barrier("extracted")
+    # a failing rank releases the others immediately
+    d, e = _Rendezvous(tmp_path, 0, 2, 30.0), _Rendezvous(tmp_path, 1, 2, 30.0)
+    threading.Thread(target=lambda: (time.sleep(0.2), e.failed())).start()
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match=r"ranks \[1\] failed before 'combined'"):
+        d.barrier("combined")
+    assert time.time() - t0 < 5.0
