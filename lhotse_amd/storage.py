@@ -253,6 +253,7 @@ def _plain_copy(v):
 # which attaches a `dataloading_info` custom field to every cut: lhotse/dataset/sampling/base.py:473-487)
 TEMPLATE_STATS = {"template": 0, "fallback": 0}
 _REC_CACHE_MAX = 4096
+_SAVE_BACKLOG = 8  # batches in flight between the extractor and the save thread
 
 
 def _mono_cut_dict(cut, feats: Dict, rec_cache: Dict[str, Tuple[object, Dict]]) -> Optional[Dict]:
@@ -391,7 +392,11 @@ def compute_and_store_features_batch(
         if getattr(manifest, "file", None) is not None:
             manifest.file.flush()  # one flush per batch
 
-    futures = []
+    # At most _SAVE_BACKLOG batches wait for the save thread: each holds its page-locked result, and a failed save (disk full) stops the
+    # run at the next batch instead of after the whole corpus (the reference collects its futures at the very end, cut/set.py:2400-2404).
+    from collections import deque
+
+    futures = deque()
     with manifest, storage_type(storage_path, mode="w" if overwrite else "a") as writer, ThreadPoolExecutor(max_workers=1) as saver:
         template = None
         for batch in loader:
@@ -408,6 +413,8 @@ def compute_and_store_features_batch(
                 template = {"type": extractor.name, "num_features": int(host.shape[1]), "frame_shift": frame_shift, "sampling_rate": sr,
                             "storage_type": writer.name, "storage_path": str(writer.storage_path)}
             futures.append(saver.submit(save, writer, list(batch_cuts), host, frames, template))
-        for f in futures:
-            f.result()
+            while len(futures) > _SAVE_BACKLOG or (futures and futures[0].done()):
+                futures.popleft().result()
+        while futures:
+            futures.popleft().result()
     return manifest.open_manifest()

@@ -323,6 +323,57 @@ def test_bulk_save_driver_equals_the_reference_driver(tmp_path, cutset, cpu_devi
         assert a.features.storage_type == "numpy_files" and np.allclose(a.load_features(), b.load_features(), atol=2e-3)
 
 
+def test_a_failing_or_slow_save_thread_stops_or_throttles_the_extractor(tmp_path, cutset, cpu_device, monkeypatch):
+    """The save thread runs behind the extractor (as in lhotse/cut/set.py:2365-2404).  A write that fails must stop the run at the next
+    batch, not after the whole corpus, and a slow writer must not let finished (page-locked) batches pile up without bound."""
+    import threading
+    import time
+
+    import lhotse_amd as LA
+    import lhotse_amd.storage as S
+
+    calls = {"extracted": 0, "in_flight_max": 0, "written": 0}
+    real = S._batch_features_on_host
+
+    def counting(*a, **kw):
+        calls["extracted"] += 1
+        calls["in_flight_max"] = max(calls["in_flight_max"], calls["extracted"] - calls["written"])
+        return real(*a, **kw)
+
+    monkeypatch.setattr(S, "_batch_features_on_host", counting)
+
+    class FailingWriter(LA.HipArchiveWriter):
+        name = "hip_archive"
+
+        def write_packed(self, matrix, frames):
+            calls["written"] += 1
+            raise OSError("No space left on device")
+
+    ex = LA.HipFbank()
+    many = cutset + cutset.modify_ids(lambda i: i + "_b") + cutset.modify_ids(lambda i: i + "_c")  # 15 cuts, one per batch below
+    with pytest.raises(OSError, match="No space left"):
+        LA.compute_and_store_features_batch(many, extractor=ex, storage_path=tmp_path / "full", manifest_path=tmp_path / "full.jsonl.gz",
+                                            batch_duration=0.4, num_workers=0, storage_type=FailingWriter)
+    assert calls["extracted"] < 15  # stopped early
+
+    calls.update(extracted=0, in_flight_max=0, written=0)
+    monkeypatch.setattr(S, "_SAVE_BACKLOG", 2)
+
+    class SlowWriter(LA.HipArchiveWriter):
+        name = "hip_archive"
+
+        def write_packed(self, matrix, frames):
+            time.sleep(0.05)
+            keys = super().write_packed(matrix, frames)
+            calls["written"] += 1
+            return keys
+
+    out = LA.compute_and_store_features_batch(many, extractor=ex, storage_path=tmp_path / "slow", manifest_path=tmp_path / "slow.jsonl.gz",
+                                              batch_duration=0.4, num_workers=0, storage_type=SlowWriter)
+    assert len(list(out)) == 15 and calls["written"] == 15
+    assert calls["in_flight_max"] <= 2 + 2  # backlog + the batch being written + the one being extracted
+
+
 def test_template_manifests_behind_lazy_cuts_and_loader_workers(tmp_path, cutset, cpu_device):
     """with lazily loaded cuts (fresh Recording objects per batch, addresses reused by CPython) and DataLoader workers the
     per-recording cache of the template path must never hand one cut another cut's recording, and the template path must be the one
