@@ -26,7 +26,7 @@ for sr in [int(r) for r in a.rates.split(",")]:
     torch.cuda.synchronize()
     ms = float(np.mean([s.elapsed_time(e) for s, e in evs]))
     bpc = S * 4 + int(fr[0]) * 80 * 4
-    print(json.dumps({"sampling_rate": sr, "fft": plan.fft, "kernel": plan.kernel_name.split(" ")[0], "ms_per_launch": round(ms, 3),
+    print(json.dumps({"sampling_rate": sr, "fft": plan.fft, "kernel": plan.kernel_name.split(" ")[0] + (" fixed-schedule" if "fixed-schedule" in plan.kernel_name else ""), "ms_per_launch": round(ms, 3),
                       "cuts_per_s": round(a.cuts / ms * 1e3, 1), "audio_seconds_per_s": round(a.cuts * 10 / ms * 1e3, 1),
                       "frac_of_8TBps": round(a.cuts * bpc / ms / 1e6 / 8000, 3)}))
     del wave, out
