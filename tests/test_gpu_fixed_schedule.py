@@ -6,7 +6,9 @@ import numpy as np
 import pytest
 import torch
 
+from _golden import err_stats
 from _hip import make_hip
+from oracle.kaldi_ref import RefConfig, RefExtractor
 
 pytestmark = pytest.mark.gpu
 
@@ -23,9 +25,13 @@ def test_fixed_schedule_instances_equal_the_generic_ones(sr, kernel, monkeypatch
     rng = np.random.default_rng(sr)
     waves = [torch.from_numpy((rng.standard_normal(n) * a).astype(np.float32)) for n, a in
              ((int(0.9 * sr), 0.1), (3 * sr + 17, 0.3), (sr // 20 + 1, 1e-3), (7 * sr + 5, 0.05))]
-    for a, b in zip(fixed.extract_batch(waves, sr), generic.extract_batch(waves, sr)):
+    o32, o64 = RefExtractor(RefConfig(kind="fbank", sampling_rate=sr), np.float32), RefExtractor(RefConfig(kind="fbank", sampling_rate=sr), np.float64)
+    for w, a, b in zip(waves, fixed.extract_batch(waves, sr), generic.extract_batch(waves, sr)):
         assert a.shape == b.shape and a.shape[1] == 80
         assert torch.equal(a, b)
+        want, truth = o32.extract(w.numpy()), o64.extract(w.numpy())  # and both against the oracle of the reference at this rate
+        st = err_stats(a.cpu().numpy(), want)
+        assert a.shape == want.shape and st["rel_l2"] <= 1e-4 and st["max_abs"] <= max(2e-3, 3 * err_stats(want, truth)["max_abs"]), (sr, len(w), st)
 
 
 def test_other_filterbanks_run_the_generic_instance():
