@@ -570,7 +570,9 @@ def self_launch(args) -> None:
 
 def init_dist(backend: str, dev):
     """(dist module, backend actually used).  RCCL first; if its initialisation (or its first collective) fails, the same ranks fall back
-    to gloo -- the group carries three scalars per run, no data, so the measurement does not depend on which one it is."""
+    to gloo -- the group carries three scalars per run, no data, so the measurement does not depend on which one it is.  The fallback
+    group gets its OWN TCPStore (rank 0 hosts it one port above MASTER_PORT): under torchrun the env:// rendezvous is a client of the
+    launcher's agent store, which a second initialisation cannot reuse safely (stale keys of the failed group)."""
     import datetime
 
     import torch
@@ -580,7 +582,18 @@ def init_dist(backend: str, dev):
     os.environ.setdefault("MASTER_PORT", "29511")
     os.environ.setdefault("RANK", "0")  # (BENCH_FORCE_DIST without a launcher: a group of one)
     os.environ.setdefault("WORLD_SIZE", "1")
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+
+    def gloo_group(why: str):
+        store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1, world, is_master=(rank == 0),
+                              timeout=datetime.timedelta(seconds=120), wait_for_workers=False)
+        dist.init_process_group(backend="gloo", store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        return dist, why
+
     if backend == "nccl":
+        if dev.type != "cuda" or torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+            # ranks that share a GPU (a self-test of the N > 1 path on a smaller box): RCCL refuses duplicate devices -- do not even try
+            return gloo_group("gloo (fewer GPUs than ranks on this node)")
         try:
             dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=120))
             t = torch.ones(1, device=dev)
@@ -588,16 +601,13 @@ def init_dist(backend: str, dev):
             torch.cuda.synchronize(dev)
             return dist, "nccl"
         except Exception as e:  # noqa: BLE001
-            print(f"[bench] rank {os.environ.get('RANK', '0')}: RCCL initialisation failed ({e!r}); falling back to gloo", file=sys.stderr, flush=True)
+            print(f"[bench] rank {rank}: RCCL initialisation failed ({e!r}); falling back to gloo", file=sys.stderr, flush=True)
             try:
                 if dist.is_initialized():
                     dist.destroy_process_group()
             except Exception:  # noqa: BLE001
                 pass
-            # a fresh rendezvous: the TCP store of the failed group may be half torn down
-            os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
-            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
-            return dist, "gloo (RCCL initialisation failed)"
+            return gloo_group("gloo (RCCL initialisation failed)")
     dist.init_process_group(backend=backend)
     return dist, backend
 

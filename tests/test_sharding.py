@@ -152,3 +152,24 @@ def test_marker_file_rendezvous_meets_fails_fast_and_cleans_up(tmp_path, monkeyp
     with pytest.raises(RuntimeError, match=r"ranks \[1\] failed before 'combined'"):
         d.barrier("combined")
     assert time.time() - t0 < 5.0
+
+
+@pytest.mark.parametrize("mode,why", [("no-gpus", "fewer GPUs than ranks"), ("rccl-raises", "RCCL initialisation failed")])
+def test_bench_group_falls_back_to_gloo_under_the_launcher(mode, why):
+    """The driver's launch line (`python -m torch.distributed.run ... bench.py --gpus N`) on a box where RCCL cannot initialise: both
+    ranks must end up in ONE gloo group (bench.py::init_dist) -- the launcher's agent store cannot serve a second initialisation, so the
+    fallback brings its own TCPStore."""
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "_bench_dist_helper.py"), mode]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line and "world=2 sum=3.0" in line[0] and why in line[0], (out.stdout, out.stderr[-2000:])
