@@ -90,6 +90,8 @@ class _Rendezvous:
     from ONE shell share its pid across runs and should set HIPFEAT_RUN_ID.  A rank that fails leaves a ``failed`` marker, so that the
     others stop waiting at once instead of after the timeout."""
 
+    _calls = 0  # rendezvous created in this process (the same number on every rank: they all make the same calls)
+
     def __init__(self, marker_dir, rank: int, world: int, timeout: float, device_index=None):
         self.dir, self.rank, self.world, self.timeout = marker_dir, rank, world, timeout
         self.dist = None
@@ -98,6 +100,8 @@ class _Rendezvous:
         self.token = os.environ.get("HIPFEAT_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or f"ppid{os.getppid()}"
         if world == 1:
             return
+        _Rendezvous._calls += 1
+        self.seq = _Rendezvous._calls  # part of the marker names and of the store's port: a second call never meets the first one's leftovers
         try:
             import datetime
 
@@ -107,15 +111,19 @@ class _Rendezvous:
                 if dist.is_initialized():
                     self.dist = dist
                 elif "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ:
-                    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout))
+                    # a store of its own (rank 0 hosts it above MASTER_PORT, a fresh port per call): the launcher's agent store keeps the
+                    # keys of earlier groups, which a second call in the same processes would trip over
+                    store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1 + self.seq, world,
+                                          is_master=(rank == 0), timeout=datetime.timedelta(seconds=min(timeout, 600.0)), wait_for_workers=False)
+                    dist.init_process_group("gloo", store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout))
                     self.dist, self.owns_group = dist, True
         except ImportError:  # pragma: no cover
             pass
 
-    def _marker(self, tag: str, rank: int):
+    def _marker(self, tag: str, rank: int, seq: int = None):
         from pathlib import Path
 
-        return Path(self.dir) / f".{tag}-{self.token}-{rank}"
+        return Path(self.dir) / f".{tag}-{self.token}-{self.seq if seq is None else seq}-{rank}"
 
     def barrier(self, tag: str) -> None:
         import time
@@ -151,11 +159,14 @@ class _Rendezvous:
         if self.owns_group:
             self.dist.destroy_process_group()
             self.owns_group = False
-        if self.world > 1 and self.dist is None:  # this rank's markers of the first barrier: everybody is past it once "combined" was reached
-            try:
-                self._marker("extracted", self.rank).unlink()
-            except OSError:
-                pass
+        if self.world > 1 and self.dist is None:
+            # this rank's markers that nobody can be waiting for any more: the first barrier of this call (everybody is past it once
+            # "combined" was reached) and both barriers of the previous call in this process
+            for m in (self._marker("extracted", self.rank), self._marker("extracted", self.rank, self.seq - 1), self._marker("combined", self.rank, self.seq - 1)):
+                try:
+                    m.unlink()
+                except OSError:
+                    pass
 
 
 def shard_paths(storage_path, manifest_path, rank: int):

@@ -53,6 +53,10 @@ def _rank_main(rank, world, port, workdir, first, balance, q):
         import torch.distributed as dist
 
         assert not dist.is_initialized()  # the group the driver created for its barrier is gone again
+        # a second call in the same processes (everything is in the manifests already): the rendezvous must come up again
+        again = LA.compute_and_store_features_sharded(cuts, LA.HipFbank(), storage_path=work / "sharded", manifest_path=work / "sharded" / "cuts.jsonl.gz",
+                                                      batch_duration=3.0, num_workers=0, balance=balance, barrier_timeout=120.0)
+        assert [c.id for c in again] == [c.id for c in out] and not dist.is_initialized()
         q.put((rank, [c.id for c in out], dict(LA.storage.TEMPLATE_STATS), None))
     except BaseException as e:  # noqa: BLE001 -- the parent must see the reason
         import traceback

@@ -130,6 +130,7 @@ def test_marker_file_rendezvous_meets_fails_fast_and_cleans_up(tmp_path, monkeyp
     monkeypatch.delenv("MASTER_PORT", raising=False)
     monkeypatch.setenv("HIPFEAT_RUN_ID", "run-a")
     a, b = _Rendezvous(tmp_path, 0, 2, 5.0), _Rendezvous(tmp_path, 1, 2, 5.0)
+    b.seq = a.seq  # (one process per rank in real life: the n-th call of every rank carries the same number)
     assert a.dist is None and b.dist is None
     t = threading.Thread(target=lambda: (time.sleep(0.2), b.barrier("extracted")))
     t.start()
@@ -140,13 +141,14 @@ def test_marker_file_rendezvous_meets_fails_fast_and_cleans_up(tmp_path, monkeyp
     a.close(), b.close()
     assert not list(tmp_path.glob(".extracted-*"))  # every rank removed its marker of the first barrier
     # markers of an earlier run ("run-a") do not satisfy a new one
-    (tmp_path / ".extracted-run-a-1").write_text("done")
     monkeypatch.setenv("HIPFEAT_RUN_ID", "run-b")
     c = _Rendezvous(tmp_path, 0, 2, 0.3)
+    (tmp_path / f".extracted-run-a-{c.seq}-1").write_text("done")
     with pytest.raises(TimeoutError, match=r"ranks \[1\] did not reach 'extracted'"):
         c.barrier("extracted")
     # a failing rank releases the others immediately
     d, e = _Rendezvous(tmp_path, 0, 2, 30.0), _Rendezvous(tmp_path, 1, 2, 30.0)
+    e.seq = d.seq
     threading.Thread(target=lambda: (time.sleep(0.2), e.failed())).start()
     t0 = time.time()
     with pytest.raises(RuntimeError, match=r"ranks \[1\] failed before 'combined'"):
