@@ -121,6 +121,7 @@ struct hipfeat_plan {
   int fpb_unit = 0, c_rounds_max = 0;
   // fft1024 wave-autonomous fbank kernel (variant 8; shares d_c_shared / c_* with variant 7)
   int w_nsets = 0, w_steps[kWMaxSets] = {}, w_step0[kWMaxSets] = {};
+  int w_waves = kWWaves;  // fft1024c: waves per workgroup (12 for the fixed-schedule instances)
   int w_fixed = 0;  // fft1024c / fft2048c: instance with a compile-time mel schedule (fft1024c_fixed_id)
   // fft2048 wave-autonomous fbank kernel (variant 10; shares d_c_shared / c_* / w_* with variants 7 and 8)
   float* d_x_twp = nullptr;  // [32][32] v2 W_1024^(q k1)
@@ -657,9 +658,12 @@ static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, con
   while (img.size() % 64) img.push_back(0.0f);
   p->c_shared_floats = (int)img.size();
   p->c_xs_floats = (3 * shift + 32 * nrows + 3) & ~3;
-  const size_t lds = ((size_t)p->c_shared_floats + (size_t)kWWaves * (p->c_xs_floats + kWRegion)) * sizeof(float);
+  // fixed-schedule instances: 12 waves per workgroup, the span buffer aliases the exchange / power region (kernel_fft1024c.hpp)
+  int fixed = fft1024c_fixed_id(nrows, sch.nsets, sch.steps);
+  if (fixed && p->c_xs_floats > kWRegion) fixed = 0;
+  const int waves = fixed ? kWWavesFixed : kWWaves;
+  const size_t lds = ((size_t)p->c_shared_floats + (size_t)waves * (fixed ? kWRegion : p->c_xs_floats + kWRegion)) * sizeof(float);
   if (lds > 160 * 1024 || (p->c_xs_floats >> 8) > 10) return HIPFEAT_OK;
-  const int fixed = fft1024c_fixed_id(nrows, sch.nsets, sch.steps);
   const void* fn = fixed == 1 ? fft1024c_entry<20, 24, 16, 8>()
                    : fixed == 2 ? fft1024c_entry<26, 24, 16, 8>()
                    : fixed == 3 ? fft1024c_entry<20, 24, 24, 8>()
@@ -678,14 +682,15 @@ static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, con
   }
   p->nrows = nrows;
   p->c_rounds = 8;
-  p->fpb = kWWaves * p->c_rounds * 4;
-  p->fpb_unit = kWWaves * 4;
+  p->fpb = waves * p->c_rounds * 4;
+  p->fpb_unit = waves * 4;
+  p->w_waves = waves;
   p->c_rounds_max = 32;
   p->fast_lds_bytes = lds;
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * kWWaves, lds) == hipSuccess) p->blocks_per_cu = nb;
-  char nm[128];
-  snprintf(nm, sizeof(nm), "fft1024c_kernel<%d> fbank%s lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, fixed ? " fixed-schedule" : "", lds, p->blocks_per_cu, sch.nsets, total_steps);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * waves, lds) == hipSuccess) p->blocks_per_cu = nb;
+  char nm[160];
+  snprintf(nm, sizeof(nm), "fft1024c_kernel<%d> fbank%s waves=%d lds=%zuB blocks/CU=%d mel4=%dx%d", nrows, fixed ? " fixed-schedule" : "", waves, lds, p->blocks_per_cu, sch.nsets, total_steps);
   p->kernel_name = nm;
   p->variant = 8;
   return HIPFEAT_OK;
@@ -1701,7 +1706,7 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.nsets = plan->w_nsets;
     for (int s2 = 0; s2 < kWMaxSets; ++s2) fp.steps[s2] = plan->w_steps[s2], fp.step0[s2] = plan->w_step0[s2];
     DeviceGuard g(plan->device);
-    const dim3 grid((unsigned)lay->total_blocks), block(64 * kWWaves);
+    const dim3 grid((unsigned)lay->total_blocks), block(64 * plan->w_waves);
     set_lds_poison(plan->fast_lds_bytes);
     if (plan->w_fixed == 1) hipLaunchKernelGGL((fft1024c_kernel<20, 24, 16, 8>), grid, block, plan->fast_lds_bytes, stream, fp);
     else if (plan->w_fixed == 2) hipLaunchKernelGGL((fft1024c_kernel<26, 24, 16, 8>), grid, block, plan->fast_lds_bytes, stream, fp);

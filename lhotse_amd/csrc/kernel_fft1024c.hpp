@@ -28,7 +28,8 @@ constexpr int kWPRowStride = 528;                        // dwords per power row
 constexpr int kWRegion = 4 * kWExFrameStride + 16;       // 2192 dwords per wave; the 4 power rows (2112) alias it
 constexpr int kWMaxSets = 4;                             // accumulator sets (16 slots each)
 constexpr int kWMaxSteps = 32;                           // MFMA steps per set
-constexpr int kWWaves = 8;                               // waves per workgroup
+constexpr int kWWaves = 8;                               // waves per workgroup (generic instances: 2 waves/SIMD)
+constexpr int kWWavesFixed = 12;                         // fixed-schedule instances: 3 waves/SIMD (137 VGPRs; the span buffer aliases the region)
 constexpr int kWSplitSteps = 17;                         // bin-pair steps of the split (16 + lane 0's extra one)
 
 struct Fft1024cParams {
@@ -59,9 +60,16 @@ __device__ __forceinline__ v2 sel64(unsigned long long m, v2 a, v2 b) { return v
 // S0 / S1 / S2 != 0: the (padded) step counts of a three-set schedule as compile-time constants -- the 80-filter Kaldi defaults at 24 / 32 kHz
 // (24, 16, 8) and 22.05 kHz (24, 24, 8).  Without the "does this chunk exist" tests the mel phase needs 100 VGPRs, ~350 scalar instructions
 // and 20 SGPR spills less per round (+2 % at 24 kHz, +4 % at 32 kHz); any other filterbank runs the generic <NROWS, 0, 0, 0>.
+//
+// The fixed-schedule instances run 12 waves per workgroup = 3 waves/SIMD (the power probe of round 3 shows these kernels at the full clock under the
+// power cap: latency-limited at 2 waves/SIMD).  The LDS for that comes from giving up the span prefetch: the wave's span buffer ALIASES its
+// exchange / power region (8.8 KB per wave instead of 14.2), the span of a round is requested at the top of that round and waited for at
+// once -- the third wave per SIMD covers that latency and more.
 template <int NROWS, int S0 = 0, int S1 = 0, int S2 = 0>
-__global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024cParams p) {
+__global__ __launch_bounds__(64 * (S0 != 0 ? kWWavesFixed : kWWaves), (S0 != 0 ? 3 : 2)) void fft1024c_kernel(const Fft1024cParams p) {
   constexpr bool kFixed = S0 != 0;
+  constexpr int kWv = kFixed ? kWWavesFixed : kWWaves;  // waves per workgroup
+  constexpr bool kPrefetch = !kFixed;                   // span of round r + 1 requested during round r (needs a span buffer of its own)
   constexpr int kFixSteps[4] = {S0, S1, S2, 0}, kFixStep0[4] = {0, S0, S0 + S1, S0 + S1 + S2};
   extern __shared__ __attribute__((aligned(16))) float smem[];
   HF_POISON_LDS(smem);
@@ -88,9 +96,9 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
   const float* __restrict__ w = p.wave + cd.wave_off;
   const int N = p.N, shift = p.shift;
 
-  for (int i = tid; i < p.shared_floats; i += 64 * kWWaves) smem[i] = p.shared_consts[i];
-  float* xs = smem + p.shared_floats + wv * (p.xs_floats + kWRegion);
-  float* myreg = xs + p.xs_floats;
+  for (int i = tid; i < p.shared_floats; i += 64 * kWv) smem[i] = p.shared_consts[i];
+  float* xs = smem + p.shared_floats + wv * (kPrefetch ? p.xs_floats + kWRegion : kWRegion);
+  float* myreg = kPrefetch ? xs + p.xs_floats : xs;  // (no prefetch: the span is dead once the samples are in registers, before the exchange)
   const bool dc = (p.flags & F_REMOVE_DC) != 0;
   const bool mag = (p.flags & F_FFT_MAG) != 0;
   const float log_scale = (p.flags & F_LOG10) ? 0.30102999566398120f : 0.69314718055994531f;  // log2 -> log10 / ln
@@ -121,19 +129,20 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
 
   const int first_frame = fb * p.frames_per_block + 4 * wv;  // the waves take the frame quads round-robin
   __syncthreads();  // the constant tables are in place (the only workgroup barrier of the kernel)
-  if (first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
+  if (kPrefetch && first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
 
 #ifdef HIPFEAT_PHASE_TIMERS
   unsigned long long hfc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hfc_last = __builtin_readcyclecounter();
 #endif
   for (int r = 0; r < p.rounds; ++r) {
-    const int f0 = first_frame + 4 * kWWaves * r;
+    const int f0 = first_frame + 4 * kWv * r;
     if (f0 >= cd.num_frames) break;
     const int nf = min(4, cd.num_frames - f0);
 
-    if (r == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); later rounds waited before their predecessor's stores
     int lane_o = lane;  // opaque copy: keeps LICM from pinning per-lane addresses in VGPRs for the whole kernel
     asm volatile("" : "+v"(lane_o));
+    if (!kPrefetch) stage_span(f0, (unsigned)lane_o * 4u);  // (the previous round's power-row reads were consumed by its MFMAs: the region is free)
+    if (r == 0 || !kPrefetch) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); with prefetch, later rounds waited before their predecessor's stores
     const int q = lane_o & 15, g = lane_o >> 4;
     const unsigned long long q0 = __builtin_amdgcn_ballot_w64(q == 0);  // lanes 0, 16, 32, 48
 
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
       // the samples are in flight to registers; once they have arrived the buffer is free for the next round's span
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       HFC_T(0);  // sample, neighbour and window reads
-      if (r + 1 < p.rounds && f0 + 4 * kWWaves < cd.num_frames) stage_span(f0 + 4 * kWWaves, (unsigned)lane_o * 4u);
+      if (kPrefetch && r + 1 < p.rounds && f0 + 4 * kWv < cd.num_frames) stage_span(f0 + 4 * kWv, (unsigned)lane_o * 4u);
       HFC_T(1);  // span request (LDS-DMA issue)
 
 #pragma unroll
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
 
     // the next round's span (requested at the start of this round) must have landed before this round's stores join the
     // same in-order vmcnt queue: waiting here instead of at the top of the next round never waits for the stores
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (kPrefetch) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     HFC_T(5);  // wait for the next span
     // ---- mel filterbank on the matrix cores: one accumulator set after the other (kernel_fft512c.hpp, mel4_schedule.hpp) ----
     float* orow = p.out + (cd.out_row + f0) * p.out_stride;
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void fft1024c_kernel(const Fft1024
   }
 #ifdef HIPFEAT_PHASE_TIMERS
   if (lane == 0 && g_phase_buf) {
-    unsigned long long* o = g_phase_buf + ((size_t)blockIdx.x * kWWaves + wv) * 8;
+    unsigned long long* o = g_phase_buf + ((size_t)blockIdx.x * kWv + wv) * 8;
     for (int i = 0; i < 8; ++i) o[i] = hfc_acc[i];
   }
 #endif
