@@ -7,7 +7,8 @@ import lhotse_amd as LA
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cuts", type=int, default=2000)
-ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--warmup", type=int, default=8, help="untimed launches first: the shader clock ramps up over the first ~6 launches after an idle phase")
 ap.add_argument("--rates", default="8000,16000,22050,24000,32000,44100,48000")
 a = ap.parse_args()
 for sr in [int(r) for r in a.rates.split(",")]:
@@ -19,7 +20,9 @@ for sr in [int(r) for r in a.rates.split(",")]:
     wave = torch.empty(a.cuts * S, device="cuda").uniform_(-0.5, 0.5)
     offs = np.arange(a.cuts, dtype=np.int64) * S
     lens = np.full(a.cuts, S, dtype=np.int64)
-    plan.run(wave, offs, lens, None); torch.cuda.synchronize()
+    for _ in range(max(1, a.warmup)):
+        plan.run(wave, offs, lens, None)
+    torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     for s, e in evs:
         s.record(); out, fr = plan.run(wave, offs, lens, None); e.record()
