@@ -1034,9 +1034,9 @@ static hipfeat_status setup_whisper2(hipfeat_plan* p, const float* h_mel) {
 }
 
 // fft2048 wave-autonomous fbank kernel (kernel_fft2048c.hpp): 44.1 / 48 kHz Kaldi filterbanks, librosa-style log-mel with n_fft 2048
-template <int NROWS, bool ODD, int S0 = 0, int S1 = 0, int S2 = 0>
+template <int NROWS, bool ODD, int S0 = 0, int S1 = 0, int S2 = 0, bool W12 = false>
 static const void* fft2048c_entry() {
-  return reinterpret_cast<const void*>(&fft2048c_kernel<NROWS, ODD, S0, S1, S2>);
+  return reinterpret_cast<const void*>(&fft2048c_kernel<NROWS, ODD, S0, S1, S2, W12>);
 }
 
 static hipfeat_status setup_fft2048c(hipfeat_plan* p, const float* h_window, const float* h_mel) {
@@ -1099,15 +1099,18 @@ static hipfeat_status setup_fft2048c(hipfeat_plan* p, const float* h_window, con
   p->c_shared_floats = (int)img.size();
   p->c_xs_floats = (shift + 64 * nrows + 3) & ~3;
   if ((p->c_xs_floats >> 8) > 10) return HIPFEAT_OK;
-  int waves = kXMaxWaves;
-  auto lds_of = [&](int wv) { return ((size_t)p->c_shared_floats + (size_t)wv * (p->c_xs_floats + kXRegion)) * sizeof(float); };
+  // instance with the mel schedule as compile-time constants (kernel_fft2048c.hpp): the 80-filter Kaldi default at 44.1 / 48 kHz.  The 44.1 kHz one
+  // runs 12 waves per workgroup (3 waves/SIMD) without a span prefetch, the span buffer aliasing the exchange / power region (at 48 kHz that
+  // layout measured 3 % slower than 8 waves with the prefetch)
+  const bool fixed = sch.nsets == 3 && sch.steps[0] == 52 && sch.steps[1] == 28 && sch.steps[2] == 16 && sch.step0[1] == 52 && sch.step0[2] == 80 &&
+                     (odd ? nrows == 18 : nrows == 19) && !getenv("HIPFEAT_NO_FIXED_SCHEDULE");
+  const bool w12 = fixed && odd && p->c_xs_floats <= kXRegion && ((size_t)p->c_shared_floats + (size_t)kXWavesFixed * kXRegion) * sizeof(float) <= 160 * 1024;
+  int waves = w12 ? kXWavesFixed : kXMaxWaves;
+  auto lds_of = [&](int wv) { return ((size_t)p->c_shared_floats + (size_t)wv * (w12 ? kXRegion : p->c_xs_floats + kXRegion)) * sizeof(float); };
   while (waves > 0 && lds_of(waves) > 160 * 1024) --waves;
   if (waves < 4) return HIPFEAT_OK;
   const size_t lds = lds_of(waves);
-  // instance with the mel schedule as compile-time constants (kernel_fft2048c.hpp): the 80-filter Kaldi default at 44.1 / 48 kHz
-  const bool fixed = sch.nsets == 3 && sch.steps[0] == 52 && sch.steps[1] == 28 && sch.steps[2] == 16 && sch.step0[1] == 52 && sch.step0[2] == 80 &&
-                     (odd ? nrows == 18 : nrows == 19) && !getenv("HIPFEAT_NO_FIXED_SCHEDULE");
-  const void* fn = fixed ? (odd ? fft2048c_entry<18, true, 52, 28, 16>() : fft2048c_entry<19, false, 52, 28, 16>())
+  const void* fn = fixed ? (odd ? (w12 ? fft2048c_entry<18, true, 52, 28, 16, true>() : fft2048c_entry<18, true, 52, 28, 16>()) : fft2048c_entry<19, false, 52, 28, 16>())
                    : odd ? (nrows == 18 ? fft2048c_entry<18, true>() : fft2048c_entry<32, true>())
                          : (nrows == 19 ? fft2048c_entry<19, false>() : fft2048c_entry<32, false>());
   p->w_fixed = fixed ? 1 : 0;
@@ -1670,7 +1673,8 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     const dim3 grid((unsigned)lay->total_blocks), block(64 * plan->x_waves);
     set_lds_poison(plan->fast_lds_bytes);
     if (plan->x_odd) {
-      if (plan->w_fixed) hipLaunchKernelGGL((fft2048c_kernel<18, true, 52, 28, 16>), grid, block, plan->fast_lds_bytes, stream, fp);
+      if (plan->w_fixed && plan->x_waves == kXWavesFixed) hipLaunchKernelGGL((fft2048c_kernel<18, true, 52, 28, 16, true>), grid, block, plan->fast_lds_bytes, stream, fp);
+      else if (plan->w_fixed) hipLaunchKernelGGL((fft2048c_kernel<18, true, 52, 28, 16>), grid, block, plan->fast_lds_bytes, stream, fp);
       else if (plan->nrows == 18) hipLaunchKernelGGL((fft2048c_kernel<18, true>), grid, block, plan->fast_lds_bytes, stream, fp);
       else hipLaunchKernelGGL((fft2048c_kernel<32, true>), grid, block, plan->fast_lds_bytes, stream, fp);
     } else {

@@ -70,9 +70,15 @@ __device__ __forceinline__ void half_fft32(const v2 (&x)[32], v2 sg, const v2* t
 
 // S0 / S1 / S2 != 0: the step counts of a three-set mel schedule as compile-time constants (the 80-filter Kaldi default at 44.1 / 48 kHz:
 // 52, 28, 16), as in kernel_fft1024c.hpp; any other filterbank runs the generic <NROWS, ODD, 0, 0, 0>.
-template <int NROWS, bool ODD, int S0 = 0, int S1 = 0, int S2 = 0>
-__global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2048cParams p) {
+// W12: 12 waves per workgroup = 3 waves/SIMD without a span prefetch, the span buffer aliasing the exchange / power region, as in
+// kernel_fft1024c.hpp; the pass twiddles are then requested AFTER the 32-point FFT, in two bursts (133-147 VGPRs).  Same-box A/B against the
+// 8-wave fixed-schedule instances: 44.1 kHz (odd hop) + 4 %, 48 kHz - 3 % -- so only the 44.1 kHz default uses it.
+constexpr int kXWavesFixed = 12;
+template <int NROWS, bool ODD, int S0 = 0, int S1 = 0, int S2 = 0, bool W12 = false>
+__global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 2)) void fft2048c_kernel(const Fft2048cParams p) {
   constexpr bool kFixed = S0 != 0;
+  constexpr bool kPrefetch = !W12;  // span of round r + 1 requested during round r (needs a span buffer of its own)
+  constexpr bool kTwLate = NROWS == 32 || !kPrefetch;  // pass twiddles requested after the 32-point FFT
   constexpr int kFixSteps[4] = {S0, S1, S2, 0}, kFixStep0[4] = {0, S0, S0 + S1, S0 + S1 + S2};
   extern __shared__ __attribute__((aligned(16))) float smem[];
   HF_POISON_LDS(smem);
@@ -101,8 +107,8 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
   const int N = p.N, shift = p.shift;
 
   for (int i = tid; i < p.shared_floats; i += nthreads) smem[i] = p.shared_consts[i];
-  float* xs = smem + p.shared_floats + wv * (p.xs_floats + kXRegion);
-  float* myreg = xs + p.xs_floats;
+  float* xs = smem + p.shared_floats + wv * (kPrefetch ? p.xs_floats + kXRegion : kXRegion);
+  float* myreg = kPrefetch ? xs + p.xs_floats : xs;  // (no prefetch: the span is dead once the samples are in registers, before the exchange)
   const bool dc = (p.flags & F_REMOVE_DC) != 0;
   const bool mag = (p.flags & F_FFT_MAG) != 0;
   const float log_scale = (p.flags & F_LOG10) ? 0.30102999566398120f : 0.69314718055994531f;  // log2 -> log10 / ln
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
 
   const int first_frame = fb * p.frames_per_block + 2 * wv;  // the waves take the frame pairs round-robin
   __syncthreads();  // the constant tables are in place (the only workgroup barrier of the kernel)
-  if (first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
+  if (kPrefetch && first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
 
 #ifdef HIPFEAT_PHASE_TIMERS
   unsigned long long hfc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hfc_last = __builtin_readcyclecounter();
@@ -143,9 +149,10 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
     if (f0 >= cd.num_frames) break;
     const int nf = min(2, cd.num_frames - f0);
 
-    if (r == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); later rounds waited before their predecessor's stores
     int lane_o = lane;  // opaque copy: keeps LICM from pinning per-lane addresses in VGPRs for the whole kernel
     asm volatile("" : "+v"(lane_o));
+    if (!kPrefetch) stage_span(f0, (unsigned)lane_o * 4u);  // (the previous round's power-row reads were consumed by its MFMAs: the region is free)
+    if (r == 0 || !kPrefetch) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); with prefetch, later rounds waited before their predecessor's stores
     const int q = lane_o & 31, g = lane_o >> 5;
     const unsigned long long q0 = __builtin_amdgcn_ballot_w64(q == 0);  // lanes 0 and 32
 
@@ -176,14 +183,14 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
         // span request follow the 32-point FFT)
         v2 twp[32];
         const v2* gt = reinterpret_cast<const v2*>(p.twp) + q;
-        if (NROWS < 32) {
+        if (!kTwLate) {
 #pragma unroll
           for (int k1 = 1; k1 < 32; ++k1) twp[k1] = gt[k1 * 32];
         }
         // the samples are in flight to registers; once they have arrived the buffer is free for the next round's span
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         HFC_T(0);  // sample, neighbour and window reads
-        if (NROWS < 32 && r + 1 < p.rounds && f0 + 2 * p.waves < cd.num_frames) stage_span(f0 + 2 * p.waves, (unsigned)lane_o * 4u);
+        if (kPrefetch && NROWS < 32 && r + 1 < p.rounds && f0 + 2 * p.waves < cd.num_frames) stage_span(f0 + 2 * p.waves, (unsigned)lane_o * 4u);
         HFC_T(1);  // span request (LDS-DMA issue)
 
 #pragma unroll
@@ -223,14 +230,25 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
 #pragma unroll
         for (int n1 = NROWS; n1 < 32; ++n1) z[n1] = v2{0.f, 0.f};
         fft32<NROWS>(z, a);
-        if (NROWS == 32) {
+        if (kTwLate && kPrefetch) {
           asm volatile("" : "+v"(a[0].x), "+v"(a[31].y) : : "memory");  // not before the FFT's results exist (hipcc would hoist the loads)
 #pragma unroll
           for (int k1 = 1; k1 < 32; ++k1) twp[k1] = gt[k1 * 32];
           if (r + 1 < p.rounds && f0 + 2 * p.waves < cd.num_frames) stage_span(f0 + 2 * p.waves, (unsigned)lane_o * 4u);
         }
+        if (kTwLate && !kPrefetch) {  // two bursts of 16: request, multiply, request, multiply
 #pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) a[k1] = cmul2(a[k1], twp[k1]);
+          for (int h = 0; h < 2; ++h) {
+            asm volatile("" : "+v"(a[16 * h].x), "+v"(a[16 * h + 15].y) : : "memory");
+#pragma unroll
+            for (int k1 = 16 * h + (h == 0 ? 1 : 0); k1 < 16 * h + 16; ++k1) twp[k1] = gt[k1 * 32];
+#pragma unroll
+            for (int k1 = 16 * h + (h == 0 ? 1 : 0); k1 < 16 * h + 16; ++k1) a[k1] = cmul2(a[k1], twp[k1]);
+          }
+        } else {
+#pragma unroll
+          for (int k1 = 1; k1 < 32; ++k1) a[k1] = cmul2(a[k1], twp[k1]);
+        }
       }
       HFC_T(2);  // mean, prolog, pass 1, twiddles
       float* exf = myreg + mul24(g, kXExFrameStride);
@@ -346,7 +364,7 @@ __global__ __launch_bounds__(64 * kXMaxWaves, 2) void fft2048c_kernel(const Fft2
 
     // the next round's span (requested at the start of this round) must have landed before this round's stores join the same
     // in-order vmcnt queue: waiting here instead of at the top of the next round never waits for the stores
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (kPrefetch) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     HFC_T(5);  // wait for the next span
     // ---- mel filterbank on the matrix cores: one accumulator set after the other, 32 steps at a time, two accumulation chains ----
     float* orow = p.out + (cd.out_row + f0) * p.out_stride;
