@@ -590,6 +590,10 @@ class _HipExtractor(FeatureExtractor):
         return st
 
     def _drop_plan(self):
+        # the host pipeline (two side streams) and the pinned staging belong to the plan's device: they go with it, or a moved
+        # extractor would record / wait on the OLD device's streams while the kernel runs on the new one
+        self.__dict__.pop("_pipeline", None)
+        self._staging = None
         if self._plan is not None:
             self._plan.close()
             self._plan = None
@@ -640,10 +644,10 @@ class _HipExtractor(FeatureExtractor):
 
     def _pipe(self) -> "_HostPipeline":
         pipe = self.__dict__.get("_pipeline")
-        if pipe is None:
+        if pipe is None or pipe.device != self.plan.device:
             with self._lazy_lock():
                 pipe = self.__dict__.get("_pipeline")
-                if pipe is None:
+                if pipe is None or pipe.device != self.plan.device:
                     pipe = self.__dict__["_pipeline"] = _HostPipeline(self.plan.device)
         return pipe
 
@@ -957,6 +961,7 @@ class HipSpectrogram(_SpecMixin, _HipExtractor):
     config_type = HipSpectrogramConfig
     kind = KIND_SPECTROGRAM
     _cpu_outputs = True
+    log_domain = False  # power / magnitude values: not storable in binary16 (storage.py::HipArchiveF16Writer)
 
 
 @register_extractor

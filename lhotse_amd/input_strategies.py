@@ -107,13 +107,18 @@ if HAVE_LHOTSE:  # pragma: no cover - authoring container only
         extractor's GPU, ready for the training step; ``"cpu"`` hands back a host tensor like the reference does) and
         ``gpu_speed_perturb`` (see the module docstring)."""
 
-        def __init__(self, extractor, *args, return_device: Optional[Union[str, torch.device]] = None, gpu_speed_perturb: bool = True,
-                     **kwargs) -> None:
+        def __init__(self, extractor, *args, return_device: Optional[Union[str, torch.device]] = None,
+                     gpu_speed_perturb: Optional[bool] = None, **kwargs) -> None:
             if not hasattr(extractor, "extract_collated"):
                 raise TypeError("HipOnTheFlyFeatures needs a Hip* extractor (with extract_collated)")
             super().__init__(extractor, *args, **kwargs)
             self.return_device = return_device
-            self.gpu_speed_perturb = gpu_speed_perturb
+            # None (default) = on the device unless `wave_transforms` are given: those run on the LOADED samples, i.e. after the
+            # Speed that Recording.load_audio applies, so with them the reference order (CPU Speed inside load_audio, then the
+            # transforms) is kept and the strategy behaves exactly like OnTheFlyFeatures.  An explicit True together with
+            # wave_transforms is a contradiction and raises when a perturbed cut is met.
+            self._gpu_speed_explicit = gpu_speed_perturb is not None
+            self.gpu_speed_perturb = (not self.wave_transforms) if gpu_speed_perturb is None else bool(gpu_speed_perturb)
 
         def _read(self, cuts, pool, recording_field):
             """read_audio_from_cuts (lhotse/dataset/collation.py:541-600) with the Speed of eligible cuts left for the device."""
@@ -142,8 +147,9 @@ if HAVE_LHOTSE:  # pragma: no cover - authoring container only
             audios, factors, wants, cuts = self._read(cuts, pool, recording_field)
             for transform in self.wave_transforms:
                 if any(f != 1.0 for f in factors):
-                    raise ValueError("wave_transforms run on the loaded samples, before the device applies the pending speed factors: "
-                                     "use gpu_speed_perturb=False together with wave_transforms")
+                    raise ValueError("gpu_speed_perturb=True was requested together with wave_transforms: the transforms run on the loaded "
+                                     "samples, before the device applies the pending speed factors; leave gpu_speed_perturb at its default "
+                                     "(None: the reference's CPU Speed whenever wave_transforms are given) or pass False")
                 audios = [transform(a) for a in audios]
             rates = {c.sampling_rate for c in cuts}
             assert len(rates) == 1, f"one launch per batch needs a single sampling rate, got {sorted(rates)}"

@@ -85,23 +85,32 @@ class _Rendezvous:
     """The two barriers of the sharded driver (everybody has extracted / rank 0 has combined).  In order of preference: the caller's
     process group (RCCL or gloo); a gloo group created here from torchrun's MASTER_ADDR / MASTER_PORT (host-side only -- the barrier
     carries no data, so it does not need RCCL) and destroyed again; marker files next to the shards for ranks that were only given
-    RANK / WORLD_SIZE.  Marker names carry a run token shared by the ranks of one launch (HIPFEAT_RUN_ID, else torchrun's run id, else
-    the parent process id), so that the markers of an earlier run in the same directory cannot satisfy this one; ranks started by hand
-    from ONE shell share its pid across runs and should set HIPFEAT_RUN_ID.  A rank that fails leaves a ``failed`` marker, so that the
-    others stop waiting at once instead of after the timeout."""
+    RANK / WORLD_SIZE.
+
+    Marker-file mode.  File names carry a run token shared by the ranks of one launch (HIPFEAT_RUN_ID, else torchrun's
+    run id, else the parent process id) -- but a token can repeat: ranks started by hand from ONE shell share its pid across runs, which
+    is exactly the advertised per-shard resume.  The barriers are therefore keyed by a NONCE that is agreed per launch and cannot be
+    satisfied by leftovers: every rank publishes a fresh random id in its ``hello`` file; rank 0 draws the nonce and publishes it in
+    the ``nonce`` file together with the hello ids it has seen (re-published from inside its barrier loops whenever a hello changes);
+    rank r adopts the nonce only from a nonce file that quotes ITS current id.  A stale nonce / hello / barrier marker of an earlier run
+    quotes other ids and is ignored; every rank sweeps its own leftovers of the same token when it starts, and its own files of this
+    launch that nobody can be waiting for when it finishes.  A rank that fails leaves a ``failed`` marker, so that the others stop
+    waiting at once instead of after the timeout; it counts only if it is not older than the waiting rank's own hello file, so the
+    marker of a failed earlier launch is inert (and swept by its rank when that starts again)."""
 
     _calls = 0  # rendezvous created in this process (the same number on every rank: they all make the same calls)
 
-    def __init__(self, marker_dir, rank: int, world: int, timeout: float, device_index=None):
+    def __init__(self, marker_dir, rank: int, world: int, timeout: float, device_index=None, seq: int = None):
         self.dir, self.rank, self.world, self.timeout = marker_dir, rank, world, timeout
         self.dist = None
         self.owns_group = False
         self.device_index = device_index
         self.token = os.environ.get("HIPFEAT_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or f"ppid{os.getppid()}"
+        self.nonce = None
         if world == 1:
             return
         _Rendezvous._calls += 1
-        self.seq = _Rendezvous._calls  # part of the marker names and of the store's port: a second call never meets the first one's leftovers
+        self.seq = _Rendezvous._calls if seq is None else seq  # part of the marker names and of the store's port: a second call never meets the first one's leftovers
         try:
             import datetime
 
@@ -119,11 +128,104 @@ class _Rendezvous:
                     self.dist, self.owns_group = dist, True
         except ImportError:  # pragma: no cover
             pass
+        if self.dist is None:
+            self._marker_mode_hello()
 
-    def _marker(self, tag: str, rank: int, seq: int = None):
+    # ---- marker files ------------------------------------------------------------------------------------------------------------
+    def _path(self, tag: str, rank=None, nonce: str = None):
         from pathlib import Path
 
-        return Path(self.dir) / f".{tag}-{self.token}-{self.seq if seq is None else seq}-{rank}"
+        parts = [f".{tag}", self.token, str(self.seq)] + ([nonce] if nonce else []) + ([str(rank)] if rank is not None else [])
+        return Path(self.dir) / "-".join(parts)
+
+    @staticmethod
+    def _write_atomic(path, text: str) -> None:
+        tmp = path.with_name(path.name + f".tmp{os.getpid()}")
+        tmp.write_text(text)
+        os.replace(tmp, path)
+
+    @staticmethod
+    def _read(path):
+        try:
+            return path.read_text()
+        except OSError:
+            return None
+
+    def _marker_mode_hello(self) -> None:
+        import glob
+        import uuid
+
+        # this rank's leftovers of earlier launches with the same token (any call number, any nonce): nobody of THIS launch waits for
+        # them -- except the files of the previous call in this very process, which a slower rank may still be polling
+        for tag in ("hello", "extracted", "combined", "failed"):
+            keep = f".{tag}-{self.token}-{self.seq - 1}-"
+            for f in glob.glob(os.path.join(glob.escape(str(self.dir)), f".{tag}-{glob.escape(self.token)}-*-{self.rank}")):
+                if os.path.basename(f).startswith(keep):
+                    continue
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
+        self.my_id = uuid.uuid4().hex
+        if self.rank == 0:
+            for f in glob.glob(os.path.join(glob.escape(str(self.dir)), f".nonce-{glob.escape(self.token)}-*")):
+                if os.path.basename(f) == f".nonce-{self.token}-{self.seq - 1}":
+                    continue
+                try:
+                    os.unlink(f)
+                except OSError:
+                    pass
+            self.nonce = uuid.uuid4().hex
+            self._published = None
+        self._write_atomic(self._path("hello", self.rank), self.my_id)
+        if self.rank == 0:
+            self._publish()
+
+    def _hello_ids(self):
+        return {r: self._read(self._path("hello", r)) for r in range(self.world)}
+
+    def _publish(self) -> None:
+        """Rank 0: (re-)publish the nonce with the hello ids currently on disk."""
+        import json
+
+        ids = {str(r): i for r, i in self._hello_ids().items() if i}
+        if ids != self._published:
+            self._write_atomic(self._path("nonce"), json.dumps({"nonce": self.nonce, "ids": ids}))
+            self._published = ids
+
+    def _resolve(self) -> bool:
+        """Rank r > 0: adopt the nonce once rank 0 has quoted this rank's current id next to it."""
+        import json
+
+        if self.nonce is not None:
+            return True
+        raw = self._read(self._path("nonce"))
+        if raw:
+            try:
+                doc = json.loads(raw)
+            except ValueError:
+                return False
+            if doc.get("ids", {}).get(str(self.rank)) == self.my_id:
+                self.nonce = doc["nonce"]
+                return True
+        return False
+
+    def _failed_ranks(self):
+        """Ranks whose `failed` marker is not older than this rank's own hello file (both times come from the file system that holds
+        them): the marker of an earlier launch with the same token is older and does not count.  (A rank that fails before this one
+        has even started is therefore not noticed, and this rank waits for it until the timeout.)"""
+        try:
+            born = os.stat(self._path("hello", self.rank)).st_mtime_ns
+        except OSError:
+            return []
+        out = []
+        for r in range(self.world):
+            try:
+                if r != self.rank and os.stat(self._path("failed", r)).st_mtime_ns >= born:
+                    out.append(r)
+            except OSError:
+                pass
+        return out
 
     def barrier(self, tag: str) -> None:
         import time
@@ -136,22 +238,32 @@ class _Rendezvous:
             else:
                 self.dist.barrier()
             return
-        self._marker(tag, self.rank).write_text("done")
         deadline = time.time() + self.timeout
-        while not all(self._marker(tag, r).exists() for r in range(self.world)):
-            failed = [r for r in range(self.world) if self._marker("failed", r).exists()]
+        written = False
+        while True:
+            if self.rank == 0:
+                self._publish()
+            if self._resolve():
+                if not written:
+                    self._path(tag, self.rank, self.nonce).write_text("done")
+                    written = True
+                missing = [r for r in range(self.world) if not self._path(tag, r, self.nonce).exists()]
+                if not missing:
+                    return
+            else:
+                missing = [0]
+            failed = self._failed_ranks()
             if failed:
                 raise RuntimeError(f"sharded extraction: ranks {failed} failed before '{tag}' (see their own tracebacks)")
             if time.time() > deadline:
-                missing = [r for r in range(self.world) if not self._marker(tag, r).exists()]
                 raise TimeoutError(f"sharded extraction: ranks {missing} did not reach '{tag}' within {self.timeout:.0f} s")
-            time.sleep(0.05)
+            time.sleep(0.02)
 
     def failed(self) -> None:
         """Called on the way out of a failing rank (marker-file mode: process groups have their own timeouts)."""
         if self.world > 1 and self.dist is None:
             try:
-                self._marker("failed", self.rank).write_text("failed")
+                self._write_atomic(self._path("failed", self.rank), self.my_id)
             except OSError:  # pragma: no cover
                 pass
 
@@ -159,14 +271,13 @@ class _Rendezvous:
         if self.owns_group:
             self.dist.destroy_process_group()
             self.owns_group = False
-        if self.world > 1 and self.dist is None:
-            # this rank's markers that nobody can be waiting for any more: the first barrier of this call (everybody is past it once
-            # "combined" was reached) and both barriers of the previous call in this process
-            for m in (self._marker("extracted", self.rank), self._marker("extracted", self.rank, self.seq - 1), self._marker("combined", self.rank, self.seq - 1)):
-                try:
-                    m.unlink()
-                except OSError:
-                    pass
+        if self.world > 1 and self.dist is None and self.nonce is not None:
+            # this rank's marker of the first barrier: everybody is past it once "combined" was reached.  The "combined" marker, the hello
+            # and (rank 0) the nonce file stay -- a slower rank may still be polling them -- and are swept by the next launch.
+            try:
+                self._path("extracted", self.rank, self.nonce).unlink()
+            except OSError:
+                pass
 
 
 def shard_paths(storage_path, manifest_path, rank: int):
@@ -176,7 +287,12 @@ def shard_paths(storage_path, manifest_path, rank: int):
 
     sp = Path(storage_path)
     mp = Path(manifest_path)
-    return sp / f"feats-{rank}", mp.parent / f"{mp.name.split('.')[0]}-{rank}.jsonl.gz"
+    stem = mp.name
+    for ext in (".jsonl.gz", ".jsonl", ".json.gz", ".json", ".yaml.gz", ".yaml", ".yml"):  # only the manifest extension goes:
+        if stem.endswith(ext):  # "cuts.train.jsonl.gz" and "cuts.dev.jsonl.gz" in one directory must not share shard manifests
+            stem = stem[: -len(ext)]
+            break
+    return sp / f"feats-{rank}", mp.parent / f"{stem}-{rank}.jsonl.gz"
 
 
 def combine_shard_manifests(cuts, manifest_path, shard_manifests: Sequence, owner) -> "object":

@@ -82,9 +82,14 @@ class _ArchiveWriterImpl:
     def write_packed(self, matrix: np.ndarray, frames: Sequence[int]) -> List[str]:
         """Append the packed ``(sum(frames), F)`` matrix of a batch with ONE write; returns one key per item.  A matrix that already
         has the archive's dtype (the driver converts to binary16 on the device) is written as it is."""
-        matrix = np.ascontiguousarray(matrix, dtype=self.np_dtype)
+        with np.errstate(over="ignore"):
+            matrix = np.ascontiguousarray(matrix, dtype=self.np_dtype)
         cols = int(matrix.shape[1])
         item, tag = matrix.dtype.itemsize, (":f16" if matrix.dtype.itemsize == 2 else "")
+        if item == 2 and matrix.size and int((matrix.view(np.uint16) & 0x7FFF).max()) >= 0x7C00:
+            # binary16 tops out at 65504: log-domain features (|x| < 32) are far inside, linear-domain ones (power spectra, energies) are not
+            raise ValueError(f"{self.name}: the batch holds values that are not finite in binary16 (|x| > 65504, inf or nan); this storage is "
+                             "meant for log-domain features -- use 'hip_archive' (float32) for linear-domain ones")
         assert int(sum(frames)) == matrix.shape[0], (sum(frames), matrix.shape)
         with self._lock:
             base = self._offset
@@ -161,7 +166,10 @@ if HAVE_LHOTSE:
     class HipArchiveF16Writer(_ArchiveWriterImpl, FeaturesWriter):
         """``"hip_archive_f16"``: the same archive with binary16 rows -- half the file, and with the Hip* extractors half the
         device -> host traffic (the batch driver converts on the device).  Lossy like the reference's default lilcom storage: log-domain
-        features (|x| < 32) keep 2^-6 ... 2^-7 absolute, the error of the lilcom fixture the reference ships."""
+        features (|x| < 32) keep 2^-6 ... 2^-7 absolute, the error of the lilcom fixture the reference ships.  NOT for linear-domain
+        features: binary16 overflows above 65504 and flushes below 6e-8, so power spectra / unlogged energies would be stored as inf or 0.
+        ``write`` / ``write_packed`` raise on values that are not finite in binary16, and the batch driver refuses the combination of
+        this storage with a non-log extractor (``HipSpectrogram``) up front."""
 
         name = "hip_archive_f16"
         np_dtype = "<f2"
@@ -397,6 +405,9 @@ def compute_and_store_features_batch(
     from collections import deque
 
     futures = deque()
+    if getattr(storage_type, "np_dtype", "<f4") == "<f2" and not getattr(extractor, "log_domain", True):
+        raise ValueError(f"storage '{storage_type.name}' keeps binary16 rows, which cannot hold the linear-domain output of '{extractor.name}' "
+                         "(overflow above 65504, flush to zero below 6e-8): use 'hip_archive'")
     with manifest, storage_type(storage_path, mode="w" if overwrite else "a") as writer, ThreadPoolExecutor(max_workers=1) as saver:
         template = None
         for batch in loader:

@@ -99,7 +99,9 @@ def test_no_gpu_means_loud_failure_not_fallback():
 
 def test_to_device_and_frame_count_contract():
     ex = LA.HipFbank()
+    ex.__dict__["_pipeline"] = object()  # a host pipeline built for the previous device (its streams live there)
     assert ex.to("cuda:1") is ex and ex.config.device == "cuda:1"
+    assert "_pipeline" not in ex.__dict__ and ex._plan is None and ex._staging is None
     # lhotse/utils.py:424-434 -- validate_features asserts this on every stored matrix
     for s in (140, 159, 160, 16000, 160000, 100050):
         assert compat.compute_num_frames_from_samples(s, 0.01, 16000) == (s + 80) // 160

@@ -146,3 +146,23 @@ def test_float_to_half_on_the_device_and_the_half_pipeline(many_chunks):
     f16, frames16 = ex._host_items_to_host(waves, None, half=True)
     assert f16.dtype == torch.float16 and np.array_equal(frames, frames16)
     assert torch.equal(f16, f32.to(torch.float16))
+
+
+def test_moving_the_extractor_rebuilds_the_pipeline(many_chunks):
+    """`to()` dropped the plan but kept the cached pipeline, whose side streams (and events) belong to the device the
+    extractor was on before -- compute_and_store_features_sharded does exactly `extractor.to(f"cuda:{LOCAL_RANK}")` after a warm-up.
+    (One GPU per box: the move is to the same index under another spelling; what is checked is that the pipeline goes with the plan.)"""
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cuda"))
+    waves = _waves(11, 24)
+    first = [np.asarray(o) for o in ex.extract_batch(waves, 16000)]
+    pipe0 = ex.__dict__["_pipeline"]
+    ex.to("cuda:0")
+    assert "_pipeline" not in ex.__dict__ and ex._plan is None
+    again = [np.asarray(o) for o in ex.extract_batch(waves, 16000)]
+    pipe1 = ex.__dict__["_pipeline"]
+    assert pipe1 is not pipe0 and pipe1.device == ex.plan.device
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    # a pipeline left over for another device is never used (belt and braces behind _drop_plan)
+    ex.__dict__["_pipeline"] = type("P", (), {"device": torch.device("cuda", 7)})()
+    assert ex._pipe().device == ex.plan.device

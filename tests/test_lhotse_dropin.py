@@ -451,6 +451,19 @@ def test_half_precision_archive(tmp_path, cutset, cpu_device):
         assert np.abs(x - y).max() <= 2.0 ** -6
         assert np.array_equal(a.features.load(start=a.start + 0.2, duration=0.3), x[20:50])
     assert os.path.getsize(half[0].features.storage_path) * 2 == os.path.getsize(full[0].features.storage_path)
+    # binary16 holds log-domain features only -- a linear-domain extractor is refused up front, and values that are not finite
+    # in binary16 (|x| > 65504) never reach the file
+    with pytest.raises(ValueError, match="linear-domain output of 'hip-spectrogram'"):
+        LA.compute_and_store_features_batch(cutset, extractor=LA.HipSpectrogram(), storage_path=tmp_path / "bad", manifest_path=tmp_path / "bad.jsonl.gz",
+                                            batch_duration=3.0, num_workers=0, storage_type=LA.HipArchiveF16Writer)
+    with LA.HipArchiveF16Writer(tmp_path / "range") as w:
+        ok = w.write("a", np.float32([[65504.0, -65504.0, 1e-9]]))
+        with pytest.raises(ValueError, match="not finite in binary16"):
+            w.write("b", np.float32([[1.0, 7e4, 0.0]]))
+        with pytest.raises(ValueError, match="not finite in binary16"):
+            w.write_packed(np.float16([[np.inf, 0.0]]), [1])
+        assert w.write("c", np.float32([[2.0, 3.0, 4.0]])) == "6:1:3:f16"  # the refused batches left nothing behind
+    assert ok == "0:1:3:f16"
 
 
 LAYER_PAIRS = [("HipWav2Spec", "Wav2Spec"), ("HipWav2LogSpec", "Wav2LogSpec"), ("HipWav2LogFilterBank", "Wav2LogFilterBank"), ("HipWav2MFCC", "Wav2MFCC")]
@@ -541,8 +554,12 @@ def test_on_the_fly_features_with_speed_perturbed_cuts(cutset, cpu_device, monke
     # switched off, or with wave transforms, the reference's own loading path is taken
     f2, l2 = LA.HipOnTheFlyFeatures(LA.HipFbank(LA.HipFbankConfig(edge_rule="batch_zero_pad")), gpu_speed_perturb=False)(mixed)
     assert calls["raw"] == 12 and torch.equal(l2, ref_l) and torch.allclose(f2, ref_f, atol=2e-3)
-    with pytest.raises(ValueError, match="gpu_speed_perturb=False"):
-        LA.HipOnTheFlyFeatures(LA.HipFbank(), wave_transforms=[lambda x: x])(mixed)
+    # wave_transforms run on the LOADED samples: by default (gpu_speed_perturb=None) the strategy then behaves like the reference one
+    # (CPU Speed inside load_audio, then the transforms) -- what worked with OnTheFlyFeatures keeps working
+    f3, l3 = LA.HipOnTheFlyFeatures(LA.HipFbank(LA.HipFbankConfig(edge_rule="batch_zero_pad")), wave_transforms=[lambda x: x])(mixed)
+    assert calls["raw"] == 12 and torch.equal(l3, ref_l) and torch.allclose(f3, ref_f, atol=2e-3)
+    with pytest.raises(ValueError, match="gpu_speed_perturb=True was requested together with wave_transforms"):  # only the explicit contradiction
+        LA.HipOnTheFlyFeatures(LA.HipFbank(), wave_transforms=[lambda x: x], gpu_speed_perturb=True)(mixed)
     # cuts whose recording carries anything but exactly one Speed are not touched
     assert IS.deferred_speed_factor(list(cutset)[0]) is None
     assert IS.deferred_speed_factor(list(cutset.perturb_speed(1.1).perturb_volume(2.0))[0]) is None

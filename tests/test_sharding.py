@@ -129,31 +129,96 @@ def test_marker_file_rendezvous_meets_fails_fast_and_cleans_up(tmp_path, monkeyp
     monkeypatch.delenv("MASTER_ADDR", raising=False)
     monkeypatch.delenv("MASTER_PORT", raising=False)
     monkeypatch.setenv("HIPFEAT_RUN_ID", "run-a")
-    a, b = _Rendezvous(tmp_path, 0, 2, 5.0), _Rendezvous(tmp_path, 1, 2, 5.0)
-    b.seq = a.seq  # (one process per rank in real life: the n-th call of every rank carries the same number)
-    assert a.dist is None and b.dist is None
+    a, b = _Rendezvous(tmp_path, 0, 2, 5.0, seq=1), _Rendezvous(tmp_path, 1, 2, 5.0, seq=1)
+    assert a.dist is None and b.dist is None and a.nonce and b.nonce is None
     t = threading.Thread(target=lambda: (time.sleep(0.2), b.barrier("extracted")))
     t.start()
     t0 = time.time()
     a.barrier("extracted")
     t.join()
-    assert 0.15 < time.time() - t0 < 3.0
+    assert 0.15 < time.time() - t0 < 3.0 and b.nonce == a.nonce
     a.close(), b.close()
     assert not list(tmp_path.glob(".extracted-*"))  # every rank removed its marker of the first barrier
     # markers of an earlier run ("run-a") do not satisfy a new one
     monkeypatch.setenv("HIPFEAT_RUN_ID", "run-b")
-    c = _Rendezvous(tmp_path, 0, 2, 0.3)
-    (tmp_path / f".extracted-run-a-{c.seq}-1").write_text("done")
+    c = _Rendezvous(tmp_path, 0, 2, 0.3, seq=1)
+    (tmp_path / f".extracted-run-a-1-{a.nonce}-1").write_text("done")
     with pytest.raises(TimeoutError, match=r"ranks \[1\] did not reach 'extracted'"):
         c.barrier("extracted")
     # a failing rank releases the others immediately
-    d, e = _Rendezvous(tmp_path, 0, 2, 30.0), _Rendezvous(tmp_path, 1, 2, 30.0)
-    e.seq = d.seq
+    d, e = _Rendezvous(tmp_path, 0, 2, 30.0, seq=2), _Rendezvous(tmp_path, 1, 2, 30.0, seq=2)
     threading.Thread(target=lambda: (time.sleep(0.2), e.failed())).start()
     t0 = time.time()
     with pytest.raises(RuntimeError, match=r"ranks \[1\] failed before 'combined'"):
         d.barrier("combined")
     assert time.time() - t0 < 5.0
+
+
+def test_marker_file_rendezvous_survives_a_repeated_run_token(tmp_path, monkeypatch):
+    """the token falls back to the parent pid, so a re-run from the same shell (the advertised per-shard resume) meets the
+    leftovers of the run before it: a `failed` marker that used to fail every retry at once, `combined` markers that let a rank run
+    through the second barrier on its own and strand the other one until the timeout.  With the per-launch nonce they are inert."""
+    import threading
+    import time
+
+    from lhotse_amd.sharding import _Rendezvous
+
+    monkeypatch.delenv("MASTER_ADDR", raising=False)
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    monkeypatch.delenv("HIPFEAT_RUN_ID", raising=False)  # -> ppid, the same for both "launches" of this test
+
+    def launch(fail_rank=None, late=(1,)):
+        """One launch of two ranks (threads); the ranks in `late` start 0.3 s after the others, i.e. they find the other's fresh files and
+        the other finds only THEIR stale ones.  Returns per-rank outcome."""
+        out = {}
+
+        def rank_main(r):
+            try:
+                if r in late:
+                    time.sleep(0.3)
+                m = _Rendezvous(tmp_path, r, 2, 10.0, seq=1)
+                try:
+                    if r == fail_rank:
+                        raise ValueError("boom")
+                    m.barrier("extracted")
+                    m.barrier("combined")
+                except BaseException:
+                    m.failed()
+                    raise
+                finally:
+                    m.close()
+                out[r] = "ok"
+            except BaseException as e:  # noqa: BLE001
+                out[r] = type(e).__name__
+
+        ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+        t0 = time.time()
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        return out, time.time() - t0
+
+    out, dt = launch(fail_rank=1)           # launch 1 fails on rank 1: rank 0 is released at once ...
+    assert out == {0: "RuntimeError", 1: "ValueError"} and dt < 5.0
+    assert list(tmp_path.glob(".failed-*-1"))  # ... and the failed marker stays behind
+    out, dt = launch()                      # launch 2, same token: the stale `failed` marker does not fail it
+    assert out == {0: "ok", 1: "ok"} and dt < 5.0
+    assert list(tmp_path.glob(".combined-*"))  # its `combined` markers stay behind (a slower rank may still be polling them)
+    for late in ((1,), (0,)):               # launches 3 and 4: nobody runs through a barrier on the strength of stale markers, whoever is first
+        out, dt = launch(late=late)
+        assert out == {0: "ok", 1: "ok"} and 0.25 < dt < 5.0
+    # the leftovers do not pile up: one hello per rank, one nonce, the `combined` markers of the last launch
+    names = sorted(p.name.split("-")[0] for p in tmp_path.iterdir())
+    assert names == [".combined", ".combined", ".hello", ".hello", ".nonce"], names
+
+
+def test_shard_manifests_keep_the_whole_stem(tmp_path):
+    """`cuts.train.jsonl.gz` and `cuts.dev.jsonl.gz` in one directory must not map to the same shard manifests."""
+    a = S.shard_paths(tmp_path / "feats", tmp_path / "cuts.train.jsonl.gz", 1)
+    b = S.shard_paths(tmp_path / "feats", tmp_path / "cuts.dev.jsonl.gz", 1)
+    assert a[1].name == "cuts.train-1.jsonl.gz" and b[1].name == "cuts.dev-1.jsonl.gz" and a[0].name == "feats-1"
+    assert S.shard_paths(tmp_path, tmp_path / "cuts.jsonl.gz", 0)[1].name == "cuts-0.jsonl.gz"  # (what the drivers' tests rely on)
+    assert S.shard_paths(tmp_path, tmp_path / "cuts.jsonl", 3)[1].name == "cuts-3.jsonl.gz"
 
 
 @pytest.mark.parametrize("mode,why", [("no-gpus", "fewer GPUs than ranks"), ("rccl-raises", "RCCL initialisation failed")])
