@@ -171,55 +171,66 @@ def load_profile_constants(kernel_name: str):
 
 
 def compare(got, want, truth, log_mel=True):
-    """Error figures of one cut: rel_l2 / max_abs vs the float32 oracle, values inside rtol 1e-4 + atol 1e-3, and BOTH float32
-    implementations against the float64 oracle (max and mean square), so that an element-wise number can be read in context."""
-    import numpy as np
+    """Error figures of one cut (oracle/parity_bar.py::figures -- the checker's module, imported by the parity leg only)."""
+    from oracle import parity_bar
 
-    d = np.abs(got.astype(np.float64) - want)
-    fl = np.abs(want.astype(np.float64) - truth)
-    own = np.abs(got.astype(np.float64) - truth)
-    return {
-        "rel": float(np.linalg.norm(got - want) / np.linalg.norm(want)),
-        "abs": float(d.max()),
-        "within": int((d <= 1e-3 + 1e-4 * np.abs(want)).sum()),
-        "total": int(d.size),
-        "floor_rel": float(np.linalg.norm(want - truth) / np.linalg.norm(truth)),
-        "floor_abs": float(fl.max()),
-        "own_abs": float(own.max()),
-        "floor_sq": float((fl ** 2).sum()),
-        "own_sq": float((own ** 2).sum()),
-        # the elements behind a max_abs above the suite's bar: how many, and how far above log(mel floor) the largest of them sits
-        # the same comparison in the LINEAR domain with the reference's own floor constant as absolute tolerance: the reference clamps
-        # every mel energy at eps = 1.19e-7 (layers.py:536-538, 577), i.e. treats differences below eps as nothing
-        "lin_bad": (int((np.abs(np.exp(got.astype(np.float64)) - np.exp(want.astype(np.float64))) > 1e-4 * np.exp(want.astype(np.float64)) + 1.1920929e-07).sum())
-                    if log_mel else 0),
-        "over": int((d > 2e-3).sum()),
-        "over_ref_max": float(want[d > 2e-3].max()) if bool((d > 2e-3).any()) else None,
-    }
+    return parity_bar.figures(got, want, truth, log_mel=log_mel)
 
 
 def fold(stats):
-    n = max(1, sum(s["total"] for s in stats))
-    return {
-        "rel_l2_max": max(s["rel"] for s in stats),
-        "max_abs_max": max(s["abs"] for s in stats),
-        "frac_within": sum(s["within"] for s in stats) / n,
-        "n": len(stats),
-        "oracle_f32_vs_f64_rel_l2_max": max(s["floor_rel"] for s in stats),
-        "oracle_f32_vs_f64_max_abs": max(s["floor_abs"] for s in stats),
-        "hip_vs_f64_max_abs": max(s["own_abs"] for s in stats),
-        "oracle_f32_vs_f64_rms": (sum(s["floor_sq"] for s in stats) / n) ** 0.5,
-        "hip_vs_f64_rms": (sum(s["own_sq"] for s in stats) / n) ** 0.5,
-        "lin_bad": sum(max(s["lin_bad"], 0) for s in stats),
-        "n_over_2e-3": sum(s["over"] for s in stats),
-        "over_ref_value_max": max([s["over_ref_max"] for s in stats if s["over_ref_max"] is not None], default=None),
-        "n_values": n,
-    }
+    from oracle import parity_bar
+
+    return parity_bar.fold(stats)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------------------------
+FILL_CHUNK = 500  # cuts per uniform_() call: part of the definition of the synthetic input (the generator's stream position)
+
+
+def fbank16k_fill(wave, seed: int, first: int = 0) -> None:
+    """The synthetic input of the headline workload: rows of U(-0.5, 0.5) from ONE device generator stream, FILL_CHUNK cuts per draw.
+    `first` = global index of wave[0] (a multiple of FILL_CHUNK): the stream is advanced past the rows in front of it, so that any
+    window of the 10 000-cut input can be regenerated (tests/test_gpu_parity.py re-creates the cuts the in-run parity leg samples)."""
+    import torch
+
+    assert first % FILL_CHUNK == 0
+    g = torch.Generator(device=wave.device).manual_seed(seed)
+    if first:
+        scratch = torch.empty((FILL_CHUNK, wave.shape[1]), dtype=torch.float32, device=wave.device)
+        for _ in range(first // FILL_CHUNK):
+            scratch.uniform_(-0.5, 0.5, generator=g)
+    for i in range(0, wave.shape[0], FILL_CHUNK):
+        wave[i : i + FILL_CHUNK].uniform_(-0.5, 0.5, generator=g)
+
+
+def fbank16k_fill_shard(wave, seed: int, total: int, rank: int, world: int) -> None:
+    """Rank `rank`'s rows of ONE global corpus of `total` cuts (global cut i = row i of the `fbank16k_fill` stream of `seed`): the cuts
+    rank, rank + world, ...  Every rank draws the whole stream chunk by chunk and keeps its own rows, so N = 1 and N = 8 extract the
+    same `total` cuts (and N = 1 holds exactly the rows of `fbank16k_fill`)."""
+    import torch
+
+    g = torch.Generator(device=wave.device).manual_seed(seed)
+    scratch = torch.empty((FILL_CHUNK, wave.shape[1]), dtype=torch.float32, device=wave.device)
+    row = 0
+    for base in range(0, total, FILL_CHUNK):
+        n = min(FILL_CHUNK, total - base)
+        scratch.uniform_(-0.5, 0.5, generator=g)  # always a whole chunk: the stream does not depend on where the corpus ends
+        sel = scratch[(rank - base) % world : n : world]
+        wave[row : row + sel.shape[0]] = sel
+        row += sel.shape[0]
+    assert row == wave.shape[0], (row, wave.shape)
+
+
+def fbank16k_parity_indices(cuts: int, rank: int):
+    """The cuts of the timed output buffer that the in-run parity leg compares with the oracle."""
+    import numpy as np
+
+    rs = np.random.RandomState(4321 + rank)
+    return np.sort(rs.choice(cuts, size=min(PARITY_CUTS, cuts), replace=False))
+
+
 class Fbank16k:
     """BASELINE configs[1]."""
 
@@ -236,14 +247,20 @@ class Fbank16k:
         from lhotse_amd import _lib
 
         self.torch, self.np = torch, np
-        C = self.C = args.cuts or self.default_cuts
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        total = int(getattr(args, "total_cuts", 0) or 0)
+        # --total-cuts T (BASELINE configs[2] as written: T cuts SHARDED over the ranks): rank r takes the cuts r, r + W, ... of ONE global
+        # synthetic corpus, as CutSet.compute_and_store_features shards with LazySlicer(k=r, n=W) (lhotse/cut/set.py:2158-2160)
+        C = self.C = len(range(rank, total, world)) if total else (args.cuts or self.default_cuts)
+        assert C > 0, "fewer cuts than ranks"
         self.ex = lhotse_amd.HipFbank(lhotse_amd.HipFbankConfig(device=f"cuda:{dev.index}"))
         self.plan = self.ex.plan
         L = self.L = self.plan.lib
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
         self.wave = torch.empty((C, SAMPLES_PER_CUT), dtype=torch.float32, device=dev)
-        for i in range(0, C, 500):
-            self.wave[i : i + 500].uniform_(-0.5, 0.5, generator=g)
+        if total:
+            fbank16k_fill_shard(self.wave, 1234, total, rank, world)
+        else:
+            fbank16k_fill(self.wave, 1234 + rank)
         if args.input == "zeros":
             self.wave.zero_()
         elif args.input == "sine":
@@ -263,6 +280,10 @@ class Fbank16k:
         self.kernel = self.plan.kernel_name
         self.workload = (f"BASELINE configs[1]: {C} x 10 s 16 kHz mono cuts per GPU per step, 80-dim log-mel Fbank (25/10 ms, povey, no dither), "
                          "device-resident float32 in / float32 out")
+        if total:
+            self.workload = (f"BASELINE configs[2]: {total} x 10 s 16 kHz mono cuts in total per step, sharded round-robin over {world} GPU(s) "
+                             f"(rank r takes cuts r, r + {world}, ...: {C} on rank {rank}), 80-dim log-mel Fbank (25/10 ms, povey, no dither), "
+                             "device-resident float32 in / float32 out")
 
     def step(self):
         self.L.check("hipfeat_extract_layout", self.plan.handle, self.layout, self.wave.data_ptr(), self.out.data_ptr(), self.stream)
@@ -276,8 +297,7 @@ class Fbank16k:
         np = self.np
         chk = self.out[:FRAMES_PER_CUT].float()
         assert self.torch.isfinite(chk).all() and float(chk.std()) > 0.1
-        rs = np.random.RandomState(4321 + rank)
-        idx = np.sort(rs.choice(self.C, size=min(PARITY_CUTS, self.C), replace=False))
+        idx = fbank16k_parity_indices(self.C, rank)
         o32, o64 = RefExtractor(RefConfig(kind="fbank"), np.float32), RefExtractor(RefConfig(kind="fbank"), np.float64)
         stats = []
         for i in idx:
@@ -485,7 +505,215 @@ class OnTheFly:
         pass
 
 
-WORKLOADS = {w.name: w for w in (Fbank16k, Mfcc40Libri, OnTheFly)}
+class BulkSave:
+    """The offline path end to end on the GPU box (SURVEY 8d timing method iii; lhotse/cut/set.py:2307-2404): 600 s batches of HOST
+    waveforms -> the H2D / kernel / D2H pipeline (`_batch_features_on_host`) on the calling thread -> ONE background thread:
+    `write_packed` into the flat archive on tmpfs + one template manifest line per cut (gzip JSONL, flushed per batch), with the
+    back-pressure of `storage.pump_batches` -- the loop `compute_and_store_features_batch` runs, minus lhotse's loader and objects
+    (lhotse cannot travel to the GPU box; the manifest half is tested against the reference driver in tests/test_lhotse_dropin.py).
+    PCIe-, host- and file-system-inclusive: NOT a device-resident rate (the default config is)."""
+
+    name = "bulk_save"
+    host_bound = True
+    metric = "cuts/sec (10 s @16 kHz host waveforms -> 80-dim log-mel fbank -> hip_archive on tmpfs + manifests; PCIe- and host-inclusive)"
+    default_cuts = 32  # batches of 60 cuts (600 s) per step
+    cpu_mode, cpu_what = "", "Fbank"
+
+    def __init__(self, dev, rank, args):
+        import dataclasses
+        import tempfile
+
+        import numpy as np
+        import torch
+
+        import lhotse_amd
+        from lhotse_amd import storage as S
+
+        self.torch, self.np, self.S, self.dev, self.rank = torch, np, S, dev, rank
+        NB = self.NB = args.cuts or self.default_cuts
+        self.ex = lhotse_amd.HipFbank(lhotse_amd.HipFbankConfig(device=f"cuda:{dev.index}"))
+        self.plan = self.ex.plan
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        self.tmp = tempfile.TemporaryDirectory(prefix=f"hipfeat_bulk_r{rank}_", dir=base)
+        self.fs = "tmpfs (/dev/shm)" if base else "the default temporary directory"
+
+        @dataclasses.dataclass
+        class Sup:  # the JSON-scalar fields of a SupervisionSegment (lhotse/supervision.py:44-120)
+            id: str
+            recording_id: str
+            start: float
+            duration: float
+            channel: int = 0
+            text: str = None
+            language: str = None
+            speaker: str = None
+            gender: str = None
+            custom: dict = None
+            alignment: dict = None
+
+        @dataclasses.dataclass
+        class Src:
+            type: str
+            channels: list
+            source: str
+
+        @dataclasses.dataclass
+        class Rec:  # Recording (lhotse/audio/recording.py:59-120)
+            id: str
+            sources: list
+            sampling_rate: int
+            num_samples: int
+            duration: float
+            channel_ids: list = None
+            transforms: list = None
+
+        class Cut:  # what storage._mono_cut_dict reads off a MonoCut
+            __slots__ = ("id", "start", "duration", "channel", "recording_id", "supervisions", "custom", "recording", "sampling_rate")
+
+        g = torch.Generator().manual_seed(99 + rank)
+        pool = [(torch.rand(SAMPLES_PER_CUT, generator=g) - 0.5) for _ in range(64)]  # pageable float32, as a DataLoader hands them over
+        self.pool16 = [(x * 32767).to(torch.int16) for x in pool]
+        self.pool32 = pool
+        self.batches = []
+        n = 0
+        for b in range(NB):
+            cuts = []
+            for i in range(60):
+                c = Cut()
+                c.id, c.start, c.duration, c.channel, c.recording_id, c.sampling_rate = f"cut-{rank}-{n:07d}", 0.0, 10.0, 0, f"rec-{rank}-{n:07d}", SR
+                c.supervisions = [Sup(id=c.id, recording_id=c.recording_id, start=0.0, duration=10.0, text="SYNTHETIC UTTERANCE " * 4, language="English", speaker=f"spk{n % 251}")]
+                c.custom = {"dataloading_info": {"rank": 0, "world_size": 1, "worker_id": None}}  # what lhotse's sampler attaches (sampling/base.py:473-487)
+                c.recording = Rec(id=c.recording_id, sources=[Src("file", [0], f"/data/corpus/{c.recording_id}.flac")], sampling_rate=SR,
+                                  num_samples=SAMPLES_PER_CUT, duration=10.0, channel_ids=[0])
+                cuts.append(c)
+                n += 1
+            self.batches.append((cuts, [(b * 60 + i) % 64 for i in range(60)]))
+        self.units = n
+        self.audio_seconds = 10.0 * n
+        self.algo_bytes = ALGO_BYTES_PER_CUT * n
+        self.kernel = self.plan.kernel_name
+        self.stats = {}
+        self.variant = ("float32", "hip_archive")
+        self.workload = (f"SURVEY 8d(iii) offline path: {NB} batches of 60 x 10 s (600 s) pageable float32 host waveforms per GPU per step -> chunked H2D / "
+                         f"fft512c / D2H pipeline -> background save thread: write_packed into a 'hip_archive' on {self.fs} + one template MonoCut manifest "
+                         "line per cut (gzip JSONL, flush per batch), back-pressure of 8 batches -- compute_and_store_features_batch's loop without lhotse's loader")
+        self._run_id = 0
+
+    def _one_pass(self, dtype: str, storage: str, stats: dict):
+        import gzip
+        import json
+        import time
+
+        S = self.S
+        wcls = S.HipArchiveF16Writer if storage == "hip_archive_f16" else S.HipArchiveWriter
+        half = getattr(wcls, "np_dtype", "<f4") == "<f2"
+        pool = self.pool16 if dtype == "int16" else self.pool32
+        self._run_id += 1
+        root = os.path.join(self.tmp.name, f"run{self._run_id}")
+        os.makedirs(root)
+        rec_cache = {}
+        frame_shift = self.ex.frame_shift
+        save_busy = [0.0, 0, 0]  # seconds, archive bytes, manifest lines
+
+        with wcls(os.path.join(root, "feats"), mode="w") as writer, gzip.open(os.path.join(root, "cuts.jsonl.gz"), "wt") as manifest:
+            template = {"type": self.ex.name, "num_features": NUM_MELS, "frame_shift": frame_shift, "sampling_rate": SR,
+                        "storage_type": writer.name, "storage_path": str(writer.storage_path)}
+
+            def extract(batch):
+                cuts, idx = batch
+                host, frames = S._batch_features_on_host(self.ex, [pool[i] for i in idx], SR, None, half=half)
+                return cuts, host, frames
+
+            def save(cuts, host, frames):
+                t0 = time.perf_counter()
+                for c, t in zip(cuts, frames):  # the frame-count contract of validate_features (lhotse/qa.py:286-301)
+                    if (int(round(c.duration * SR)) + 80) // 160 != t:
+                        raise AssertionError(f"cut {c.id}: {t} frames")
+                keys = writer.write_packed(host, frames)
+                for c, t, k in zip(cuts, frames, keys):
+                    d = S._mono_cut_dict(c, S._features_dict(template, c, t, k), rec_cache)
+                    manifest.write(json.dumps(d) + "\n")
+                writer.flush()
+                manifest.flush()
+                save_busy[0] += time.perf_counter() - t0
+                save_busy[1] = os.path.getsize(writer.storage_path)  # (flushed above)
+                save_busy[2] += len(cuts)
+
+            S.pump_batches(self.batches, extract, save, stats=stats)
+        stats["save_s"] = stats.get("save_s", 0.0) + save_busy[0]
+        stats["archive_bytes"] = stats.get("archive_bytes", 0) + save_busy[1]
+        stats["manifest_lines"] = stats.get("manifest_lines", 0) + save_busy[2]
+        stats["manifest_bytes"] = stats.get("manifest_bytes", 0) + os.path.getsize(os.path.join(root, "cuts.jsonl.gz"))
+        self.last_root = root
+        return root
+
+    def _drop(self, root):
+        import shutil
+
+        shutil.rmtree(root, ignore_errors=True)
+
+    def step(self):
+        prev = getattr(self, "last_root", None)
+        self._one_pass(*self.variant, self.stats)
+        if prev:
+            self._drop(prev)
+
+    def clear(self):
+        self.stats.clear()
+
+    def parity(self, rank):
+        """What the last timed pass stored, read back through the archive reader, against the oracle."""
+        import gzip
+        import json
+
+        from oracle.kaldi_ref import RefConfig, RefExtractor
+
+        np, S = self.np, self.S
+        o32, o64 = RefExtractor(RefConfig(kind="fbank"), np.float32), RefExtractor(RefConfig(kind="fbank"), np.float64)
+        with gzip.open(os.path.join(self.last_root, "cuts.jsonl.gz"), "rt") as f:
+            lines = [json.loads(ln) for ln in f]
+        assert len(lines) == self.units and [d["id"] for d in lines[:3]] == [c.id for c in self.batches[0][0][:3]]
+        reader = S.HipArchiveReader(lines[0]["features"]["storage_path"])
+        rs = np.random.RandomState(4321 + rank)
+        stats = []
+        flat = [i for _, idx in self.batches for i in idx]
+        for j in rs.choice(self.units, size=min(PARITY_CUTS, self.units), replace=False):
+            d = lines[int(j)]
+            assert d["features"]["num_frames"] == FRAMES_PER_CUT and d["features"]["storage_type"] == "hip_archive"
+            got = reader.read(d["features"]["storage_key"])
+            x = self.pool32[flat[int(j)]].numpy()
+            stats.append(compare(got, o32.extract(x), o64.extract(x)))
+        return fold(stats)
+
+    def extra(self, args):
+        """The other entry forms / storages, one pass each, with the stage split of every variant."""
+        import time
+
+        out = {}
+        for dtype, storage in (("float32", "hip_archive"), ("int16", "hip_archive"), ("float32", "hip_archive_f16"), ("int16", "hip_archive_f16")):
+            self._drop(self._one_pass(dtype, storage, {}))  # warm
+            st = {}
+            t0 = time.perf_counter()
+            for _ in range(3):
+                self._drop(self._one_pass(dtype, storage, st))
+            dt = time.perf_counter() - t0
+            cuts = 3 * self.units
+            out[f"{dtype}->{storage}"] = {
+                "cuts_per_s": round(cuts / dt, 1), "archive_MB_per_s": round(st["archive_bytes"] / dt / 1e6, 1),
+                "manifest_bytes_per_cut": round(st["manifest_bytes"] / cuts, 1),
+                "main_thread_extract_share": round(st["extract_s"] / dt, 3), "main_thread_blocked_on_save_share": round(st["wait_s"] / dt, 3),
+                "save_thread_busy_share": round(st["save_s"] / dt, 3),
+                "binds": "save thread (archive write + manifests)" if st["save_s"] > st["extract_s"] else "extraction (pack + PCIe pipeline)",
+            }
+        out["what"] = ("3 passes per variant after one warm-up; shares are of wall time: the calling thread extracts (pack to pinned + H2D + kernel + D2H), "
+                       "ONE background thread writes the archive and the manifest lines; the larger share binds")
+        return {"bulk_save": out}
+
+    def close(self):
+        self.tmp.cleanup()
+
+
+WORKLOADS = {w.name: w for w in (Fbank16k, Mfcc40Libri, OnTheFly, BulkSave)}
 
 
 def host_fed(ex, seconds: float = 2.0):
@@ -617,8 +845,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default per config: >= 1 s of GPU time)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="fbank16k", choices=sorted(WORKLOADS), help="fbank16k = BASELINE configs[1] (default), mfcc40_libri = configs[3], onthefly = configs[4]")
+    ap.add_argument("--config", default="fbank16k", choices=sorted(WORKLOADS), help="fbank16k = BASELINE configs[1] (default), mfcc40_libri = configs[3], onthefly = configs[4], bulk_save = the offline path end to end (SURVEY 8d iii)")
     ap.add_argument("--cuts", type=int, default=0, help="cuts per GPU per step (onthefly: mini-batches per step); default per config")
+    ap.add_argument("--total-cuts", type=int, default=0, help="fbank16k only: STRONG scaling (BASELINE configs[2]: 100000): this many cuts in total per step, "
+                    "sharded round-robin over the ranks (same global corpus for every N); default 0 = weak scaling, --cuts per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -628,7 +858,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default; falls back to gloo if it cannot be initialised) or gloo (self-test of the N>1 path on one GPU)")
     args = ap.parse_args()
     if not args.steps:
-        args.steps = {"fbank16k": 250, "mfcc40_libri": 200, "onthefly": 60}[args.config]
+        args.steps = {"fbank16k": 250, "mfcc40_libri": 200, "onthefly": 60, "bulk_save": 5}[args.config]
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)  # does not return
@@ -651,6 +881,8 @@ def main():
         dist, backend_used = init_dist(args.dist_backend, dev)
     cdev = dev if (dist is not None and backend_used == "nccl") else torch.device("cpu")  # where collective tensors live
 
+    if args.total_cuts and args.config != "fbank16k":
+        ap.error("--total-cuts is defined for --config fbank16k")
     w = WORKLOADS[args.config](dev, rank, args)
 
     def barrier():
@@ -673,6 +905,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    if getattr(w, "host_bound", False):  # the step runs on side streams and host threads: the events on this stream see none of it
+        launch_ms = elapsed / args.steps * 1e3
     rank_launch_ms = [launch_ms]
     units_total, audio_total = float(w.units), float(w.audio_seconds)
     if dist is not None:
@@ -692,41 +926,46 @@ def main():
         par = w.parity(rank)
         if dist is not None:
             keys = ["rel_l2_max", "max_abs_max", "oracle_f32_vs_f64_rel_l2_max", "oracle_f32_vs_f64_max_abs", "hip_vs_f64_max_abs",
-                    "oracle_f32_vs_f64_rms", "hip_vs_f64_rms"]
+                    "oracle_f32_vs_f64_rms", "hip_vs_f64_rms", "lin_margin_max"]
             mx = torch.tensor([par[k] for k in keys] + [-par["frac_within"]], dtype=torch.float64, device=cdev)
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            cnt = torch.tensor([float(par["n"])], dtype=torch.float64, device=cdev)
+            cnt = torch.tensor([float(par["n"]), float(par["lin_bad"]), float(par["n_over_2e-3"]), float(par["n_values"])], dtype=torch.float64, device=cdev)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
             local = par
             par = {k: float(v) for k, v in zip(keys, mx[:-1])}
-            par.update(frac_within=-float(mx[-1]), n=int(cnt.item()))
-            par.update({k: local[k] for k in ("n_over_2e-3", "over_ref_value_max", "n_values", "lin_bad")})  # (rank 0's own sample)
-        # element-wise bar: the suite's 2e-3 (log units), or 3 x the reference arithmetic's OWN float32 error against float64 on the same
-        # cuts where that is larger -- measured the same way for both (each against the float64 oracle), DESIGN section 2
-        abs_bar = max(2e-3, 3.0 * par["oracle_f32_vs_f64_max_abs"])
-        ok_rel = bool(par["rel_l2_max"] <= 1e-4)
-        ok_abs = bool(par["hip_vs_f64_max_abs"] <= abs_bar)
+            par.update(frac_within=-float(mx[-1]), n=int(cnt[0].item()), lin_bad=int(cnt[1].item()))
+            par.update({"n_over_2e-3": int(cnt[2].item()), "n_values": int(cnt[3].item()), "over_ref_value_max": local["over_ref_value_max"]})  # (the last one: rank 0's own sample)
+        # the ONE parity statement of the repository (oracle/parity_bar.py; the GPU suite enforces the same three clauses on the same inputs)
+        from oracle import parity_bar
+
+        v = parity_bar.verdict(par)
         parity = {
             "rel_l2_max": float(f"{par['rel_l2_max']:.3e}"),
             "max_abs_max": float(f"{par['max_abs_max']:.3e}"),
             "hip_vs_f64_max_abs": float(f"{par['hip_vs_f64_max_abs']:.3e}"),
             "oracle_f32_vs_f64_max_abs": float(f"{par['oracle_f32_vs_f64_max_abs']:.3e}"),
-            "max_abs_bar": float(f"{abs_bar:.3e}"),
+            "elementwise_bar": float(f"{v['elementwise_bar']:.3e}"),
+            "K_measured": round(v["K_measured"], 2),
+            "K_allowed": v["K_allowed"],
             "hip_vs_f64_rms": float(f"{par['hip_vs_f64_rms']:.3e}"),
             "oracle_f32_vs_f64_rms": float(f"{par['oracle_f32_vs_f64_rms']:.3e}"),
             "frac_within_rtol1e-4_atol1e-3": par["frac_within"],
             "values_over_2e-3": {"count": par["n_over_2e-3"], "of": par["n_values"], "largest_reference_value_among_them": par["over_ref_value_max"],
-                                 "log_mel_floor": -15.942385},  # elements over the bar sit within a few nats of the log(eps) clamp: DESIGN section 2
+                                 "log_mel_floor": -15.942385},  # elements over 2e-3 sit within a few nats of the log(eps) clamp: DESIGN section 2
             "linear_domain_outside_rtol1e-4_atol_eps": par["lin_bad"],  # values with |exp(hip) - exp(ref32)| > 1e-4 exp(ref32) + eps (the reference's own mel floor)
+            "linear_domain_worst_share_of_tolerance": round(par["lin_margin_max"], 4),  # max |exp(hip) - exp(ref32)| / (1e-4 exp(ref32) + eps)
             "n": par["n"],
             "oracle_f32_vs_f64_rel_l2_max": float(f"{par['oracle_f32_vs_f64_rel_l2_max']:.3e}"),
-            "pass_rel_l2": ok_rel,
-            "pass_max_abs": ok_abs,
-            "pass": bool(ok_rel and ok_abs),
-            "what": f"{PARITY_CUTS} cuts per rank sampled from the timed output buffer vs the oracle (float32 = the reference's arithmetic, float64 = truth); worst over "
-                    "all ranks; pass = rel_l2(hip, ref32) <= 1e-4 and max|hip - f64| <= max(2e-3, 3 x max|ref32 - f64|); max_abs_max = max|hip - ref32|",
+            "pass_rel_l2": v["pass_rel_l2"],
+            "pass_linear": v["pass_linear"],
+            "pass_elementwise": v["pass_elementwise"],
+            "pass": v["pass"],
+            "what": f"{PARITY_CUTS} cuts per rank sampled from the timed output buffer vs the oracle, worst over all ranks; max_abs_max = max|hip - ref32|; "
+                    + parity_bar.STATEMENT,
         }
-        assert ok_rel, parity  # the north star's tolerance; the element-wise verdict is reported, not asserted (it is a tail statistic)
+        # clauses (1) and (2) stop the run; clause (3) is a tail statistic of a maximum: it is reported in `pass` (and enforced on these
+        # very inputs by the GPU suite) rather than allowed to cost the driver its bench line
+        assert v["pass_rel_l2"] and v["pass_linear"], parity
 
     if rank == 0:
         value = units_total * args.steps / elapsed
@@ -742,7 +981,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_cuts else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -752,6 +991,8 @@ def main():
                 "cuts_per_gpu_per_step": w.units,
                 "audio_seconds_per_s": round(audio_total * args.steps / elapsed, 1),
                 "sharding": "cuts sharded across ranks, no data-path collective",
+                "scaling": (f"strong: {args.total_cuts} cuts in total per step, ceil(total / world) per rank" if args.total_cuts
+                            else "weak: the same number of cuts per GPU per step for every N"),
                 "kernel": w.kernel,
                 "world_size": world,
                 "dist_backend": None if dist is None else ("rccl" if backend_used == "nccl" else backend_used),
@@ -771,6 +1012,10 @@ def main():
                 "algorithmic_bytes_per_launch": w.algo_bytes,
             },
         }
+        if getattr(w, "host_bound", False):
+            res["roofline"]["note"] = ("host-, PCIe- and file-system-bound configuration: `achieved` is algorithmic feature-kernel bytes per wall second of the "
+                                       "whole step, not a kernel rate; the stage split is in extra")
+            res["data"] = "synthetic (host-resident waveforms: PCIe-inclusive)"
         ipf = prof.get("valu_instr_per_frame")
         if ipf:
             # every wave64 VALU instruction occupies its SIMD's issue port for >= 2 clk (packed f32 ones 3, measured:

@@ -321,6 +321,40 @@ def _batch_features_on_host(extractor, waves, sampling_rate: int, lengths, half:
     return (np.concatenate(mats, axis=0) if len(mats) != 1 else mats[0]), [int(m.shape[0]) for m in mats]
 
 
+def pump_batches(batches, extract, save, backlog: int = None, stats: Optional[Dict] = None) -> None:
+    """The loop of the batch driver (lhotse/cut/set.py:2365-2404): the calling thread runs ``extract(batch)`` -> arguments of ``save`` (or
+    None to skip the batch), ONE background thread runs ``save(*args)`` behind it.  At most ``backlog`` (_SAVE_BACKLOG) finished batches
+    wait for the save thread: each holds its page-locked result, and a failed save (disk full) stops the run at the next batch instead
+    of after the whole corpus (the reference collects its futures at the very end, cut/set.py:2400-2404).  ``stats`` (optional) receives
+    the seconds the calling thread spent extracting (``extract_s``) and blocked on the save thread (``wait_s``) -- bench.py's
+    ``--config bulk_save`` reads them to say which stage binds."""
+    import time
+    from collections import deque
+
+    backlog = _SAVE_BACKLOG if backlog is None else backlog
+    futures = deque()
+    t_ext = t_wait = 0.0
+    with ThreadPoolExecutor(max_workers=1) as saver:
+        for batch in batches:
+            t0 = time.perf_counter()
+            item = extract(batch)
+            t1 = time.perf_counter()
+            t_ext += t1 - t0
+            if item is None:
+                continue
+            futures.append(saver.submit(save, *item))
+            while len(futures) > backlog or (futures and futures[0].done()):
+                futures.popleft().result()
+            t_wait += time.perf_counter() - t1
+        t1 = time.perf_counter()
+        while futures:
+            futures.popleft().result()
+        t_wait += time.perf_counter() - t1
+    if stats is not None:
+        stats["extract_s"] = stats.get("extract_s", 0.0) + t_ext
+        stats["wait_s"] = stats.get("wait_s", 0.0) + t_wait
+
+
 def compute_and_store_features_batch(
     cuts,
     extractor,
@@ -400,32 +434,26 @@ def compute_and_store_features_batch(
         if getattr(manifest, "file", None) is not None:
             manifest.file.flush()  # one flush per batch
 
-    # At most _SAVE_BACKLOG batches wait for the save thread: each holds its page-locked result, and a failed save (disk full) stops the
-    # run at the next batch instead of after the whole corpus (the reference collects its futures at the very end, cut/set.py:2400-2404).
-    from collections import deque
-
-    futures = deque()
     if getattr(storage_type, "np_dtype", "<f4") == "<f2" and not getattr(extractor, "log_domain", True):
         raise ValueError(f"storage '{storage_type.name}' keeps binary16 rows, which cannot hold the linear-domain output of '{extractor.name}' "
                          "(overflow above 65504, flush to zero below 6e-8): use 'hip_archive'")
-    with manifest, storage_type(storage_path, mode="w" if overwrite else "a") as writer, ThreadPoolExecutor(max_workers=1) as saver:
-        template = None
-        for batch in loader:
+    with manifest, storage_type(storage_path, mode="w" if overwrite else "a") as writer:
+        state = {"template": None}
+
+        def extract(batch):
             batch_cuts, waves = batch["cuts"], batch["audio"]
             lens = batch["audio_lens"] if collate else None
             if len(batch_cuts) == 0:
-                continue
+                return None
             sr = batch_cuts[0].sampling_rate
             assert all(c.sampling_rate == sr for c in batch_cuts)
             if augment_fn is not None:
                 waves = [augment_fn(w, c.sampling_rate) for c, w in zip(batch_cuts, waves)]
             host, frames = _batch_features_on_host(extractor, waves, sr, lens, half=getattr(writer, "np_dtype", "<f4") == "<f2")
-            if template is None:
-                template = {"type": extractor.name, "num_features": int(host.shape[1]), "frame_shift": frame_shift, "sampling_rate": sr,
-                            "storage_type": writer.name, "storage_path": str(writer.storage_path)}
-            futures.append(saver.submit(save, writer, list(batch_cuts), host, frames, template))
-            while len(futures) > _SAVE_BACKLOG or (futures and futures[0].done()):
-                futures.popleft().result()
-        while futures:
-            futures.popleft().result()
+            if state["template"] is None:
+                state["template"] = {"type": extractor.name, "num_features": int(host.shape[1]), "frame_shift": frame_shift, "sampling_rate": sr,
+                                     "storage_type": writer.name, "storage_path": str(writer.storage_path)}
+            return writer, list(batch_cuts), host, frames, state["template"]
+
+        pump_batches(loader, extract, save)
     return manifest.open_manifest()

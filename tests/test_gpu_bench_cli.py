@@ -1,0 +1,47 @@
+"""GPU: bench.py's command line as the driver runs it -- the process-group leg on RCCL (one rank: all a 1-GPU box can show) and the
+strong-scaling form of BASELINE configs[2] (`--total-cuts`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags, env=None):
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-host-fed", *flags], capture_output=True, text=True,
+                       env=e, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line), r.stderr
+
+
+def test_the_process_group_leg_runs_on_rccl():
+    """BENCH_FORCE_DIST=1: the N > 1 code path (barrier, MAX of the elapsed time, gathered launch times, parity maxima) on a
+    single-rank RCCL group.  A silent fall-back to gloo on a box whose RCCL works would hide a broken RCCL path until the 8-GPU run."""
+    res, err = _bench("--steps", "3", "--cuts", "2000", env={"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29417",
+                                                              "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert res["config"]["dist_backend"] == "rccl", (res["config"], err[-2000:])
+    assert res["n_gpus"] == 1 and res["scaling"] == "weak" and res["parity"]["pass"] is True
+    assert len(res["config"]["rank_launch_ms"]) == 1
+
+
+def test_total_cuts_is_the_same_corpus_and_the_same_rate_as_the_default_form():
+    """`--total-cuts T` at N = 1 holds exactly the cuts of the default form (one generator stream), reports strong scaling, and its rate
+    agrees with the weak form's (the same launch over the same data)."""
+    weak, _ = _bench("--steps", "20", "--cuts", "4000")
+    strong, _ = _bench("--steps", "20", "--total-cuts", "4000")
+    assert strong["scaling"] == "strong" and weak["scaling"] == "weak"
+    assert strong["config"]["cuts_per_gpu_per_step"] == weak["config"]["cuts_per_gpu_per_step"] == 4000
+    assert "configs[2]" in strong["config"]["workload"]
+    # identical inputs -> identical sampled outputs -> identical parity figures
+    for k in ("rel_l2_max", "max_abs_max", "hip_vs_f64_max_abs"):
+        assert strong["parity"][k] == weak["parity"][k], k
+    assert abs(strong["value"] / weak["value"] - 1.0) < 0.08, (strong["value"], weak["value"])
