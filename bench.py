@@ -438,10 +438,20 @@ class OnTheFly:
             front = int(offs[-1] + lens[-1])
             arena = torch.empty(((front + 3) & ~3) + A.perturbed_tail_floats(lens, fac, SR), dtype=torch.float32, device=dev)
             arena[:front].uniform_(-0.5, 0.5, generator=g)
-            self.batches.append({"arena": arena, "offs": offs, "lens": lens, "fac": fac, "front": front})
+            self.batches.append({"arena": arena, "offs": offs, "lens": lens, "fac": fac, "front": front, "idx": None})
             ncuts += len(lens)
         self.units = ncuts
         self.feats = [None] * NB
+        # the resamplers of the three factors resident in one bank: ONE launch perturbs a whole mini-batch, whatever its mix of factors,
+        # fills the padding rows and carries the descriptor tables of the feature launch in its kernel arguments (hipfeat_minibatch_*)
+        self.bank = A.HipSpeedBank([0.9, 1.0, 1.1], SR, dev)
+        for bt in self.batches:
+            bt["idx"] = self.bank.index_of(bt["fac"])
+        self.nstreams = max(1, int(getattr(args, "streams", 2) or 2))
+        # mini-batches alternate between two streams, as a prefetching loader's would: the feature launch of one overlaps the
+        # perturbation launch of the next (each mini-batch is too small to fill 256 CUs through its ramp and tail on its own)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.nstreams)] if self.nstreams > 1 else []
+        self.route = getattr(args, "route", "pair")
         self.step()  # sizes of the perturbed batch (for the byte count) and the first outputs
         in_samples = out_samples = frames = audio_in = all_out = 0
         for bt, (f, fl, po, pl) in zip(self.batches, self.feats):
@@ -454,17 +464,40 @@ class OnTheFly:
         self.audio_seconds = audio_in / SR
         # resampler: reads the perturbed cuts' inputs, writes their outputs; fbank: reads every (perturbed) cut once, writes its rows once
         self.algo_bytes = 4 * (in_samples + out_samples) + 4 * all_out + 4 * NUM_MELS * frames
-        self.kernel = self.plan.kernel_name + " + resample_fast_kernel"
+        self.kernel = self.plan.kernel_name + " + minibatch_prep_inline_kernel (mixed-factor resample_fast_block + padding rows + descriptor tables)"
         self.workload = (f"BASELINE configs[4]: {NB} mini-batches of 600 s per GPU per step ({ncuts} cuts U(1,30) s, {self.audio_seconds:.0f} s of audio), "
                          "each cut speed-perturbed by 0.9 / 1.0 / 1.1 on the device, then 80-dim log-mel Fbank written straight into the padded "
-                         "(B, Tmax, 80) batch tensor (LOG_EPSILON padding); waveforms resident in HBM, features stay on the device")
+                         "(B, Tmax, 80) batch tensor (LOG_EPSILON padding); waveforms resident in HBM, features stay on the device; two launches "
+                         f"per mini-batch, mini-batches alternating over {max(1, self.nstreams)} stream(s)")
 
     def step(self):
-        A = self.A
-        for k, bt in enumerate(self.batches):
-            po, pl = A.perturb_speed_in_arena(bt["arena"], bt["offs"], bt["lens"], bt["fac"], SR, bt["front"])
-            f, fl = self.plan.run_collated(bt["arena"], po, pl, None, LOG_EPSILON)
-            self.feats[k] = (f, fl, po, pl)
+        if self.route == "per_factor":  # round 3's route: one resample launch per distinct factor, then hipfeat_extract_collated
+            A = self.A
+            for k, bt in enumerate(self.batches):
+                po, pl = A.perturb_speed_in_arena(bt["arena"], bt["offs"], bt["lens"], bt["fac"], SR, bt["front"])
+                f, fl = self.plan.run_collated(bt["arena"], po, pl, None, LOG_EPSILON)
+                self.feats[k] = (f, fl, po, pl)
+            return
+        torch, bank, plan = self.torch, self.bank, self.plan
+        if not self.streams:
+            for k, bt in enumerate(self.batches):
+                self.feats[k] = bank.extract_collated(plan, bt["arena"], bt["offs"], bt["lens"], bt["idx"], bt["front"], LOG_EPSILON)
+            return
+        main = torch.cuda.current_stream(self.dev)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        for s in self.streams:
+            s.wait_event(fork)
+        try:
+            for k, bt in enumerate(self.batches):
+                torch.cuda.set_stream(self.streams[k % self.nstreams])  # (allocations of the outputs belong to the stream that fills them)
+                self.feats[k] = bank.extract_collated(plan, bt["arena"], bt["offs"], bt["lens"], bt["idx"], bt["front"], LOG_EPSILON)
+        finally:
+            torch.cuda.set_stream(main)
+        for s in self.streams:  # join: the step ends on the launch stream, where bench.py's events are recorded
+            e = torch.cuda.Event()
+            e.record(s)
+            main.wait_event(e)
 
     def clear(self):
         for k in range(self.NB):
@@ -496,10 +529,42 @@ class OnTheFly:
             stats.append(compare(got, want, truth))
         return fold(stats)
 
+    def _rate(self, seconds: float = 1.0):
+        """(cuts/s, host microseconds per mini-batch) of the current route: the enqueue loop is timed on its own (no synchronisation
+        inside), then the device is drained."""
+        torch = self.torch
+        self.step()
+        torch.cuda.synchronize(self.dev)
+        n, host, t0 = 0, 0.0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            h0 = time.perf_counter()
+            self.step()
+            host += time.perf_counter() - h0
+            n += 1
+            if n % 4 == 0:
+                torch.cuda.synchronize(self.dev)  # keep the queues short: the enqueue time must not include waiting for queue space
+        torch.cuda.synchronize(self.dev)
+        dt = time.perf_counter() - t0
+        return round(self.units * n / dt, 1), round(host / (n * self.NB) * 1e6, 2)
+
     def extra(self, args):
-        if args.no_host_fed:
-            return {}
-        return {"host_fed": onthefly_host_fed(self)}
+        """Same-call A/B of the routes (device-resident), the host's share per mini-batch, and the host-fed rate."""
+        out = {}
+        keep = (self.route, self.streams, self.nstreams)
+        ab = {}
+        for name, route, ns in (("pair_2_streams", "pair", 2), ("pair_1_stream", "pair", 1), ("per_factor_route_of_round_3", "per_factor", 1)):
+            self.route, self.nstreams = route, ns
+            self.streams = [self.torch.cuda.Stream(device=self.dev) for _ in range(ns)] if ns > 1 else []
+            r, h = self._rate()
+            ab[name] = {"cuts_per_s": r, "host_us_per_minibatch": h}
+        self.route, self.streams, self.nstreams = keep
+        ab["what"] = ("device-resident, ~1 s each in this run: `pair` = hipfeat_minibatch_plan + _run (two launches, tables in the kernel arguments), on two "
+                      "alternating streams or one; `per_factor` = one hipfeat_resample launch per factor + hipfeat_extract_collated; host_us = wall time of "
+                      "the enqueue loop per mini-batch (Python + ctypes + the HIP launches)")
+        out["routes"] = ab
+        if not args.no_host_fed:
+            out["host_fed"] = onthefly_host_fed(self)
+        return out
 
     def close(self):
         pass
@@ -765,8 +830,7 @@ def onthefly_host_fed(w, seconds: float = 3.0):
         packed, offs, lens = pack_to_device(host[k], w.dev)
         arena = torch.empty(((packed.numel() + 3) & ~3) + A.perturbed_tail_floats(lens, bt["fac"], SR), dtype=torch.float32, device=w.dev)
         arena[: packed.numel()].copy_(packed, non_blocking=True)
-        po, pl = A.perturb_speed_in_arena(arena, offs, lens, bt["fac"], SR, packed.numel())
-        return w.plan.run_collated(arena, po, pl, None, LOG_EPSILON)
+        return w.bank.extract_collated(w.plan, arena, offs, lens, bt["idx"], packed.numel(), LOG_EPSILON)
 
     one(0)
     torch.cuda.synchronize()
@@ -847,6 +911,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="fbank16k", choices=sorted(WORKLOADS), help="fbank16k = BASELINE configs[1] (default), mfcc40_libri = configs[3], onthefly = configs[4], bulk_save = the offline path end to end (SURVEY 8d iii)")
     ap.add_argument("--cuts", type=int, default=0, help="cuts per GPU per step (onthefly: mini-batches per step); default per config")
+    ap.add_argument("--streams", type=int, default=2, help="onthefly: streams the mini-batches alternate over (default 2)")
+    ap.add_argument("--route", default="pair", choices=["pair", "per_factor"], help="onthefly: `pair` = the two-launch mini-batch (default), `per_factor` = round 3's route")
     ap.add_argument("--total-cuts", type=int, default=0, help="fbank16k only: STRONG scaling (BASELINE configs[2]: 100000): this many cuts in total per step, "
                     "sharded round-robin over the ranks (same global corpus for every N); default 0 = weak scaling, --cuts per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")

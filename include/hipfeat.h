@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HIPFEAT_ABI_VERSION 2
+#define HIPFEAT_ABI_VERSION 3
 
 #if defined(HIPFEAT_BUILD)
 #define HIPFEAT_API __attribute__((visibility("default")))
@@ -250,6 +250,42 @@ HIPFEAT_API int64_t hipfeat_resampled_length(int64_t num_samples, int32_t orig_f
 HIPFEAT_API hipfeat_status hipfeat_resample(const hipfeat_resampler* resampler, const float* d_in, const int64_t* h_in_offsets,
                                 const int64_t* h_num_samples, int64_t batch, float* d_out, const int64_t* h_out_offsets,
                                 void* stream);
+
+/* ---- on-the-fly mini-batch: mixed-factor speed perturbation + collated extraction in TWO launches ------------- */
+/*
+ * BASELINE configs[4].  What OnTheFlyFeatures does per mini-batch on the CPU -- Speed per cut inside Recording.load_audio
+ * (lhotse/dataset/cut_transforms/perturb_speed.py:8-47, lhotse/augmentation/torchaudio.py:37-42, augmentation/resample.py:284-315),
+ * extract_batch, collate_matrices with LOG_EPSILON (lhotse/dataset/input_strategies.py:410-462, dataset/collation.py:506-535) --
+ * on a packed mini-batch that is resident in ONE device buffer (the "arena": the cuts at h_offsets / h_num_samples in its front
+ * part, free space from tail_start on), as a pair of launches: (1) every perturbed cut, whatever its factor, is resampled into the
+ * arena's tail (one workgroup = 256 hops of one cut, the polyphase bank selected per cut), the padding rows of the collated tensor are
+ * filled and the descriptor table of launch (2) is put in place -- for mini-batches of up to ~100 cuts the tables travel in the kernel
+ * arguments, i.e. there is no host -> device copy in front of the launches at all; (2) the feature kernel of `plan` reads every cut
+ * where it now lies (unperturbed cuts are never copied) and writes it into its slot of the dense (batch, rows_per_cut, feature_dim)
+ * tensor.  Results are bit-identical to hipfeat_resample per factor + hipfeat_extract_collated.
+ *
+ * A bank = the resamplers a mini-batch may refer to (h_bank_index[b] = index into the bank, -1 = unperturbed); they must be of the
+ * compile-time ratios 9:10, 11:10, 19:20, 21:20 (speed 0.9 / 1.1 / 0.95 / 1.05, width 7) -- anything else: HIPFEAT_ERR_UNSUPPORTED,
+ * use hipfeat_resample per factor -- and must outlive the bank.
+ *
+ * hipfeat_minibatch_plan is host arithmetic only: where each perturbed cut goes (h_out_offsets), how long it is (h_out_num_samples;
+ * ceil(new * n / orig) as hipfeat_resampled_length, capped by h_max_samples[b] >= 0 when given: lhotse truncates a perturbed cut to
+ * the sample count its manifest states, lhotse/audio/recording.py:1058-1060), its frame count (h_num_frames), and in h_info[3] =
+ * {ticket, floats the arena must hold, largest frame count} -- what the caller needs to allocate the arena and the output.
+ * zero_pad_batch != 0 frames every cut on a row of the longest cut's length (edge_rule "batch_zero_pad", _extract_batch's rule).
+ * hipfeat_minibatch_run enqueues the two launches of a planned mini-batch on `stream`; rows_per_cut >= h_info[2].  Up to 16 plans may
+ * be outstanding per bank; a bank may be shared by threads (calls are serialised inside).
+ */
+typedef struct hipfeat_speed_bank hipfeat_speed_bank;
+HIPFEAT_API hipfeat_status hipfeat_speed_bank_create(const hipfeat_resampler* const* resamplers, int32_t num_resamplers,
+                                                     hipfeat_speed_bank** bank);
+HIPFEAT_API hipfeat_status hipfeat_speed_bank_destroy(hipfeat_speed_bank* bank);
+HIPFEAT_API hipfeat_status hipfeat_minibatch_plan(hipfeat_speed_bank* bank, const hipfeat_plan* plan, int64_t batch, const int64_t* h_offsets,
+                                                  const int64_t* h_num_samples, const int32_t* h_bank_index, const int64_t* h_max_samples,
+                                                  int64_t tail_start, int32_t zero_pad_batch, int64_t* h_out_offsets,
+                                                  int64_t* h_out_num_samples, int64_t* h_num_frames, int64_t* h_info);
+HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* bank, int64_t ticket, float* d_arena, int64_t arena_floats, float* d_out,
+                                                 int64_t rows_per_cut, float pad_value, void* stream);
 
 #ifdef __cplusplus
 }

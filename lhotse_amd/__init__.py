@@ -15,7 +15,7 @@ from .extractors import (  # noqa: F401
     HipSpectrogramConfig,
 )
 
-from .augmentation import HipResample, HipResampleTensor, HipSpeed, get_or_create_resampler  # noqa: F401,E402
+from .augmentation import HipResample, HipResampleTensor, HipSpeed, HipSpeedBank, get_or_create_resampler  # noqa: F401,E402
 
 from .kaldifeat import (  # noqa: F401,E402
     HipKaldifeatFbank,
@@ -64,6 +64,7 @@ __all__ = [
     "HipKaldifeatFrameOptions",
     "HipKaldifeatMelOptions",
     "HipSpeed",
+    "HipSpeedBank",
     "HipResample",
     "HipResampleTensor",
     "get_or_create_resampler",

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import build as _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> (return C type, [argument C types]) ; mirrors include/hipfeat.h one to one.
 _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
@@ -67,6 +67,14 @@ _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
         "int",
         ["const hipfeat_resampler*", "const float*", "const int64_t*", "const int64_t*", "int64_t", "float*", "const int64_t*", "void*"],
     ),
+    "hipfeat_speed_bank_create": ("int", ["const hipfeat_resampler* const*", "int32_t", "hipfeat_speed_bank**"]),
+    "hipfeat_speed_bank_destroy": ("int", ["hipfeat_speed_bank*"]),
+    "hipfeat_minibatch_plan": (
+        "int",
+        ["hipfeat_speed_bank*", "const hipfeat_plan*", "int64_t", "const int64_t*", "const int64_t*", "const int32_t*", "const int64_t*", "int64_t", "int32_t",
+         "int64_t*", "int64_t*", "int64_t*", "int64_t*"],
+    ),
+    "hipfeat_minibatch_run": ("int", ["hipfeat_speed_bank*", "int64_t", "float*", "int64_t", "float*", "int64_t", "float", "void*"]),
     "hipfeat_extract_host": (
         "int",
         ["const hipfeat_plan*", "const float*", "int64_t", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "int64_t", "const int64_t*", "int64_t", "void*"],

@@ -277,3 +277,75 @@ def perturb_speed_in_arena(arena: torch.Tensor, offsets: np.ndarray, lengths: np
         offsets[idx], lengths[idx] = out_offs, out_lens
         tail = (end + 3) & ~3
     return offsets, lengths
+
+
+# ---- the same in ONE launch for all factors, fused with what else has to precede the feature launch ------------------------------
+class HipSpeedBank:
+    """The resamplers a mini-batch may refer to, resident on one device (``hipfeat_speed_bank``, include/hipfeat.h): mixed-factor speed
+    perturbation of a packed mini-batch + the collated feature extraction as a PAIR of launches with no host -> device copy in front of
+    them (``hipfeat_minibatch_plan`` / ``hipfeat_minibatch_run``).  Factors must be among 0.9 / 1.1 / 0.95 / 1.05 (the compile-time
+    ratios of the mixed launch) and 1.0; anything else raises ``HipFeatError`` (UNSUPPORTED) -- use ``perturb_speed_in_arena``.
+
+        bank = HipSpeedBank([0.9, 1.0, 1.1], 16000, "cuda:0")
+        feats, frames, offs, lens = bank.extract_collated(extractor.plan, arena, offsets, lengths, bank.index_of(factors), tail_start, LOG_EPSILON)
+
+    bit-identical to ``perturb_speed_in_arena`` + ``plan.run_collated``."""
+
+    def __init__(self, factors: Sequence[float], sampling_rate: int, device: Union[str, torch.device, None] = None):
+        self.sampling_rate = int(sampling_rate)
+        self.factors = sorted({float(f) for f in factors if float(f) != 1.0})
+        self.resamplers = [get_or_create_resampler(round(sampling_rate * f), sampling_rate, device) for f in self.factors]
+        self.lib = _lib.load()
+        self.device = self.resamplers[0].device if self.resamplers else torch.device("cuda", torch.cuda.current_device())
+        handles = np.array([r.handle for r in self.resamplers], dtype=np.uint64)
+        out = np.zeros(1, dtype=np.uint64)
+        self.handle = 0
+        self.lib.check("hipfeat_speed_bank_create", _lib.addr(handles) if len(handles) else None, len(handles), _lib.addr(out))
+        self.handle = int(out[0])
+        self._info = np.zeros(3, dtype=np.int64)
+        self._info_addr = _lib.addr(self._info)
+        self._lock = threading.Lock()
+
+    def index_of(self, factors: Sequence[float]) -> np.ndarray:
+        """Per-cut bank index (int32; -1 = factor 1.0 = the cut stays where it is)."""
+        fac = np.asarray(factors, dtype=np.float64)
+        idx = np.full(len(fac), -1, dtype=np.int32)
+        for k, f in enumerate(self.factors):
+            idx[fac == f] = k
+        bad = (idx < 0) & (fac != 1.0)
+        if bad.any():
+            raise ValueError(f"factors {sorted(set(fac[bad].tolist()))} are not in this bank ({self.factors})")
+        return idx
+
+    def extract_collated(self, plan, arena: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray, bank_index: np.ndarray, tail_start: int,
+                         pad_value: float, max_samples: Optional[np.ndarray] = None, zero_pad_batch: bool = False,
+                         stream: Optional[int] = None) -> Tuple[torch.Tensor, np.ndarray, np.ndarray, np.ndarray]:
+        """-> (features (B, Tmax, F) on the arena's device, frame counts, per-cut offsets and lengths of the PERTURBED batch in the arena).
+        ``offsets`` / ``lengths`` int64, ``bank_index`` int32 (``index_of``), all C-contiguous numpy arrays; the arena must hold
+        ``perturbed_tail_floats`` floats behind ``tail_start``."""
+        B = len(lengths)
+        res = np.empty((3, B), dtype=np.int64)  # rows: offsets, lengths, frames of the perturbed batch
+        a = res.__array_interface__["data"][0]
+        with self._lock:  # (the info triple is shared; the library serialises the calls anyway)
+            self.lib.check("hipfeat_minibatch_plan", self.handle, plan.handle, B, offsets.__array_interface__["data"][0], lengths.__array_interface__["data"][0],
+                           bank_index.__array_interface__["data"][0], None if max_samples is None else max_samples.__array_interface__["data"][0],
+                           int(tail_start), 1 if zero_pad_batch else 0, a, a + 8 * B, a + 16 * B, self._info_addr)
+            ticket, need, tmax = int(self._info[0]), int(self._info[1]), int(self._info[2])
+        out = torch.empty((B, tmax, plan.feature_dim), dtype=torch.float32, device=arena.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(arena.device).cuda_stream
+        self.lib.check("hipfeat_minibatch_run", self.handle, ticket, arena.data_ptr(), arena.numel(), out.data_ptr(), tmax, float(pad_value), int(stream))
+        return out, res[2], res[0], res[1]
+
+    def close(self):
+        if self.handle:
+            try:
+                self.lib.raw("hipfeat_speed_bank_destroy", self.handle)
+            finally:
+                self.handle = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -24,6 +24,7 @@
 #include "kernel_fft2048c.hpp"
 #include "mel4_schedule.hpp"
 #include "kernel_resample.hpp"
+#include "kernel_minibatch.hpp"
 #include "kernel_specaug.hpp"
 #include "kernel_whisper2.hpp"
 #include "kernel_whisper3.hpp"
@@ -2402,6 +2403,225 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_resample(const hipfeat_resampler* 
   s.busy = (e2 == hipSuccess);
   if (e1 != hipSuccess) return fail(HIPFEAT_ERR_HIP, "resample launch failed: %s", hipGetErrorName(e1));
   return HIPFEAT_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// on-the-fly mini-batch: mixed-factor speed perturbation + collated extraction in two launches (kernel_minibatch.hpp)
+// --------------------------------------------------------------------------------------
+constexpr int kMbSlots = 16;
+constexpr int kMbMaxResamplers = 8;
+
+struct MbSlot {
+  int64_t ticket = -1;
+  bool planned = false;
+  const hipfeat_plan* plan = nullptr;
+  hipfeat_layout lay;
+  std::vector<CutDesc> descs;
+  std::vector<ResCut> res;
+  int64_t res_blocks = 0, arena_need = 0, max_frames = 0;
+  void* h = nullptr;  // pinned staging (tables that do not fit the kernel arguments)
+  void* d = nullptr;  // device tables: CutDesc[batch], then (staged path) ResCut[num_res]
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool busy = false;
+};
+
+struct hipfeat_speed_bank {
+  int device = 0;
+  int num = 0;
+  int kind[kMbMaxResamplers] = {};  // kernel_minibatch.hpp's switch index of resampler i
+  int orig[kMbMaxResamplers] = {}, nw[kMbMaxResamplers] = {}, outs[kMbMaxResamplers] = {};
+  const float* kt[kMbKinds] = {};
+  size_t lds_bytes = 0;
+  bool allow_inline = true;
+  std::mutex mu;
+  MbSlot slots[kMbSlots];
+  int64_t next_ticket = 0;
+};
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_speed_bank_create(const hipfeat_resampler* const* resamplers, int32_t num,
+                                                                hipfeat_speed_bank** out) {
+  if (!out) return fail(HIPFEAT_ERR_INVALID, "bank pointer is NULL");
+  *out = nullptr;
+  if (num < 0 || num > kMbMaxResamplers || (num > 0 && !resamplers)) return fail(HIPFEAT_ERR_INVALID, "a bank holds 0 ... %d resamplers", kMbMaxResamplers);
+  hipfeat_speed_bank* b = new (std::nothrow) hipfeat_speed_bank();
+  if (!b) return fail(HIPFEAT_ERR_INVALID, "out of host memory");
+  static const int ratios[kMbKinds][3] = {{9, 10, 7}, {11, 10, 7}, {19, 20, 7}, {21, 20, 7}};
+  static const size_t lds_floats[kMbKinds] = {ResampleFast<9, 10, 7>::LDS_FLOATS, ResampleFast<11, 10, 7>::LDS_FLOATS,
+                                              ResampleFast<19, 20, 7>::LDS_FLOATS, ResampleFast<21, 20, 7>::LDS_FLOATS};
+  static const int outs[kMbKinds] = {ResampleFast<9, 10, 7>::OUTS, ResampleFast<11, 10, 7>::OUTS, ResampleFast<19, 20, 7>::OUTS,
+                                     ResampleFast<21, 20, 7>::OUTS};
+  b->lds_bytes = 16;
+  for (int i = 0; i < num; ++i) {
+    const hipfeat_resampler* r = resamplers[i];
+    int k = -1;
+    if (r && r->d_kernel_t)
+      for (int j = 0; j < kMbKinds; ++j)
+        if (r->orig == ratios[j][0] && r->nw == ratios[j][1] && r->width == ratios[j][2]) k = j;
+    if (k < 0 || (i > 0 && r->device != b->device)) {
+      const int o = r ? r->orig : 0, n = r ? r->nw : 0;
+      delete b;
+      return fail(HIPFEAT_ERR_UNSUPPORTED, "resampler %d (%d -> %d) is not one of the compile-time ratios of the mixed launch (9:10, 11:10, 19:20, 21:20 "
+                  "= speed 0.9 / 1.1 / 0.95 / 1.05), or lives on another device: use hipfeat_resample per factor", i, o, n);
+    }
+    if (i == 0) b->device = r->device;
+    b->kind[i] = k;
+    b->orig[i] = r->orig;
+    b->nw[i] = r->nw;
+    b->outs[i] = outs[k];
+    b->kt[k] = r->d_kernel_t;
+    b->lds_bytes = std::max(b->lds_bytes, lds_floats[k] * sizeof(float));
+  }
+  b->num = num;
+  b->allow_inline = getenv("HIPFEAT_MB_NO_INLINE") == nullptr;
+  *out = b;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_speed_bank_destroy(hipfeat_speed_bank* b) {
+  if (!b) return HIPFEAT_OK;
+  DeviceGuard g(b->device);
+  for (auto& s : b->slots) {
+    if (s.busy && s.ev) (void)hipEventSynchronize(s.ev);
+    if (s.h) (void)hipHostFree(s.h);
+    if (s.d) (void)hipFree(s.d);
+    if (s.ev) (void)hipEventDestroy(s.ev);
+  }
+  delete b;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_plan(hipfeat_speed_bank* bank, const hipfeat_plan* plan, int64_t batch,
+                                                             const int64_t* h_offsets, const int64_t* h_num_samples,
+                                                             const int32_t* h_bank_index, const int64_t* h_max_samples,
+                                                             int64_t tail_start, int32_t zero_pad_batch, int64_t* h_out_offsets,
+                                                             int64_t* h_out_num_samples, int64_t* h_num_frames, int64_t* h_info) {
+  if (!bank || !plan || !h_info) return fail(HIPFEAT_ERR_INVALID, "NULL argument");
+  if (batch <= 0 || !h_offsets || !h_num_samples || batch > 65535) return fail(HIPFEAT_ERR_INVALID, "bad batch arguments (1 ... 65535 cuts)");
+  if (plan->variant == 9 || plan->cfg.kind == HIPFEAT_WHISPER || plan->cfg.kind == HIPFEAT_LIBROSA_FBANK)
+    return fail(HIPFEAT_ERR_UNSUPPORTED, "the mini-batch launch pair serves the Kaldi-style plans (spectrogram / fbank / mfcc)");
+  if (bank->num > 0 && plan->device != bank->device) return fail(HIPFEAT_ERR_INVALID, "plan and bank live on different devices");
+  std::lock_guard<std::mutex> lk(bank->mu);
+  const int64_t ticket = bank->next_ticket++;
+  MbSlot& s = bank->slots[ticket % kMbSlots];
+  s.planned = false;
+  s.ticket = ticket;
+  s.plan = plan;
+  s.res.clear();
+  // lengths and places of the perturbed batch: unperturbed cuts stay where they are, the others go to the tail in cut order, each on a
+  // 16-byte boundary (the feature kernels fetch spans by LDS-DMA)
+  std::vector<int64_t> offs((size_t)batch), lens((size_t)batch), padded;
+  int64_t tail = (tail_start + 3) & ~(int64_t)3, blocks = 0, max_len = 0;
+  for (int64_t b = 0; b < batch; ++b) {
+    const int64_t L = h_num_samples[b];
+    const int idx = h_bank_index ? h_bank_index[b] : -1;
+    if (L < 0 || L > INT32_MAX / 2) return fail(HIPFEAT_ERR_INVALID, "cut %lld: %lld samples out of range", (long long)b, (long long)L);
+    if (idx >= bank->num) return fail(HIPFEAT_ERR_INVALID, "cut %lld: bank index %d of %d", (long long)b, idx, bank->num);
+    int64_t o = h_offsets[b], n = L;
+    if (idx >= 0) {
+      const int64_t ol = hipfeat_resampled_length(L, bank->orig[idx], bank->nw[idx]);
+      if (h_offsets[b] + L > tail_start) return fail(HIPFEAT_ERR_INVALID, "cut %lld reaches into the arena's tail (tail_start %lld)", (long long)b, (long long)tail_start);
+      s.res.push_back(ResCut{h_offsets[b], tail, (int32_t)L, (int32_t)ol, (int32_t)blocks, bank->kind[idx]});
+      blocks += (ol + bank->outs[idx] - 1) / bank->outs[idx];
+      if (blocks > INT32_MAX - (1 << 24)) return fail(HIPFEAT_ERR_INVALID, "batch too large for one launch");
+      o = tail;
+      n = ol;
+      tail += (ol + 3) & ~(int64_t)3;
+    }
+    if (h_max_samples && h_max_samples[b] >= 0) n = std::min(n, h_max_samples[b]);  // a sample or two to truncate (lhotse/audio/recording.py:1058-1060)
+    offs[(size_t)b] = o;
+    lens[(size_t)b] = n;
+    max_len = std::max(max_len, n);
+  }
+  if (zero_pad_batch) padded.assign((size_t)batch, max_len);  // edge_rule "batch_zero_pad" (_extract_batch, extractors.py:531-537)
+  hipfeat_status st = build_descs(plan, batch, offs.data(), lens.data(), zero_pad_batch ? padded.data() : nullptr, nullptr, plan->feature_dim, s.descs, &s.lay);
+  if (st != HIPFEAT_OK) return st;
+  s.lay.owns = false;
+  s.res_blocks = blocks;
+  s.arena_need = tail;
+  s.max_frames = 0;
+  for (int64_t b = 0; b < batch; ++b) {
+    s.max_frames = std::max(s.max_frames, s.lay.num_frames[(size_t)b]);
+    if (h_out_offsets) h_out_offsets[b] = offs[(size_t)b];
+    if (h_out_num_samples) h_out_num_samples[b] = lens[(size_t)b];
+    if (h_num_frames) h_num_frames[b] = s.lay.num_frames[(size_t)b];
+  }
+  s.planned = true;
+  h_info[0] = ticket;
+  h_info[1] = s.arena_need;
+  h_info[2] = s.max_frames;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* bank, int64_t ticket, float* d_arena, int64_t arena_floats,
+                                                            float* d_out, int64_t rows_per_cut, float pad_value, void* stream) {
+  if (!bank || !d_arena || !d_out) return fail(HIPFEAT_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> lk(bank->mu);
+  MbSlot& s = bank->slots[((ticket % kMbSlots) + kMbSlots) % kMbSlots];
+  if (s.ticket != ticket || !s.planned)
+    return fail(HIPFEAT_ERR_INVALID, "ticket %lld is not a planned mini-batch (at most %d plans may be outstanding)", (long long)ticket, kMbSlots);
+  s.planned = false;
+  const hipfeat_plan* plan = s.plan;
+  const int64_t batch = s.lay.batch;
+  if (arena_floats < s.arena_need) return fail(HIPFEAT_ERR_INVALID, "arena holds %lld floats, the perturbed mini-batch needs %lld", (long long)arena_floats, (long long)s.arena_need);
+  if (rows_per_cut < s.max_frames) return fail(HIPFEAT_ERR_INVALID, "the collated output holds %lld rows per cut, the longest cut has %lld frames", (long long)rows_per_cut, (long long)s.max_frames);
+  for (int64_t b = 0; b < batch; ++b) s.descs[(size_t)b].out_row = b * rows_per_cut;
+  DeviceGuard g(plan->device);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t cut_bytes = (size_t)batch * sizeof(CutDesc), res_bytes = s.res.size() * sizeof(ResCut), bytes = cut_bytes + res_bytes;
+  const bool inl = bank->allow_inline && bytes <= (size_t)kMbInlineBytes;
+  if (s.busy) {  // the launches that used this slot's device table last time
+    HIP_TRY(hipEventSynchronize(s.ev));
+    s.busy = false;
+  }
+  if (!s.ev) HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  if (s.cap < bytes) {
+    if (s.h) (void)hipHostFree(s.h);
+    if (s.d) (void)hipFree(s.d);
+    s.h = s.d = nullptr;
+    s.cap = 0;
+    const size_t cap = std::max<size_t>(bytes * 2, 1 << 14);
+    HIP_TRY(hipHostMalloc(&s.h, cap, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&s.d, cap));
+    s.cap = cap;
+  }
+  s.lay.d_cuts = static_cast<CutDesc*>(s.d);
+  const unsigned grid = (unsigned)(s.res_blocks + batch * kMbFillBlocks);
+  MbInlineArgs args;  // (header + 3.5 KB; only the used part of the blob is written)
+  MbHeader& h = args.h;
+  h.arena = d_arena;
+  h.out = d_out;
+  h.cuts_dst = static_cast<CutDesc*>(s.d);
+  h.res_src = nullptr;
+  for (int k = 0; k < kMbKinds; ++k) h.kt[k] = bank->kt[k];
+  h.num_cuts = (int32_t)batch;
+  h.num_res = (int32_t)s.res.size();
+  h.res_blocks = (int32_t)s.res_blocks;
+  h.copy_descs = inl ? 1 : 0;
+  h.rows_per_cut = (int32_t)rows_per_cut;
+  h.feature_dim = plan->feature_dim;
+  h.pad_value = pad_value;
+  h.pad_ = 0;
+  hipError_t e1 = hipSuccess;
+  if (inl) {
+    if (res_bytes) std::memcpy(args.blob, s.res.data(), res_bytes);
+    std::memcpy(args.blob + res_bytes, s.descs.data(), cut_bytes);
+    hipLaunchKernelGGL(minibatch_prep_inline_kernel, dim3(grid), dim3(256), bank->lds_bytes, st, args);
+    e1 = hipGetLastError();
+  } else {
+    std::memcpy(s.h, s.descs.data(), cut_bytes);
+    if (res_bytes) std::memcpy(static_cast<unsigned char*>(s.h) + cut_bytes, s.res.data(), res_bytes);
+    HIP_TRY(hipMemcpyAsync(s.d, s.h, bytes, hipMemcpyHostToDevice, st));
+    h.res_src = reinterpret_cast<const ResCut*>(static_cast<unsigned char*>(s.d) + cut_bytes);
+    hipLaunchKernelGGL(minibatch_prep_kernel, dim3(grid), dim3(256), bank->lds_bytes, st, h);
+    e1 = hipGetLastError();
+  }
+  hipfeat_status rc = HIPFEAT_OK;
+  if (e1 != hipSuccess) rc = fail(HIPFEAT_ERR_HIP, "mini-batch prep launch failed: %s", hipGetErrorName(e1));
+  if (rc == HIPFEAT_OK && s.lay.total_blocks > 0) rc = launch(plan, &s.lay, d_arena, d_out, st);
+  hipError_t e2 = hipEventRecord(s.ev, st);
+  s.busy = (e2 == hipSuccess);
+  return rc;
 }
 
 #ifdef HIPFEAT_PHASE_TIMERS

@@ -89,16 +89,13 @@ struct ResampleFast {
   static constexpr int LDS_FLOATS = SPAN > OUTS ? SPAN : OUTS;
 };
 
+// The work of one workgroup: hops [j0, j0 + 256) of cut `cd`.  `xs` = G::LDS_FLOATS floats of LDS.
 template <int ORIG, int NEW, int WIDTH>
-__global__ __launch_bounds__(256) void resample_fast_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                            const ResCut* __restrict__ cuts, const float* __restrict__ kt,
-                                                            int num_cuts) {
+__device__ __forceinline__ void resample_fast_block(const float* __restrict__ in, float* __restrict__ out, const ResCut& cd, int block_in_cut,
+                                                    const float* __restrict__ kt, float* xs) {
   using G = ResampleFast<ORIG, NEW, WIDTH>;
-  __shared__ float xs[G::LDS_FLOATS];
   const int tid = threadIdx.x;
-  const int cut = find_res_cut(cuts, num_cuts, blockIdx.x);
-  const ResCut cd = cuts[cut];
-  const int j0 = (blockIdx.x - cd.first_block) * G::HOPS;
+  const int j0 = block_in_cut * G::HOPS;
   const int x0 = j0 * ORIG - WIDTH;  // j0 * ORIG <= in_len + ORIG < 2^31
   const float* __restrict__ x = in + cd.in_off;
   {
@@ -134,6 +131,17 @@ __global__ __launch_bounds__(256) void resample_fast_kernel(const float* __restr
 #pragma unroll
   for (int k = 0; k < NEW; ++k)
     if (tid + 256 * k < n) y[tid + 256 * k] = xs[tid + 256 * k];
+}
+
+template <int ORIG, int NEW, int WIDTH>
+__global__ __launch_bounds__(256) void resample_fast_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            const ResCut* __restrict__ cuts, const float* __restrict__ kt,
+                                                            int num_cuts) {
+  using G = ResampleFast<ORIG, NEW, WIDTH>;
+  __shared__ float xs[G::LDS_FLOATS];
+  const int cut = find_res_cut(cuts, num_cuts, blockIdx.x);
+  const ResCut cd = cuts[cut];
+  resample_fast_block<ORIG, NEW, WIDTH>(in, out, cd, blockIdx.x - cd.first_block, kt, xs);
 }
 
 }  // namespace hipfeat

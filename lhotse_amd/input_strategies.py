@@ -167,6 +167,30 @@ if HAVE_LHOTSE:  # pragma: no cover - authoring container only
                 result.append(cuts)
             return tuple(result)
 
+        def _speed_bank(self, factors, sr: int, device):
+            """The bank of the factors met so far on this device (rebuilt when a new factor shows up); None if one of them is not among
+            the mixed launch's ratios."""
+            from ._lib import ERR_UNSUPPORTED, HipFeatError
+            from .augmentation import HipSpeedBank
+
+            need = {float(f) for f in factors if float(f) != 1.0}
+            cache = self.__dict__.setdefault("_banks", {})
+            key = (int(sr), str(device))
+            refused = cache.setdefault("refused", set())
+            if need & refused:
+                return None
+            bank = cache.get(key)
+            if bank is None or not need <= set(bank.factors):
+                have = set() if bank is None else set(bank.factors)
+                try:
+                    bank = cache[key] = HipSpeedBank(sorted(have | need), sr, device)
+                except HipFeatError as e:
+                    if e.status != ERR_UNSUPPORTED:
+                        raise
+                    refused |= need - have  # (one of them is outside the mixed launch's ratios: per-factor launches from now on)
+                    return None
+            return bank
+
         def _perturb_and_extract(self, audios: List[torch.Tensor], factors: List[float], wants: List[int], sr: int):
             """Pack the (partly unperturbed) batch, resample the cuts with a pending factor into the tail of the same buffer, extract."""
             from .augmentation import perturbed_tail_floats
@@ -180,11 +204,18 @@ if HAVE_LHOTSE:  # pragma: no cover - authoring container only
                 front = int(packed.numel())
                 arena = torch.empty(((front + 3) & ~3) + perturbed_tail_floats(lens, factors, sr), dtype=torch.float32, device=packed.device)
                 arena[:front].copy_(packed, non_blocking=True)
-                po, pl = _perturb_in_arena(arena, offs, lens, factors, sr, front)
-                pl = np.minimum(pl, np.asarray(wants, dtype=np.int64))  # a sample or two to truncate (recording.py:1058-1060)
                 zero_pad = getattr(ex.config, "edge_rule", "reflect") == "batch_zero_pad"  # as extract_collated
-                padded = np.full(len(pl), int(pl.max()), dtype=np.int64) if zero_pad else None
-                feats, frames = ex.plan.run_collated(arena, po, pl, padded, float(LOG_EPSILON))
+                want = np.ascontiguousarray(wants, dtype=np.int64)
+                bank = self._speed_bank(factors, sr, packed.device) if hasattr(ex.plan, "handle") else None
+                if bank is not None:  # ONE launch for all factors + the padding rows, then the feature launch (hipfeat_minibatch_*)
+                    feats, frames, po, pl = bank.extract_collated(ex.plan, arena, np.ascontiguousarray(offs, dtype=np.int64),
+                                                                  np.ascontiguousarray(lens, dtype=np.int64), bank.index_of(factors), front,
+                                                                  float(LOG_EPSILON), max_samples=want, zero_pad_batch=zero_pad)
+                else:  # factors outside the mixed launch's compile-time ratios: one resample launch per factor
+                    po, pl = _perturb_in_arena(arena, offs, lens, factors, sr, front)
+                    pl = np.minimum(pl, want)  # a sample or two to truncate (recording.py:1058-1060)
+                    padded = np.full(len(pl), int(pl.max()), dtype=np.int64) if zero_pad else None
+                    feats, frames = ex.plan.run_collated(arena, po, pl, padded, float(LOG_EPSILON))
             perturbed = None
             if self.return_audio:
                 perturbed = [arena[int(o) : int(o) + int(n)].cpu() for o, n in zip(po, pl)]
