@@ -416,13 +416,15 @@ class OnTheFly:
         import lhotse_amd
         from lhotse_amd import augmentation as A
 
-        self.torch, self.np, self.A, self.dev = torch, np, A, dev
+        self.torch, self.np, self.A, self.dev, self.rank = torch, np, A, dev, rank
         NB = self.NB = args.cuts or self.default_cuts
         self.ex = lhotse_amd.HipFbank(lhotse_amd.HipFbankConfig(device=f"cuda:{dev.index}"))
         self.plan = self.ex.plan
         rng = np.random.RandomState(rank)  # rank 0 = seed 0
         g = torch.Generator(device=dev).manual_seed(7 + rank)
-        self.batches = []
+        K = self.K = max(1, int(getattr(args, "prefetch", 1) or 1))
+        assert NB % K == 0, "--cuts (mini-batches per step) must be a multiple of --prefetch"
+        minis = []
         ncuts = 0
         for b in range(NB):
             lens, tot = [], 0.0
@@ -432,24 +434,30 @@ class OnTheFly:
                     break
                 lens.append(int(d * SR))
                 tot += d
-            lens = np.asarray(lens, dtype=np.int64)
-            fac = rng.choice([0.9, 1.0, 1.1], size=len(lens))
+            minis.append((np.asarray(lens, dtype=np.int64), rng.choice([0.9, 1.0, 1.1], size=len(lens))))
+            ncuts += len(lens)
+        # `batches`: what ONE call serves -- a mini-batch, or (--prefetch K) the K mini-batches a prefetching loader has packed into one arena
+        self.batches = []
+        for b0 in range(0, NB, K):
+            lens = np.concatenate([m[0] for m in minis[b0 : b0 + K]])
+            fac = np.concatenate([m[1] for m in minis[b0 : b0 + K]])
+            sizes = np.asarray([len(m[0]) for m in minis[b0 : b0 + K]], dtype=np.int64)
             offs = np.concatenate([[0], np.cumsum((lens + 3) & ~3)[:-1]]).astype(np.int64)
             front = int(offs[-1] + lens[-1])
             arena = torch.empty(((front + 3) & ~3) + A.perturbed_tail_floats(lens, fac, SR), dtype=torch.float32, device=dev)
             arena[:front].uniform_(-0.5, 0.5, generator=g)
-            self.batches.append({"arena": arena, "offs": offs, "lens": lens, "fac": fac, "front": front, "idx": None})
-            ncuts += len(lens)
+            self.batches.append({"arena": arena, "offs": offs, "lens": lens, "fac": fac, "front": front, "idx": None, "sizes": sizes if K > 1 else None,
+                                 "first": np.concatenate([[0], np.cumsum(sizes)])})
         self.units = ncuts
-        self.feats = [None] * NB
+        self.feats = [None] * len(self.batches)
         # the resamplers of the three factors resident in one bank: ONE launch perturbs a whole mini-batch, whatever its mix of factors,
         # fills the padding rows and carries the descriptor tables of the feature launch in its kernel arguments (hipfeat_minibatch_*)
         self.bank = A.HipSpeedBank([0.9, 1.0, 1.1], SR, dev)
         for bt in self.batches:
             bt["idx"] = self.bank.index_of(bt["fac"])
-        self.nstreams = max(1, int(getattr(args, "streams", 2) or 2))
-        # mini-batches alternate between two streams, as a prefetching loader's would: the feature launch of one overlaps the
-        # perturbation launch of the next (each mini-batch is too small to fill 256 CUs through its ramp and tail on its own)
+        self.nstreams = max(1, int(getattr(args, "streams", 3) or 3))
+        # mini-batches alternate between a few streams, as a prefetching loader's would: the ramp and tail of one mini-batch's launches
+        # overlap with the next one's (a 600 s mini-batch is too small to keep 256 CUs busy from its first workgroup to its last)
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.nstreams)] if self.nstreams > 1 else []
         self.route = getattr(args, "route", "pair")
         self.step()  # sizes of the perturbed batch (for the byte count) and the first outputs
@@ -464,15 +472,17 @@ class OnTheFly:
         self.audio_seconds = audio_in / SR
         # resampler: reads the perturbed cuts' inputs, writes their outputs; fbank: reads every (perturbed) cut once, writes its rows once
         self.algo_bytes = 4 * (in_samples + out_samples) + 4 * all_out + 4 * NUM_MELS * frames
-        self.kernel = self.plan.kernel_name + " + minibatch_prep_inline_kernel (mixed-factor resample_fast_block + padding rows + descriptor tables)"
+        self.kernel = self.plan.kernel_name + " + minibatch_prep_" + ("inline_" if K == 1 else "") + "kernel (mixed-factor resample_fast_block + padding rows + descriptor tables)"
         self.workload = (f"BASELINE configs[4]: {NB} mini-batches of 600 s per GPU per step ({ncuts} cuts U(1,30) s, {self.audio_seconds:.0f} s of audio), "
                          "each cut speed-perturbed by 0.9 / 1.0 / 1.1 on the device, then 80-dim log-mel Fbank written straight into the padded "
                          "(B, Tmax, 80) batch tensor (LOG_EPSILON padding); waveforms resident in HBM, features stay on the device; two launches "
-                         f"per mini-batch, mini-batches alternating over {max(1, self.nstreams)} stream(s)")
+                         + (f"per mini-batch" if K == 1 else f"per {K} mini-batches (a loader that prefetches {K}: every mini-batch its own dense tensor)")
+                         + f", calls alternating over {max(1, self.nstreams)} stream(s)")
 
     def step(self):
         if self.route == "per_factor":  # round 3's route: one resample launch per distinct factor, then hipfeat_extract_collated
             A = self.A
+            assert self.K == 1
             for k, bt in enumerate(self.batches):
                 po, pl = A.perturb_speed_in_arena(bt["arena"], bt["offs"], bt["lens"], bt["fac"], SR, bt["front"])
                 f, fl = self.plan.run_collated(bt["arena"], po, pl, None, LOG_EPSILON)
@@ -481,7 +491,7 @@ class OnTheFly:
         torch, bank, plan = self.torch, self.bank, self.plan
         if not self.streams:
             for k, bt in enumerate(self.batches):
-                self.feats[k] = bank.extract_collated(plan, bt["arena"], bt["offs"], bt["lens"], bt["idx"], bt["front"], LOG_EPSILON)
+                self.feats[k] = bank.extract_collated(plan, bt["arena"], bt["offs"], bt["lens"], bt["idx"], bt["front"], LOG_EPSILON, group_sizes=bt["sizes"])
             return
         main = torch.cuda.current_stream(self.dev)
         fork = torch.cuda.Event()
@@ -491,7 +501,7 @@ class OnTheFly:
         try:
             for k, bt in enumerate(self.batches):
                 torch.cuda.set_stream(self.streams[k % self.nstreams])  # (allocations of the outputs belong to the stream that fills them)
-                self.feats[k] = bank.extract_collated(plan, bt["arena"], bt["offs"], bt["lens"], bt["idx"], bt["front"], LOG_EPSILON)
+                self.feats[k] = bank.extract_collated(plan, bt["arena"], bt["offs"], bt["lens"], bt["idx"], bt["front"], LOG_EPSILON, group_sizes=bt["sizes"])
         finally:
             torch.cuda.set_stream(main)
         for s in self.streams:  # join: the step ends on the launch stream, where bench.py's events are recorded
@@ -500,9 +510,10 @@ class OnTheFly:
             main.wait_event(e)
 
     def clear(self):
-        for k in range(self.NB):
-            if self.feats[k] is not None:
-                self.feats[k][0].zero_()
+        for ft in self.feats:
+            if ft is not None:
+                for t in (ft[0] if isinstance(ft[0], list) else [ft[0]]):
+                    t.zero_()
 
     def parity(self, rank):
         from oracle import resample_ref as R
@@ -513,19 +524,24 @@ class OnTheFly:
         o32, o64 = RefExtractor(RefConfig(kind="fbank"), np.float32), RefExtractor(RefConfig(kind="fbank"), np.float64)
         stats = []
         for _ in range(PARITY_CUTS):
-            b = int(rs.randint(self.NB))
+            b = int(rs.randint(len(self.batches)))
             bt = self.batches[b]
             f, fl, po, pl = self.feats[b]
             i = int(rs.randint(len(bt["lens"])))
+            if isinstance(f, list):  # --prefetch K: the mini-batch of cut i, and the cut's row in that mini-batch's tensor
+                j = int(np.searchsorted(bt["first"], i, side="right")) - 1
+                f, row = f[j], i - int(bt["first"][j])
+            else:
+                row = i
             x = bt["arena"][int(bt["offs"][i]) : int(bt["offs"][i]) + int(bt["lens"][i])].cpu().numpy()
             fac = float(bt["fac"][i])
             y32 = R.speed(x, SR, fac, np.float32) if fac != 1.0 else x
             y64 = R.speed(x.astype(np.float64), SR, fac, np.float64) if fac != 1.0 else x.astype(np.float64)
             assert len(y32) == int(pl[i]), (len(y32), int(pl[i]))
             want, truth = o32.extract(y32), o64.extract(y64)
-            got = f[i, : int(fl[i])].cpu().numpy()
+            got = f[row, : int(fl[i])].cpu().numpy()
             assert got.shape == want.shape, (got.shape, want.shape)
-            assert bool((f[i, int(fl[i]) :] == LOG_EPSILON).all()), "padding rows of the collated batch"
+            assert bool((f[row, int(fl[i]) :] == LOG_EPSILON).all()), "padding rows of the collated batch"
             stats.append(compare(got, want, truth))
         return fold(stats)
 
@@ -545,22 +561,33 @@ class OnTheFly:
                 torch.cuda.synchronize(self.dev)  # keep the queues short: the enqueue time must not include waiting for queue space
         torch.cuda.synchronize(self.dev)
         dt = time.perf_counter() - t0
-        return round(self.units * n / dt, 1), round(host / (n * self.NB) * 1e6, 2)
+        return round(self.units * n / dt, 1), round(host / (n * self.NB) * 1e6, 2)  # (per MINI-BATCH, whatever the prefetch depth)
 
     def extra(self, args):
         """Same-call A/B of the routes (device-resident), the host's share per mini-batch, and the host-fed rate."""
+        import copy
+
         out = {}
         keep = (self.route, self.streams, self.nstreams)
         ab = {}
-        for name, route, ns in (("pair_2_streams", "pair", 2), ("pair_1_stream", "pair", 1), ("per_factor_route_of_round_3", "per_factor", 1)):
-            self.route, self.nstreams = route, ns
-            self.streams = [self.torch.cuda.Stream(device=self.dev) for _ in range(ns)] if ns > 1 else []
-            r, h = self._rate()
+        for name, route, ns, K in (("pair_3_streams", "pair", 3, 1), ("pair_2_streams", "pair", 2, 1), ("pair_1_stream", "pair", 1, 1),
+                                   ("pair_4_minibatches_per_call_2_streams", "pair", 2, 4), ("per_factor_route_of_round_3", "per_factor", 1, 1)):
+            w = self
+            if K != self.K:
+                a2 = copy.copy(args)
+                a2.prefetch, a2.cuts = K, self.NB
+                w = OnTheFly(self.dev, self.rank, a2)
+            w.route, w.nstreams = route, ns
+            w.streams = [self.torch.cuda.Stream(device=self.dev) for _ in range(ns)] if ns > 1 else []
+            r, h = w._rate()
             ab[name] = {"cuts_per_s": r, "host_us_per_minibatch": h}
+            if w is not self:
+                del w
         self.route, self.streams, self.nstreams = keep
-        ab["what"] = ("device-resident, ~1 s each in this run: `pair` = hipfeat_minibatch_plan + _run (two launches, tables in the kernel arguments), on two "
-                      "alternating streams or one; `per_factor` = one hipfeat_resample launch per factor + hipfeat_extract_collated; host_us = wall time of "
-                      "the enqueue loop per mini-batch (Python + ctypes + the HIP launches)")
+        ab["what"] = ("device-resident, ~1 s each in this run: `pair` = hipfeat_minibatch_plan + _run (two launches, tables in the kernel arguments), calls "
+                      "alternating over 3 / 2 / 1 streams, one mini-batch per call or four (a loader that prefetches: every mini-batch still its own dense "
+                      "tensor); `per_factor` = one hipfeat_resample launch per factor + hipfeat_extract_collated; host_us = wall time of the enqueue loop "
+                      "per mini-batch (Python + ctypes + the HIP launches; an upper bound: it includes waiting for a free table slot when the device is the slower side)")
         out["routes"] = ab
         if not args.no_host_fed:
             out["host_fed"] = onthefly_host_fed(self)
@@ -830,7 +857,7 @@ def onthefly_host_fed(w, seconds: float = 3.0):
         packed, offs, lens = pack_to_device(host[k], w.dev)
         arena = torch.empty(((packed.numel() + 3) & ~3) + A.perturbed_tail_floats(lens, bt["fac"], SR), dtype=torch.float32, device=w.dev)
         arena[: packed.numel()].copy_(packed, non_blocking=True)
-        return w.bank.extract_collated(w.plan, arena, offs, lens, bt["idx"], packed.numel(), LOG_EPSILON)
+        return w.bank.extract_collated(w.plan, arena, offs, lens, bt["idx"], packed.numel(), LOG_EPSILON, group_sizes=bt["sizes"])
 
     one(0)
     torch.cuda.synchronize()
@@ -845,7 +872,7 @@ def onthefly_host_fed(w, seconds: float = 3.0):
         n += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"batches_per_s": round(n / dt, 1), "cuts_per_s": round(cuts / dt, 1), "audio_seconds_per_s": round(secs / dt, 1),
+    return {"batches_per_s": round(n * w.K / dt, 1), "cuts_per_s": round(cuts / dt, 1), "audio_seconds_per_s": round(secs / dt, 1),
             "what": "600 s mini-batches as host float32 arrays -> pack + H2D -> speed perturbation -> fbank collated on the device; PCIe-inclusive, never `value`"}
 
 
@@ -911,13 +938,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="fbank16k", choices=sorted(WORKLOADS), help="fbank16k = BASELINE configs[1] (default), mfcc40_libri = configs[3], onthefly = configs[4], bulk_save = the offline path end to end (SURVEY 8d iii)")
     ap.add_argument("--cuts", type=int, default=0, help="cuts per GPU per step (onthefly: mini-batches per step); default per config")
-    ap.add_argument("--streams", type=int, default=2, help="onthefly: streams the mini-batches alternate over (default 2)")
+    ap.add_argument("--prefetch", type=int, default=1, help="onthefly: mini-batches per call (a loader that prefetches K packs them into one arena and gets K dense tensors "
+                    "from ONE pair of launches); default 1")
+    ap.add_argument("--streams", type=int, default=3, help="onthefly: streams the calls alternate over (default 3)")
     ap.add_argument("--route", default="pair", choices=["pair", "per_factor"], help="onthefly: `pair` = the two-launch mini-batch (default), `per_factor` = round 3's route")
     ap.add_argument("--total-cuts", type=int, default=0, help="fbank16k only: STRONG scaling (BASELINE configs[2]: 100000): this many cuts in total per step, "
                     "sharded round-robin over the ranks (same global corpus for every N); default 0 = weak scaling, --cuts per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (`extra`) altogether: A/B runs")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="host processes of the CPU baseline (default: best of a sweep over cores/8, cores/4, cores/2)")
     ap.add_argument("--input", default="uniform", choices=["uniform", "zeros", "sine"], help="fbank16k: synthetic input (the metric is defined on `uniform`; the others exist to expose power/DVFS effects)")
@@ -1097,7 +1127,7 @@ def main():
                         "/ (1024 SIMDs x 2.4 GHz): the share of the chip's VALU issue slots this launch rate needs",
             }
         if world == 1:
-            extra = w.extra(args)
+            extra = {} if args.no_extra else w.extra(args)
             if extra:
                 res["extra"] = extra
             if not args.no_cpu_baseline:

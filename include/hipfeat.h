@@ -265,15 +265,20 @@ HIPFEAT_API hipfeat_status hipfeat_resample(const hipfeat_resampler* resampler, 
  * tensor.  Results are bit-identical to hipfeat_resample per factor + hipfeat_extract_collated.
  *
  * A bank = the resamplers a mini-batch may refer to (h_bank_index[b] = index into the bank, -1 = unperturbed); they must be of the
- * compile-time ratios 9:10, 11:10, 19:20, 21:20 (speed 0.9 / 1.1 / 0.95 / 1.05, width 7) -- anything else: HIPFEAT_ERR_UNSUPPORTED,
- * use hipfeat_resample per factor -- and must outlive the bank.
+ * compile-time ratios 9:10 and 11:10 (speed 0.9 / 1.1, width 7: the factors of Kaldi-style three-way speed perturbation) -- anything
+ * else: HIPFEAT_ERR_UNSUPPORTED, use hipfeat_resample per factor -- and must outlive the bank.
  *
  * hipfeat_minibatch_plan is host arithmetic only: where each perturbed cut goes (h_out_offsets), how long it is (h_out_num_samples;
  * ceil(new * n / orig) as hipfeat_resampled_length, capped by h_max_samples[b] >= 0 when given: lhotse truncates a perturbed cut to
- * the sample count its manifest states, lhotse/audio/recording.py:1058-1060), its frame count (h_num_frames), and in h_info[3] =
- * {ticket, floats the arena must hold, largest frame count} -- what the caller needs to allocate the arena and the output.
- * zero_pad_batch != 0 frames every cut on a row of the longest cut's length (edge_rule "batch_zero_pad", _extract_batch's rule).
- * hipfeat_minibatch_run enqueues the two launches of a planned mini-batch on `stream`; rows_per_cut >= h_info[2].  Up to 16 plans may
+ * the sample count its manifest states, lhotse/audio/recording.py:1058-1060), its frame count (h_num_frames), and in h_info[4] =
+ * {ticket, floats the arena must hold, largest frame count, rows of the output} -- what the caller needs to allocate the arena and the
+ * output.  zero_pad_batch != 0 frames every cut on a row of the longest cut's length (edge_rule "batch_zero_pad", _extract_batch's rule).
+ * SEVERAL mini-batches per launch pair (a prefetching loader: fewer, larger launches fill 256 CUs better than one 600 s mini-batch can):
+ * num_groups > 1 and h_group_sizes[k] = cuts of mini-batch k (consecutive cuts; the sizes add up to `batch`).  Every mini-batch then is
+ * its own dense (B_k, T_k, feature_dim) tensor, T_k = its longest cut, the tensors back to back in d_out: h_group_rows[2k] = first row,
+ * h_group_rows[2k + 1] = T_k; h_info[3] = rows in total.  num_groups <= 1 (h_group_sizes may be NULL): one mini-batch.
+ * hipfeat_minibatch_run enqueues the two launches of a planned mini-batch on `stream`; one mini-batch: rows_per_cut >= h_info[2] (the
+ * caller may want more rows than the longest cut has); grouped plans: rows_per_cut = -1, d_out holds h_info[3] rows.  Up to 16 plans may
  * be outstanding per bank; a bank may be shared by threads (calls are serialised inside).
  */
 typedef struct hipfeat_speed_bank hipfeat_speed_bank;
@@ -282,8 +287,9 @@ HIPFEAT_API hipfeat_status hipfeat_speed_bank_create(const hipfeat_resampler* co
 HIPFEAT_API hipfeat_status hipfeat_speed_bank_destroy(hipfeat_speed_bank* bank);
 HIPFEAT_API hipfeat_status hipfeat_minibatch_plan(hipfeat_speed_bank* bank, const hipfeat_plan* plan, int64_t batch, const int64_t* h_offsets,
                                                   const int64_t* h_num_samples, const int32_t* h_bank_index, const int64_t* h_max_samples,
-                                                  int64_t tail_start, int32_t zero_pad_batch, int64_t* h_out_offsets,
-                                                  int64_t* h_out_num_samples, int64_t* h_num_frames, int64_t* h_info);
+                                                  int64_t tail_start, int32_t zero_pad_batch, int64_t num_groups, const int64_t* h_group_sizes,
+                                                  int64_t* h_out_offsets, int64_t* h_out_num_samples, int64_t* h_num_frames,
+                                                  int64_t* h_group_rows, int64_t* h_info);
 HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* bank, int64_t ticket, float* d_arena, int64_t arena_floats, float* d_out,
                                                  int64_t rows_per_cut, float pad_value, void* stream);
 

@@ -72,7 +72,7 @@ _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
     "hipfeat_minibatch_plan": (
         "int",
         ["hipfeat_speed_bank*", "const hipfeat_plan*", "int64_t", "const int64_t*", "const int64_t*", "const int32_t*", "const int64_t*", "int64_t", "int32_t",
-         "int64_t*", "int64_t*", "int64_t*", "int64_t*"],
+         "int64_t", "const int64_t*", "int64_t*", "int64_t*", "int64_t*", "int64_t*", "int64_t*"],
     ),
     "hipfeat_minibatch_run": ("int", ["hipfeat_speed_bank*", "int64_t", "float*", "int64_t", "float*", "int64_t", "float", "void*"]),
     "hipfeat_extract_host": (
@@ -144,6 +144,9 @@ class _CtypesBackend:
     def call(self, name: str, *args):
         return self.fns[name](*args)
 
+    def bound(self, name: str):
+        return self.fns[name]
+
     @staticmethod
     def string(v) -> str:
         return v.decode() if v else ""
@@ -177,6 +180,9 @@ class _CffiBackend:
                 conv.append(a)
         return self.fns[name](*conv)
 
+    def bound(self, name: str):
+        return lambda *args: self.call(name, *args)
+
     def string(self, v) -> str:
         return self.ffi.string(v).decode() if v != self.ffi.NULL else ""
 
@@ -202,6 +208,11 @@ class Lib:
 
     def raw(self, name: str, *args):
         return self.backend.call(name, *args)
+
+    def fn(self, name: str):
+        """The bound entry point itself (hot paths that call it per mini-batch skip the name lookup): takes the same plain integers /
+        floats / None as `raw` and returns the status code."""
+        return self.backend.bound(name)
 
     def last_error(self) -> str:
         return self.backend.string(self.raw("hipfeat_last_error"))

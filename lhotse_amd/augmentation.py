@@ -283,8 +283,8 @@ def perturb_speed_in_arena(arena: torch.Tensor, offsets: np.ndarray, lengths: np
 class HipSpeedBank:
     """The resamplers a mini-batch may refer to, resident on one device (``hipfeat_speed_bank``, include/hipfeat.h): mixed-factor speed
     perturbation of a packed mini-batch + the collated feature extraction as a PAIR of launches with no host -> device copy in front of
-    them (``hipfeat_minibatch_plan`` / ``hipfeat_minibatch_run``).  Factors must be among 0.9 / 1.1 / 0.95 / 1.05 (the compile-time
-    ratios of the mixed launch) and 1.0; anything else raises ``HipFeatError`` (UNSUPPORTED) -- use ``perturb_speed_in_arena``.
+    them (``hipfeat_minibatch_plan`` / ``hipfeat_minibatch_run``).  Factors must be among 0.9 / 1.1 (the compile-time ratios of the
+    mixed launch) and 1.0; anything else raises ``HipFeatError`` (UNSUPPORTED) -- use ``perturb_speed_in_arena``.
 
         bank = HipSpeedBank([0.9, 1.0, 1.1], 16000, "cuda:0")
         feats, frames, offs, lens = bank.extract_collated(extractor.plan, arena, offsets, lengths, bank.index_of(factors), tail_start, LOG_EPSILON)
@@ -302,8 +302,9 @@ class HipSpeedBank:
         self.handle = 0
         self.lib.check("hipfeat_speed_bank_create", _lib.addr(handles) if len(handles) else None, len(handles), _lib.addr(out))
         self.handle = int(out[0])
-        self._info = np.zeros(3, dtype=np.int64)
+        self._info = np.zeros(4, dtype=np.int64)
         self._info_addr = _lib.addr(self._info)
+        self._plan_fn, self._run_fn = self.lib.fn("hipfeat_minibatch_plan"), self.lib.fn("hipfeat_minibatch_run")  # bound once: this is a per-mini-batch path
         self._lock = threading.Lock()
 
     def index_of(self, factors: Sequence[float]) -> np.ndarray:
@@ -319,23 +320,42 @@ class HipSpeedBank:
 
     def extract_collated(self, plan, arena: torch.Tensor, offsets: np.ndarray, lengths: np.ndarray, bank_index: np.ndarray, tail_start: int,
                          pad_value: float, max_samples: Optional[np.ndarray] = None, zero_pad_batch: bool = False,
-                         stream: Optional[int] = None) -> Tuple[torch.Tensor, np.ndarray, np.ndarray, np.ndarray]:
+                         stream: Optional[int] = None, group_sizes: Optional[np.ndarray] = None):
         """-> (features (B, Tmax, F) on the arena's device, frame counts, per-cut offsets and lengths of the PERTURBED batch in the arena).
         ``offsets`` / ``lengths`` int64, ``bank_index`` int32 (``index_of``), all C-contiguous numpy arrays; the arena must hold
-        ``perturbed_tail_floats`` floats behind ``tail_start``."""
+        ``perturbed_tail_floats`` floats behind ``tail_start``.
+
+        ``group_sizes`` (int64 array, K entries adding up to B): the batch is K mini-batches -- a prefetching loader's -- served by ONE
+        pair of launches; the first result then is a LIST of K dense ``(B_k, Tmax_k, F)`` tensors (views of one allocation)."""
         B = len(lengths)
-        res = np.empty((3, B), dtype=np.int64)  # rows: offsets, lengths, frames of the perturbed batch
+        K = 0 if group_sizes is None else len(group_sizes)
+        res = np.empty(3 * B + 2 * K, dtype=np.int64)  # offsets, lengths, frames of the perturbed batch; (first row, rows per cut) per group
         a = res.__array_interface__["data"][0]
-        with self._lock:  # (the info triple is shared; the library serialises the calls anyway)
-            self.lib.check("hipfeat_minibatch_plan", self.handle, plan.handle, B, offsets.__array_interface__["data"][0], lengths.__array_interface__["data"][0],
-                           bank_index.__array_interface__["data"][0], None if max_samples is None else max_samples.__array_interface__["data"][0],
-                           int(tail_start), 1 if zero_pad_batch else 0, a, a + 8 * B, a + 16 * B, self._info_addr)
-            ticket, need, tmax = int(self._info[0]), int(self._info[1]), int(self._info[2])
-        out = torch.empty((B, tmax, plan.feature_dim), dtype=torch.float32, device=arena.device)
+        info, fn = self._info, self._plan_fn
+        with self._lock:  # (the info block is shared; the library serialises the calls anyway)
+            st = fn(self.handle, plan.handle, B, offsets.__array_interface__["data"][0], lengths.__array_interface__["data"][0],
+                    bank_index.__array_interface__["data"][0], None if max_samples is None else max_samples.__array_interface__["data"][0],
+                    int(tail_start), 1 if zero_pad_batch else 0, K, None if K == 0 else group_sizes.__array_interface__["data"][0],
+                    a, a + 8 * B, a + 16 * B, (a + 24 * B) if K else None, self._info_addr)
+            if st != 0:
+                raise _lib.HipFeatError(int(st), self.lib.last_error())
+            ticket, tmax, rows = int(info[0]), int(info[2]), int(info[3])
+        F = plan.feature_dim
         if stream is None:
             stream = torch.cuda.current_stream(arena.device).cuda_stream
-        self.lib.check("hipfeat_minibatch_run", self.handle, ticket, arena.data_ptr(), arena.numel(), out.data_ptr(), tmax, float(pad_value), int(stream))
-        return out, res[2], res[0], res[1]
+        if K > 1:
+            flat = torch.empty(rows * F, dtype=torch.float32, device=arena.device)
+            st = self._run_fn(self.handle, ticket, arena.data_ptr(), arena.numel(), flat.data_ptr(), -1, float(pad_value), int(stream))
+            g = res[3 * B :].tolist()
+            out = [flat[g[2 * k] * F : (g[2 * k] + int(group_sizes[k]) * g[2 * k + 1]) * F].view(int(group_sizes[k]), g[2 * k + 1], F) for k in range(K)]
+        else:
+            out = torch.empty((B, tmax, F), dtype=torch.float32, device=arena.device)
+            st = self._run_fn(self.handle, ticket, arena.data_ptr(), arena.numel(), out.data_ptr(), tmax, float(pad_value), int(stream))
+            if K == 1:
+                out = [out]
+        if st != 0:
+            raise _lib.HipFeatError(int(st), self.lib.last_error())
+        return out, res[2 * B : 3 * B], res[:B], res[B : 2 * B]
 
     def close(self):
         if self.handle:

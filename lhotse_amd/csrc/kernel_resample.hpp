@@ -115,11 +115,15 @@ __device__ __forceinline__ void resample_fast_block(const float* __restrict__ in
 #pragma unroll
   for (int ph = 0; ph < NEW; ++ph) acc[ph] = 0.f;
   const float* xr = xs + tid * ORIG;
+  // the bank through the constant address space: wave-uniform, read-only for the whole launch -> scalar loads, SGPR operands.  (As a plain
+  // pointer that came out of a struct the compiler has to assume that the kernel's own stores may alias it, fetches the 250 coefficients
+  // with vector loads into 250 registers per lane -- and the mixed launch ran at half the rate of the per-factor ones.)
+  const __attribute__((address_space(4))) float* ktc = (const __attribute__((address_space(4))) float*)kt;
 #pragma unroll
   for (int i = 0; i < G::KW; ++i) {
     const float xv = xr[i];
 #pragma unroll
-    for (int ph = 0; ph < NEW; ++ph) acc[ph] = fmaf(xv, kt[i * G::NEWP + ph], acc[ph]);
+    for (int ph = 0; ph < NEW; ++ph) acc[ph] = fmaf(xv, ktc[i * G::NEWP + ph], acc[ph]);
   }
   __syncthreads();
 #pragma unroll

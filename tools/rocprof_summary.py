@@ -27,3 +27,26 @@ def main(path):
 
 if __name__ == "__main__":
     main(sys.argv[1])
+
+
+def gaps(path):
+    """Busy time vs span of the hipfeat dispatches (one-stream traces: how much of the wall time is gaps between kernels)."""
+    c = sqlite3.connect(path)
+    try:
+        rows = c.execute("select start, end, name from kernels where name like '%hipfeat%' order by start").fetchall()
+    except Exception as e:  # noqa: BLE001
+        print("# no start/end columns:", e)
+        return
+    if len(rows) < 4:
+        return
+    rows = rows[len(rows) // 4:]  # skip warm-up
+    busy = sum(e - s for s, e, _ in rows)
+    span = rows[-1][1] - rows[0][0]
+    gl = [rows[i + 1][0] - rows[i][1] for i in range(len(rows) - 1)]
+    gl.sort()
+    print(f"\n# timeline of the last {len(rows)} hipfeat dispatches: span {span/1e3:.1f} us, kernels busy {busy/1e3:.1f} us ({busy/span:.3f}), "
+          f"gap median {gl[len(gl)//2]/1e3:.2f} us, p90 {gl[int(len(gl)*0.9)]/1e3:.2f} us, negative gaps (overlap) {sum(1 for g in gl if g < 0)}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1:
+    gaps(sys.argv[1])
