@@ -590,14 +590,16 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
 // --------------------------------------------------------------------------------------
 // fft1024 wave-autonomous fbank kernel (kernel_fft1024c.hpp): 22.05 / 24 / 32 kHz Kaldi log-mel
 // --------------------------------------------------------------------------------------
-template <int NROWS, int S0 = 0, int S1 = 0, int S2 = 0>
+template <int NROWS, int S0 = 0, int S1 = 0, int S2 = 0, bool PLAIN = false>
 static const void* fft1024c_entry() {
-  return reinterpret_cast<const void*>(&fft1024c_kernel<NROWS, S0, S1, S2>);
+  return reinterpret_cast<const void*>(&fft1024c_kernel<NROWS, S0, S1, S2, PLAIN>);
 }
 // instances with the mel schedule as compile-time constants (kernel_fft1024c.hpp): 1 = <20, 24,16,8> (24 kHz), 2 = <26, 24,16,8> (32 kHz),
-// 3 = <20, 24,24,8> (22.05 kHz); 0 = generic
-static int fft1024c_fixed_id(int nrows, int nsets, const int* steps) {
+// 3 = <20, 24,24,8> (22.05 kHz), 4 = <32, 16,16,8, PLAIN> (the librosa default: n_fft 1024 @ 22.05 kHz, 80 slaney filters, no DC removal,
+// no pre-emphasis); 0 = generic
+static int fft1024c_fixed_id(int nrows, int nsets, const int* steps, bool plain) {
   if (nsets != 3 || getenv("HIPFEAT_NO_FIXED_SCHEDULE")) return 0;
+  if (nrows == 32) return plain && steps[0] == 16 && steps[1] == 16 && steps[2] == 8 ? 4 : 0;
   if (nrows == 20 && steps[0] == 24 && steps[1] == 16 && steps[2] == 8) return 1;
   if (nrows == 26 && steps[0] == 24 && steps[1] == 16 && steps[2] == 8) return 2;
   if (nrows == 20 && steps[0] == 24 && steps[1] == 24 && steps[2] == 8) return 3;
@@ -660,7 +662,7 @@ static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, con
   p->c_shared_floats = (int)img.size();
   p->c_xs_floats = (3 * shift + 32 * nrows + 3) & ~3;
   // fixed-schedule instances: 12 waves per workgroup, the span buffer aliases the exchange / power region (kernel_fft1024c.hpp)
-  int fixed = fft1024c_fixed_id(nrows, sch.nsets, sch.steps);
+  int fixed = fft1024c_fixed_id(nrows, sch.nsets, sch.steps, !c.remove_dc_offset && c.preemph_coeff == 0.0f);
   if (fixed && p->c_xs_floats > kWRegion) fixed = 0;
   const int waves = fixed ? kWWavesFixed : kWWaves;
   const size_t lds = ((size_t)p->c_shared_floats + (size_t)waves * (fixed ? kWRegion : p->c_xs_floats + kWRegion)) * sizeof(float);
@@ -668,6 +670,7 @@ static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, con
   const void* fn = fixed == 1 ? fft1024c_entry<20, 24, 16, 8>()
                    : fixed == 2 ? fft1024c_entry<26, 24, 16, 8>()
                    : fixed == 3 ? fft1024c_entry<20, 24, 24, 8>()
+                   : fixed == 4 ? fft1024c_entry<32, 16, 16, 8, true>()
                    : nrows == 20 ? fft1024c_entry<20>() : (nrows == 26 ? fft1024c_entry<26>() : fft1024c_entry<32>());
   hipError_t e = ensure_dynamic_lds(fn, lds);
   if (e != hipSuccess) return fail(HIPFEAT_ERR_HIP, "hipFuncSetAttribute(fft1024c) failed: %s", hipGetErrorName(e));
@@ -1737,6 +1740,7 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     if (plan->w_fixed == 1) hipLaunchKernelGGL((fft1024c_kernel<20, 24, 16, 8>), grid, block, plan->fast_lds_bytes, stream, fp);
     else if (plan->w_fixed == 2) hipLaunchKernelGGL((fft1024c_kernel<26, 24, 16, 8>), grid, block, plan->fast_lds_bytes, stream, fp);
     else if (plan->w_fixed == 3) hipLaunchKernelGGL((fft1024c_kernel<20, 24, 24, 8>), grid, block, plan->fast_lds_bytes, stream, fp);
+    else if (plan->w_fixed == 4) hipLaunchKernelGGL((fft1024c_kernel<32, 16, 16, 8, true>), grid, block, plan->fast_lds_bytes, stream, fp);
     else if (plan->nrows == 20) hipLaunchKernelGGL(fft1024c_kernel<20>, grid, block, plan->fast_lds_bytes, stream, fp);
     else if (plan->nrows == 26) hipLaunchKernelGGL(fft1024c_kernel<26>, grid, block, plan->fast_lds_bytes, stream, fp);
     else hipLaunchKernelGGL(fft1024c_kernel<32>, grid, block, plan->fast_lds_bytes, stream, fp);

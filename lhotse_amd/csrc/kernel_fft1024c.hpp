@@ -65,7 +65,11 @@ __device__ __forceinline__ v2 sel64(unsigned long long m, v2 a, v2 b) { return v
 // power cap: latency-limited at 2 waves/SIMD).  The LDS for that comes from giving up the span prefetch: the wave's span buffer ALIASES its
 // exchange / power region (8.8 KB per wave instead of 14.2), the span of a round is requested at the top of that round and waited for at
 // once -- the third wave per SIMD covers that latency and more.
-template <int NROWS, int S0 = 0, int S1 = 0, int S2 = 0>
+//
+// PLAIN: no DC removal and no pre-emphasis (the librosa-style front end, lhotse/features/librosa_fbank.py:66-137: y = x * window): no
+// left-neighbour reads, no mean, and -- what makes the librosa default <32, 16, 16, 8, true> fit the 168 registers of 3 waves/SIMD with
+// all 32 input rows live, where round 3's attempt spilled 17 -- the window goes onto the samples as they arrive.
+template <int NROWS, int S0 = 0, int S1 = 0, int S2 = 0, bool PLAIN = false>
 __global__ __launch_bounds__(64 * (S0 != 0 ? kWWavesFixed : kWWaves), (S0 != 0 ? 3 : 2)) void fft1024c_kernel(const Fft1024cParams p) {
   constexpr bool kFixed = S0 != 0;
   constexpr int kWv = kFixed ? kWWavesFixed : kWWaves;  // waves per workgroup
@@ -151,14 +155,16 @@ __global__ __launch_bounds__(64 * (S0 != 0 ? kWWavesFixed : kWWaves), (S0 != 0 ?
       const float* x = xs + mul24(g, shift) + 2 * q;
       v2 z[32];
       v2 win[NROWS];
-      float pv[NROWS];  // left neighbour of each pair's first sample (the frame's first sample replicates itself, layers.py:166)
+      float pv[PLAIN ? 1 : NROWS];  // left neighbour of each pair's first sample (the frame's first sample replicates itself, layers.py:166)
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) {
         z[n1] = *reinterpret_cast<const v2*>(x + 32 * n1);
         HFC_SEP();
       }
+      if (!PLAIN) {
 #pragma unroll
-      for (int n1 = 0; n1 < NROWS; ++n1) pv[n1] = n1 == 0 ? x[q == 0 ? 0 : -1] : x[32 * n1 - 1];
+        for (int n1 = 0; n1 < NROWS; ++n1) pv[n1] = n1 == 0 ? x[q == 0 ? 0 : -1] : x[32 * n1 - 1];
+      }
 #pragma unroll
       for (int n1 = 0; n1 < NROWS; ++n1) {
         win[n1] = cwin[n1 * 16 + q];
@@ -178,21 +184,24 @@ __global__ __launch_bounds__(64 * (S0 != 0 ? kWWavesFixed : kWWaves), (S0 != 0 ?
           if (m0 + 1 >= N) z[n1].y = 0.f;
         }
       }
-      float mu = 0.f;
-      if (dc) {
-        v2 sa = z[0], sb = z[1], sc = z[2], sd = z[3];
+      if (PLAIN) {
 #pragma unroll
-        for (int n1 = 4; n1 < NROWS; ++n1) {
-          if ((n1 & 3) == 0) sa += z[n1];
-          if ((n1 & 3) == 1) sb += z[n1];
-          if ((n1 & 3) == 2) sc += z[n1];
-          if ((n1 & 3) == 3) sd += z[n1];
+        for (int n1 = 0; n1 < NROWS; ++n1) z[n1] = z[n1] * win[n1];
+      } else {
+        float mu = 0.f;
+        if (dc) {
+          v2 sa = z[0], sb = z[1], sc = z[2], sd = z[3];
+#pragma unroll
+          for (int n1 = 4; n1 < NROWS; ++n1) {
+            if ((n1 & 3) == 0) sa += z[n1];
+            if ((n1 & 3) == 1) sb += z[n1];
+            if ((n1 & 3) == 2) sc += z[n1];
+            if ((n1 & 3) == 3) sd += z[n1];
+          }
+          const v2 sum2 = (sa + sb) + (sc + sd);
+          mu = row16_sum(sum2.x + sum2.y) * inv_n;
         }
-        const v2 sum2 = (sa + sb) + (sc + sd);
-        mu = row16_sum(sum2.x + sum2.y) * inv_n;
-      }
-      // y[n] = (x[n] - mu) - c (x[n-1] - mu) = x[n] - c x[n-1] - (1 - c) mu, times the window
-      {
+        // y[n] = (x[n] - mu) - c (x[n-1] - mu) = x[n] - c x[n-1] - (1 - c) mu, times the window
         const float nc = -c, mu1 = (1.0f - c) * mu;
 #pragma unroll
         for (int n1 = 0; n1 < NROWS; ++n1) {

@@ -37,3 +37,24 @@ def test_fixed_schedule_instances_equal_the_generic_ones(sr, kernel, monkeypatch
 def test_other_filterbanks_run_the_generic_instance():
     ex = make_hip("fbank", {"sampling_rate": 24000, "num_filters": 64})
     assert ex.kernel_name.startswith("fft1024c_kernel<20>") and "fixed-schedule" not in ex.kernel_name, ex.kernel_name
+
+
+def test_librosa_default_runs_the_plain_fixed_schedule_instance(monkeypatch):
+    """Round 4: the librosa default (n_fft 1024 @ 22.05 kHz, hop 256, 80 slaney filters; no DC removal, no pre-emphasis) has its own
+    instance fft1024c_kernel<32, 16, 16, 8, PLAIN> at 3 waves/SIMD; other librosa configurations keep the generic one.  Same instructions
+    on the same operands in the same order: bit-identical outputs (both are checked against the librosa oracle in test_gpu_librosa.py)."""
+    import lhotse_amd as LA
+
+    fixed = LA.HipLibrosaFbank()
+    assert fixed.kernel_name.startswith("fft1024c_kernel<32>") and "fixed-schedule" in fixed.kernel_name and "waves=12" in fixed.kernel_name, fixed.kernel_name
+    monkeypatch.setenv("HIPFEAT_NO_FIXED_SCHEDULE", "1")
+    generic = LA.HipLibrosaFbank()
+    assert generic.kernel_name.startswith("fft1024c_kernel<32>") and "fixed-schedule" not in generic.kernel_name, generic.kernel_name
+    monkeypatch.delenv("HIPFEAT_NO_FIXED_SCHEDULE")
+    rng = np.random.default_rng(5)
+    waves = [torch.from_numpy((rng.standard_normal(n) * a).astype(np.float32)) for n, a in ((20000, 0.1), (3 * 22050 + 17, 0.3), (1500, 1e-3), (7 * 22050 + 5, 0.05), (220500, 0.2))]
+    for w in waves:
+        a, b = fixed.extract(w, 22050), generic.extract(w, 22050)
+        assert a.shape == b.shape and a.shape[1] == 80 and torch.equal(torch.as_tensor(a), torch.as_tensor(b))
+    other = LA.HipLibrosaFbank(LA.HipLibrosaFbankConfig(num_mel_bins=64))
+    assert "fixed-schedule" not in other.kernel_name, other.kernel_name
