@@ -546,22 +546,34 @@ class OnTheFly:
         return fold(stats)
 
     def _rate(self, seconds: float = 1.0):
-        """(cuts/s, host microseconds per mini-batch) of the current route: the enqueue loop is timed on its own (no synchronisation
-        inside), then the device is drained."""
+        """(cuts/s, host microseconds per mini-batch) of the current route.  The host figure is the wall time of enqueueing a burst of
+        8 mini-batches right after the device has drained (nothing to wait for: fewer calls than the library has table slots), i.e.
+        Python + ctypes + the HIP launch calls themselves."""
         torch = self.torch
         self.step()
         torch.cuda.synchronize(self.dev)
-        n, host, t0 = 0, 0.0, time.perf_counter()
+        n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < seconds:
-            h0 = time.perf_counter()
             self.step()
-            host += time.perf_counter() - h0
             n += 1
             if n % 4 == 0:
-                torch.cuda.synchronize(self.dev)  # keep the queues short: the enqueue time must not include waiting for queue space
+                torch.cuda.synchronize(self.dev)
         torch.cuda.synchronize(self.dev)
         dt = time.perf_counter() - t0
-        return round(self.units * n / dt, 1), round(host / (n * self.NB) * 1e6, 2)  # (per MINI-BATCH, whatever the prefetch depth)
+        keep = self.batches
+        burst = max(1, 8 // self.K)
+        host = []
+        for i in range(0, len(keep) - burst + 1, burst):
+            self.batches = keep[i : i + burst]
+            torch.cuda.synchronize(self.dev)
+            h0 = time.perf_counter()
+            self.step()
+            host.append((time.perf_counter() - h0) / (burst * self.K))
+        self.batches = keep
+        self.step()  # (self.feats back in step with self.batches)
+        torch.cuda.synchronize(self.dev)
+        host.sort()
+        return round(self.units * n / dt, 1), round(host[len(host) // 2] * 1e6, 2)  # (per MINI-BATCH, whatever the prefetch depth)
 
     def extra(self, args):
         """Same-call A/B of the routes (device-resident), the host's share per mini-batch, and the host-fed rate."""
@@ -586,8 +598,8 @@ class OnTheFly:
         self.route, self.streams, self.nstreams = keep
         ab["what"] = ("device-resident, ~1 s each in this run: `pair` = hipfeat_minibatch_plan + _run (two launches, tables in the kernel arguments), calls "
                       "alternating over 3 / 2 / 1 streams, one mini-batch per call or four (a loader that prefetches: every mini-batch still its own dense "
-                      "tensor); `per_factor` = one hipfeat_resample launch per factor + hipfeat_extract_collated; host_us = wall time of the enqueue loop "
-                      "per mini-batch (Python + ctypes + the HIP launches; an upper bound: it includes waiting for a free table slot when the device is the slower side)")
+                      "tensor); `per_factor` = one hipfeat_resample launch per factor + hipfeat_extract_collated; host_us = median wall time per mini-batch of "
+                      "enqueueing a burst of 8 mini-batches on a drained device (Python + ctypes + the HIP launch calls; includes the stream fork / join of a step)")
         out["routes"] = ab
         if not args.no_host_fed:
             out["host_fed"] = onthefly_host_fed(self)

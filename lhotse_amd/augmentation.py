@@ -279,6 +279,15 @@ def perturb_speed_in_arena(arena: torch.Tensor, offsets: np.ndarray, lengths: np
     return offsets, lengths
 
 
+def _raw_stream(device: torch.device) -> int:
+    """hipStream_t of torch's current stream on `device` as an integer (the private accessor that skips building a Stream object,
+    where this torch has it: the call sits on a per-mini-batch path)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+    except AttributeError:  # pragma: no cover
+        return torch.cuda.current_stream(device).cuda_stream
+
+
 # ---- the same in ONE launch for all factors, fused with what else has to precede the feature launch ------------------------------
 class HipSpeedBank:
     """The resamplers a mini-batch may refer to, resident on one device (``hipfeat_speed_bank``, include/hipfeat.h): mixed-factor speed
@@ -342,7 +351,7 @@ class HipSpeedBank:
             ticket, tmax, rows = int(info[0]), int(info[2]), int(info[3])
         F = plan.feature_dim
         if stream is None:
-            stream = torch.cuda.current_stream(arena.device).cuda_stream
+            stream = _raw_stream(arena.device)
         if K > 1:
             flat = torch.empty(rows * F, dtype=torch.float32, device=arena.device)
             st = self._run_fn(self.handle, ticket, arena.data_ptr(), arena.numel(), flat.data_ptr(), -1, float(pad_value), int(stream))

@@ -88,7 +88,14 @@ __device__ __forceinline__ float load_sample_center(const float* __restrict__ w,
   return (j >= 0 && j < S) ? w[j] : 0.0f;
 }
 
-// Locate the cut that owns workgroup `blk` (binary search over first_block).
+// Ragged batches: the host puts a workgroup -> cut map (int32 per workgroup) behind the descriptor table and says so with
+// uniform_bpc = -1: ONE dependent load instead of log2(cuts) of them in front of every workgroup (13 for a LibriSpeech-like batch of
+// 8000 cuts -- a few microseconds of a workgroup that lives for ~40).
+__device__ __forceinline__ const int32_t* block_cut_map(const CutDesc* __restrict__ cuts, int num_cuts) {
+  return reinterpret_cast<const int32_t*>(cuts + num_cuts);
+}
+
+// Locate the cut that owns workgroup `blk` (binary search over first_block): layouts without the map.
 __device__ __forceinline__ int find_cut(const CutDesc* __restrict__ cuts, int num_cuts, int blk) {
   int lo = 0, hi = num_cuts - 1;
   while (lo < hi) {

@@ -163,6 +163,7 @@ struct hipfeat_layout {
   CutDesc* d_cuts = nullptr;
   bool owns = true;
   std::vector<int64_t> num_frames;
+  std::vector<int32_t> block_cut;  // ragged batches: owner of every workgroup (uploaded behind the descriptors; uniform_bpc = -1)
   // Whisper (variant 9): per-cut normalisation scratch behind the descriptors, kNormSlots copies handed out round-robin so that
   // launches of one layout that overlap on different streams do not share one (each copy re-arms itself at the end of its launch)
   // copy k: [total_blocks][2] float workgroup statistics, then [batch] uint32 completion counters (armed = 0)
@@ -1415,32 +1416,38 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
     lay->num_frames[(size_t)b] = T;
   }
   // frames per workgroup: fixed by the plan, or (wave-autonomous kernels) rounds x fpb_unit.  A workgroup pays a fixed start-up (the
-  // constant image, its first, un-overlapped span: ~0.64 of a round, from the 8-vs-16-rounds A/B of round 3) and the launch runs in
-  // ceil(workgroups / resident slots) waves of workgroups: the rounds that minimise waves x (start-up + rounds).  Long launches end up
-  // at the maximum (many waves, start-up amortised); a 600 s mini-batch (60 000 frames) at 4 rounds in ONE wave of 469 workgroups instead
-  // of two waves of 2-round workgroups (round 3's rule: the largest power of two that still gave four waves, else 2).
+  // constant image, its first, un-overlapped span: ~0.64 of a round, from the 8-vs-16-rounds A/B of round 3), its last round-set is
+  // only partly filled (a cut's frames are not shared between workgroups), and the launch runs in ceil(workgroups / resident slots)
+  // waves of workgroups: the rounds that minimise  waves x (start-up + rounds).  10 000 x 1000 frames end up at the maximum (16: two
+  // workgroups per cut, start-up amortised); LibriSpeech-like lengths (mean 1230 frames) at 8 (16 would leave the third workgroup of a
+  // cut 60 % empty); a 600 s mini-batch (60 000 frames) at 4 rounds in ONE wave of ~470 workgroups instead of two waves of 2-round
+  // workgroups (round 3's rule: the largest power of two that still gave four waves, else 2).  Evaluated on at most 512 evenly spaced
+  // cuts of the batch (a transient layout is built per call).
   int fpb = plan->fpb;
   if (plan->fpb_unit > 0) {
     static const int forced = getenv("HIPFEAT_ROUNDS") ? atoi(getenv("HIPFEAT_ROUNDS")) : 0;
     static const bool old_rule = getenv("HIPFEAT_ROUNDS_R3") != nullptr;
     const int64_t slots = 256LL * std::max(plan->blocks_per_cu, 1);
-    auto workgroups = [&](int rounds) {
-      int64_t nb = 0;
-      for (int64_t b = 0; b < batch; ++b) nb += (lay->num_frames[(size_t)b] + (int64_t)plan->fpb_unit * rounds - 1) / ((int64_t)plan->fpb_unit * rounds);
-      return nb;
+    const int64_t stride = std::max<int64_t>(1, batch / 512);
+    auto workgroups = [&](int rounds, int64_t step) {  // (estimate for step > 1)
+      const int64_t per = (int64_t)plan->fpb_unit * rounds;
+      int64_t nb = 0, n = 0;
+      for (int64_t b = 0; b < batch; b += step, ++n) nb += (lay->num_frames[(size_t)b] + per - 1) / per;
+      return step == 1 ? nb : (nb * batch + n / 2) / std::max<int64_t>(n, 1);
     };
     int rounds = plan->c_rounds_max;
     if (forced >= 1 && forced <= plan->c_rounds_max) {
       rounds = forced;
     } else if (old_rule) {
       for (; rounds > 2; rounds >>= 1)
-        if (workgroups(rounds) >= 4 * slots) break;
-    } else if (workgroups(plan->c_rounds_max) < 4 * slots) {  // (otherwise: the maximum, without evaluating anything)
+        if (workgroups(rounds, 1) >= 4 * slots) break;
+    } else {
       double best = -1.0;
       for (int r = std::min(2, plan->c_rounds_max); r <= plan->c_rounds_max; ++r) {
-        const int64_t nb = workgroups(r);
-        const double cost = (double)((nb + slots - 1) / slots) * (0.64 + r);
-        if (best < 0.0 || cost <= best) {  // ties go to the larger workgroup
+        const int64_t nb = workgroups(r, stride);
+        const double waves = nb >= 8 * slots ? (double)nb / (double)slots : (double)((nb + slots - 1) / slots);  // (many waves: the last one hardly matters)
+        const double cost = waves * (0.64 + r);
+        if (best < 0.0 || cost <= best * (1.0 + 1e-9)) {  // ties go to the larger workgroup
           best = cost;
           rounds = r;
         }
@@ -1460,7 +1467,15 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
   lay->total_frames = row;
   lay->total_blocks = blocks;
   lay->out_row_stride = out_row_stride;
-  lay->uniform_bpc = uniform > 0 ? uniform : 0;
+  lay->uniform_bpc = uniform > 0 ? uniform : -1;  // -1: ragged, the workgroup -> cut map sits behind the descriptor table (common.hpp)
+  lay->block_cut.clear();
+  if (uniform <= 0) {
+    lay->block_cut.resize((size_t)blocks);
+    for (int64_t b = 0; b < batch; ++b) {
+      const int64_t b0 = descs[(size_t)b].first_block, b1 = b + 1 < batch ? descs[(size_t)b + 1].first_block : blocks;
+      std::fill(lay->block_cut.begin() + b0, lay->block_cut.begin() + b1, (int32_t)b);
+    }
+  }
   lay->fpb = fpb;
   lay->fpb_unit = plan->fpb_unit;
   lay->device = plan->device;
@@ -1483,10 +1498,13 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_layout_create(const hipfeat_plan* 
   }
   DeviceGuard g(plan->device);
   // one allocation: descriptors, then (Whisper with the fused normalisation) kNormSlots armed copies of the normalisation scratch
-  const size_t desc_bytes = std::max<size_t>(descs.size(), 1) * sizeof(CutDesc);
+  // (ragged batches: the workgroup -> cut map directly behind the descriptors, common.hpp::block_cut_map)
+  const size_t map_bytes = (lay->block_cut.size() * sizeof(int32_t) + 15) & ~(size_t)15;
+  const size_t desc_bytes = std::max<size_t>(descs.size(), 1) * sizeof(CutDesc) + map_bytes;
   const size_t norm_bytes = plan->variant == 9 ? (size_t)kNormSlots * norm_slot_bytes(lay) : 0;
   std::vector<unsigned char> blob(desc_bytes + norm_bytes, 0);  // zeros = armed counters
   if (!descs.empty()) std::memcpy(blob.data(), descs.data(), descs.size() * sizeof(CutDesc));
+  if (map_bytes) std::memcpy(blob.data() + descs.size() * sizeof(CutDesc), lay->block_cut.data(), lay->block_cut.size() * sizeof(int32_t));
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&lay->d_cuts), blob.size());
   if (e == hipSuccess && !descs.empty()) {
     // synchronous w.r.t. the host (pageable source), ordered on `stream`
@@ -1994,7 +2012,8 @@ static hipfeat_status extract_transient(const hipfeat_plan* plan, const float* d
   if (lay.total_blocks == 0 && max_pad == 0) return HIPFEAT_OK;
   DeviceGuard g(plan->device);
   // Whisper with the fused normalisation: one armed scratch entry per cut travels behind the descriptors (fresh for every call)
-  const size_t desc_bytes = descs.size() * sizeof(CutDesc);
+  const size_t map_bytes = (lay.block_cut.size() * sizeof(int32_t) + 15) & ~(size_t)15;  // ragged: workgroup -> cut map behind the descriptors
+  const size_t desc_bytes = descs.size() * sizeof(CutDesc) + map_bytes;
   const size_t bytes = desc_bytes + (plan->variant == 9 ? norm_slot_bytes(&lay) : 0);
   std::lock_guard<std::mutex> lk(plan->mu);
   StagingSlot& s = plan->slots[plan->next_slot];
@@ -2014,7 +2033,8 @@ static hipfeat_status extract_transient(const hipfeat_plan* plan, const float* d
     HIP_TRY(hipMalloc(&s.d, cap));
     s.cap = cap;
   }
-  std::memcpy(s.h, descs.data(), desc_bytes);
+  std::memcpy(s.h, descs.data(), descs.size() * sizeof(CutDesc));
+  if (map_bytes) std::memcpy(static_cast<unsigned char*>(s.h) + descs.size() * sizeof(CutDesc), lay.block_cut.data(), lay.block_cut.size() * sizeof(int32_t));
   if (bytes > desc_bytes) {
     std::memset(static_cast<unsigned char*>(s.h) + desc_bytes, 0, bytes - desc_bytes);
     lay.d_norm = static_cast<unsigned char*>(s.d) + desc_bytes;
@@ -2658,7 +2678,8 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* 
     s.busy = false;
   }
   if (!s.ev) HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
-  const size_t dev_bytes = cut_bytes + bytes;  // the feature launch's CutDesc table, then (staged path) the blob
+  const size_t map_bytes = ((size_t)s.lay.total_blocks * sizeof(int32_t) + 15) & ~(size_t)15;  // the feature launch's workgroup -> cut map
+  const size_t dev_bytes = cut_bytes + map_bytes + bytes;  // the feature launch's CutDesc table and map, then (staged path) the blob
   if (s.cap < dev_bytes) {
     if (s.h) (void)hipHostFree(s.h);
     if (s.d) (void)hipFree(s.d);
@@ -2689,6 +2710,9 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* 
   h.copy_descs = inl ? 1 : 0;
   h.feature_dim = F;
   h.pad_value = pad_value;
+  h.feature_blocks = (int32_t)s.lay.total_blocks;
+  h.pad_ = 0;
+  s.lay.uniform_bpc = -1;  // (the map is always there, uniform or not)
   auto fill_blob = [&](unsigned char* dst) {
     if (res_bytes) std::memcpy(dst, s.res.data(), res_bytes);
     std::memcpy(dst + res_bytes, s.descs.data(), cut_bytes);
@@ -2696,9 +2720,17 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* 
     std::memcpy(dst + res_bytes + cut_bytes + fill_bytes, s.rows.data(), row_bytes);
   };
   hipError_t e1 = hipSuccess;
+  auto fill_map = [&](unsigned char* dst) {
+    int32_t* m = reinterpret_cast<int32_t*>(dst);
+    for (int64_t b = 0; b < batch; ++b) {
+      const int64_t b0 = s.descs[(size_t)b].first_block, b1 = b + 1 < batch ? s.descs[(size_t)b + 1].first_block : s.lay.total_blocks;
+      std::fill(m + b0, m + b1, (int32_t)b);
+    }
+  };
   if (dbg_skip == 2) {  // (experiments: no prep launch; the descriptor table of the feature launch still has to get there)
     std::memcpy(s.h, s.descs.data(), cut_bytes);
-    HIP_TRY(hipMemcpyAsync(s.d, s.h, cut_bytes, hipMemcpyHostToDevice, st));
+    fill_map(static_cast<unsigned char*>(s.h) + cut_bytes);
+    HIP_TRY(hipMemcpyAsync(s.d, s.h, cut_bytes + map_bytes, hipMemcpyHostToDevice, st));
   } else if (inl) {
     fill_blob(args.blob);
     hipLaunchKernelGGL(minibatch_prep_inline_kernel, dim3(grid), dim3(256), 0, st, args);
@@ -2706,9 +2738,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* 
   } else {
     unsigned char* hb = static_cast<unsigned char*>(s.h);
     std::memcpy(hb, s.descs.data(), cut_bytes);
-    fill_blob(hb + cut_bytes);
+    fill_map(hb + cut_bytes);
+    fill_blob(hb + cut_bytes + map_bytes);
     HIP_TRY(hipMemcpyAsync(s.d, s.h, dev_bytes, hipMemcpyHostToDevice, st));
-    h.tables = static_cast<const unsigned char*>(s.d) + cut_bytes;
+    h.tables = static_cast<const unsigned char*>(s.d) + cut_bytes + map_bytes;
     hipLaunchKernelGGL(minibatch_prep_kernel, dim3(grid), dim3(256), bytes <= (size_t)kMbLdsTableBytes ? bytes : 0, st, h);
     e1 = hipGetLastError();
   }

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64 * kDWaves, 4) void fft256c_kernel(const Fft512cP
     cut = blk / p.uniform_bpc;
     fb = blk - cut * p.uniform_bpc;
   } else {
-    cut = find_cut(p.cuts, p.num_cuts, blk);
+    cut = p.uniform_bpc < 0 ? block_cut_map(p.cuts, p.num_cuts)[blk] : find_cut(p.cuts, p.num_cuts, blk);
     fb = blk - p.cuts[cut].first_block;
   }
   const CutDesc cd = p.cuts[cut];

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
     cut = blk / p.uniform_bpc;
     fb = blk - cut * p.uniform_bpc;
   } else {
-    cut = find_cut(p.cuts, p.num_cuts, blk);
+    cut = p.uniform_bpc < 0 ? block_cut_map(p.cuts, p.num_cuts)[blk] : find_cut(p.cuts, p.num_cuts, blk);
     fb = blk - p.cuts[cut].first_block;
   }
   const CutDesc cd = p.cuts[cut];
@@ -267,6 +267,10 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
       // "their" row (all n2) back
       float* exf = myreg + mul24(g, kCExFrameStride);
       v2 b[16];
+#ifdef HIPFEAT_ABL_NO_EXCHANGE  // experiment builds (tools/r4_lds_conflicts.sh): which phase owns the LDS bank conflicts?  (wrong results)
+#pragma unroll
+      for (int n2 = 0; n2 < 16; ++n2) b[n2] = a[n2];
+#else
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
+#endif
       HFC_T(3);  // exchange
       // the power-row offsets of this lane's filterbank slots are requested here, a phase early: the operand reads of the mel phase then
       // start without a dependent LDS look-up in front of them (+ 0.6 %)
@@ -337,8 +342,12 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
           asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(im2) : "v"(tt), "v"(HF_CJ), "v"(sp));
           pw = re2 * re2;
           pw = im2 * im2 + pw;
+#ifdef HIPFEAT_ABL_NO_POWER
+          asm volatile("" : : "v"(pw.x), "v"(pw.y));
+#else
           pown[16 * k2] = pw.x;
           ppar[16 * (15 - k2)] = pw.y;
+#endif
         }
       }
       if (q == 0) prow[128] = 4.f * (Z[8].x * Z[8].x + Z[8].y * Z[8].y);
@@ -375,8 +384,16 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
       const float* wb = wtab + s * (T * 64) + 4 * lane_o;
 #pragma unroll
       for (int c4 = 0; c4 < T / 4; ++c4) {
+#if defined(HIPFEAT_ABL_NO_MELOPS) || defined(HIPFEAT_ABL_NO_MEL_A)
+        av[s][c4] = f32x4{1.f, 2.f, 3.f, 4.f} * __builtin_bit_cast(float, lane_o);
+#else
         av[s][c4] = *reinterpret_cast<const f32x4*>(pa + 4 * c4);
+#endif
+#if defined(HIPFEAT_ABL_NO_MELOPS) || defined(HIPFEAT_ABL_NO_MEL_B)
+        bv[s][c4] = f32x4{1.f, 2.f, 3.f, 4.f} * __builtin_bit_cast(float, lane_o + c4);
+#else
         bv[s][c4] = *reinterpret_cast<const f32x4*>(wb + c4 * 256);
+#endif
       }
     }
     HFC_T(5);  // operand reads of the mel phase issued (not yet waited for)

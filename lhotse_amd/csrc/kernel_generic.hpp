@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void generic_kernel(const GenericParams p) {
     cut = blk / p.uniform_bpc;
     fb = blk - cut * p.uniform_bpc;
   } else {
-    cut = find_cut(p.cuts, p.num_cuts, blk);
+    cut = p.uniform_bpc < 0 ? block_cut_map(p.cuts, p.num_cuts)[blk] : find_cut(p.cuts, p.num_cuts, blk);
     fb = blk - p.cuts[cut].first_block;
   }
   const CutDesc cd = p.cuts[cut];

@@ -45,6 +45,7 @@ struct MbHeader {
   int32_t num_cuts, num_res, fill_items, res_items;
   int32_t table_bytes, copy_descs, feature_dim;
   float pad_value;
+  int32_t feature_blocks, pad_;  // workgroups of the feature launch (its workgroup -> cut map is written next to the descriptor table)
 };
 struct MbInlineArgs {
   MbHeader h;
@@ -87,6 +88,12 @@ __device__ __forceinline__ void minibatch_prep_body(const MbHeader& h, const uns
     const mb_i4* src = reinterpret_cast<const mb_i4*>(cds);
     mb_i4* dst = reinterpret_cast<mb_i4*>(h.cuts_dst);
     for (int k = threadIdx.x; k < n4; k += 256) dst[k] = src[k];
+    // ... and its workgroup -> cut map behind it (common.hpp::block_cut_map): one lane per cut writes the cut's run of workgroups
+    int32_t* map = reinterpret_cast<int32_t*>(h.cuts_dst + h.num_cuts);
+    for (int c = threadIdx.x; c < h.num_cuts; c += 256) {
+      const int b0 = cds[c].first_block, b1 = c + 1 < h.num_cuts ? cds[c + 1].first_block : h.feature_blocks;
+      for (int b = b0; b < b1; ++b) map[b] = c;
+    }
   }
   const int total = h.fill_items + h.res_items;
   for (int item = blockIdx.x; item < total; item += gridDim.x) {

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, (N1 == 16 ? 2 : HIPFEAT_WAVE_OCC)) void wave_k
     cut = blk / p.uniform_bpc;
     fb = blk - cut * p.uniform_bpc;
   } else {
-    cut = find_cut(p.cuts, p.num_cuts, blk);
+    cut = p.uniform_bpc < 0 ? block_cut_map(p.cuts, p.num_cuts)[blk] : find_cut(p.cuts, p.num_cuts, blk);
     fb = blk - p.cuts[cut].first_block;
   }
   const CutDesc cd = p.cuts[cut];
