@@ -146,6 +146,54 @@ def cpu_baseline(seconds: float = 12.0, procs: int = 0, mode: str = "", what: st
     return out
 
 
+class ClockSampler:
+    """Shader clock while the timed loop runs: a thread polling the driver's sysfs view (pp_dpm_sclk, the starred line) every 2 ms.
+    None where the box does not expose it.  (The VALU-issue share of `roofline.secondary` is stated at the NOMINAL 2.4 GHz and at this
+    clock: under the 1.4 kW cap the chip runs the kernel at ~1.8-2.0 GHz)"""
+
+    def __init__(self):
+        import glob
+        import threading
+
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.samples, self._stop, self._thread = [], threading.Event(), None
+        if self.paths:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        best = None
+        for p in self.paths:
+            try:
+                with open(p) as f:
+                    for line in f:
+                        if "*" in line:
+                            mhz = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
+                            best = mhz if best is None else max(best, mhz)  # (the busy card is the one at the higher clock)
+            except (OSError, ValueError, IndexError):
+                pass
+        return best
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            time.sleep(0.002)
+
+    def start(self):
+        if self._thread is not None:
+            self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=1.0)
+        if not self.samples:
+            return None
+        xs = sorted(self.samples)
+        return {"median_MHz": xs[len(xs) // 2], "min_MHz": xs[0], "max_MHz": xs[-1], "samples": len(xs)}
+
+
 def kernel_source_hash(files) -> str:
     h = hashlib.sha256()
     for rel in files:
@@ -699,8 +747,8 @@ class BulkSave:
         self.stats = {}
         self.variant = ("float32", "hip_archive")
         self.workload = (f"SURVEY 8d(iii) offline path: {NB} batches of 60 x 10 s (600 s) pageable float32 host waveforms per GPU per step -> chunked H2D / "
-                         f"fft512c / D2H pipeline -> background save thread: write_packed into a 'hip_archive' on {self.fs} + one template MonoCut manifest "
-                         "line per cut (gzip JSONL, flush per batch), back-pressure of 8 batches -- compute_and_store_features_batch's loop without lhotse's loader")
+                         f"fft512c / D2H pipeline -> background thread 1: write_packed into a 'hip_archive' on {self.fs} -> background thread 2: one template "
+                         "MonoCut manifest line per cut (gzip JSONL, flush per batch); back-pressure of 8 batches -- compute_and_store_features_batch's loop without lhotse's loader")
         self._run_id = 0
 
     def _one_pass(self, dtype: str, storage: str, stats: dict):
@@ -717,7 +765,7 @@ class BulkSave:
         os.makedirs(root)
         rec_cache = {}
         frame_shift = self.ex.frame_shift
-        save_busy = [0.0, 0, 0]  # seconds, archive bytes, manifest lines
+        save_busy = [0.0, 0, 0, 0.0]  # archive-thread seconds, archive bytes, manifest lines, manifest-thread seconds
 
         with wcls(os.path.join(root, "feats"), mode="w") as writer, gzip.open(os.path.join(root, "cuts.jsonl.gz"), "wt") as manifest:
             template = {"type": self.ex.name, "num_features": NUM_MELS, "frame_shift": frame_shift, "sampling_rate": SR,
@@ -728,22 +776,28 @@ class BulkSave:
                 host, frames = S._batch_features_on_host(self.ex, [pool[i] for i in idx], SR, None, half=half)
                 return cuts, host, frames
 
-            def save(cuts, host, frames):
+            def save(cuts, host, frames):  # background thread 1: the frame-count contract and the archive
                 t0 = time.perf_counter()
                 for c, t in zip(cuts, frames):  # the frame-count contract of validate_features (lhotse/qa.py:286-301)
                     if (int(round(c.duration * SR)) + 80) // 160 != t:
                         raise AssertionError(f"cut {c.id}: {t} frames")
                 keys = writer.write_packed(host, frames)
+                writer.flush()
+                save_busy[0] += time.perf_counter() - t0
+                save_busy[1] = os.path.getsize(writer.storage_path)  # (flushed above)
+                return cuts, frames, keys
+
+            def write_manifests(cuts, frames, keys):  # background thread 2: one template manifest line per cut
+                t0 = time.perf_counter()
                 for c, t, k in zip(cuts, frames, keys):
                     d = S._mono_cut_dict(c, S._features_dict(template, c, t, k), rec_cache)
                     manifest.write(json.dumps(d) + "\n")
-                writer.flush()
                 manifest.flush()
-                save_busy[0] += time.perf_counter() - t0
-                save_busy[1] = os.path.getsize(writer.storage_path)  # (flushed above)
+                save_busy[3] += time.perf_counter() - t0
                 save_busy[2] += len(cuts)
 
-            S.pump_batches(self.batches, extract, save, stats=stats)
+            S.pump_batches(self.batches, extract, save, stats=stats, finish=write_manifests)
+        stats["manifest_s"] = stats.get("manifest_s", 0.0) + save_busy[3]
         stats["save_s"] = stats.get("save_s", 0.0) + save_busy[0]
         stats["archive_bytes"] = stats.get("archive_bytes", 0) + save_busy[1]
         stats["manifest_lines"] = stats.get("manifest_lines", 0) + save_busy[2]
@@ -805,12 +859,13 @@ class BulkSave:
             out[f"{dtype}->{storage}"] = {
                 "cuts_per_s": round(cuts / dt, 1), "archive_MB_per_s": round(st["archive_bytes"] / dt / 1e6, 1),
                 "manifest_bytes_per_cut": round(st["manifest_bytes"] / cuts, 1),
-                "main_thread_extract_share": round(st["extract_s"] / dt, 3), "main_thread_blocked_on_save_share": round(st["wait_s"] / dt, 3),
-                "save_thread_busy_share": round(st["save_s"] / dt, 3),
-                "binds": "save thread (archive write + manifests)" if st["save_s"] > st["extract_s"] else "extraction (pack + PCIe pipeline)",
+                "main_thread_extract_share": round(st["extract_s"] / dt, 3), "main_thread_blocked_share": round(st["wait_s"] / dt, 3),
+                "archive_thread_busy_share": round(st["save_s"] / dt, 3), "manifest_thread_busy_share": round(st["manifest_s"] / dt, 3),
+                "binds": max((st["extract_s"], "extraction (pack to pinned + PCIe pipeline, calling thread)"), (st["save_s"], "archive thread (write_packed)"),
+                             (st["manifest_s"], "manifest thread (template dicts + json + gzip)"))[1],
             }
         out["what"] = ("3 passes per variant after one warm-up; shares are of wall time: the calling thread extracts (pack to pinned + H2D + kernel + D2H), "
-                       "ONE background thread writes the archive and the manifest lines; the larger share binds")
+                       "one background thread writes the archive, a second one the manifest lines (storage.pump_batches); the largest share binds")
         return {"bulk_save": out}
 
     def close(self):
@@ -1005,6 +1060,9 @@ def main():
     barrier()
     # per-step device time: HIP events on the launch stream (torch's current stream)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    clock = ClockSampler() if (rank == 0 and args.config == "fbank16k") else None  # (a polling thread: kept out of the host-bound configs)
+    if clock is not None:
+        clock.start()
     t0 = time.perf_counter()
     for a, b in evs:
         a.record()
@@ -1012,6 +1070,7 @@ def main():
         b.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    sclk = clock.stop() if clock is not None else None
     launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     if getattr(w, "host_bound", False):  # the step runs on side streams and host threads: the events on this stream see none of it
         launch_ms = elapsed / args.steps * 1e3
@@ -1130,13 +1189,17 @@ def main():
             # tools/ubench/valu_rate.hip); a wave instruction covers `frames_per_wave_instr` frames
             clk_per_instr = float(prof.get("valu_clk_per_instr", 2.0))
             frames_per_s = w.units * FRAMES_PER_CUT / (launch_ms * 1e-3)
+            mhz = (sclk or {}).get("median_MHz") or prof.get("sclk_MHz_under_load")
             res["roofline"]["secondary"] = {
                 "bound": "valu_f32",
                 "instr_per_frame": ipf,
                 "clk_per_instr": clk_per_instr,
                 "achieved_frac": round(frames_per_s * float(ipf) * clk_per_instr / (NUM_SIMDS * MAX_CLOCK), 4),
+                "achieved_frac_at_measured_clock": None if not mhz else round(frames_per_s * float(ipf) * clk_per_instr / (NUM_SIMDS * mhz * 1e6), 4),
+                "shader_clock": sclk if sclk else ({"median_MHz": mhz, "source": "profiles/traffic.json (power probe of the committed PMC run; sysfs not readable in this run)"} if mhz else None),
                 "what": "wave-level VALU instructions per frame (committed PMC run: SQ_INSTS_VALU / frames) x issue clocks per instruction "
-                        "/ (1024 SIMDs x 2.4 GHz): the share of the chip's VALU issue slots this launch rate needs",
+                        "/ (1024 SIMDs x clock): the share of the chip's VALU issue slots this launch rate needs -- at the nominal 2.4 GHz "
+                        "(achieved_frac) and at the shader clock the chip actually held under its power cap during the timed loop",
             }
         if world == 1:
             extra = {} if args.no_extra else w.extra(args)

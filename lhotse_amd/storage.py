@@ -321,20 +321,32 @@ def _batch_features_on_host(extractor, waves, sampling_rate: int, lengths, half:
     return (np.concatenate(mats, axis=0) if len(mats) != 1 else mats[0]), [int(m.shape[0]) for m in mats]
 
 
-def pump_batches(batches, extract, save, backlog: int = None, stats: Optional[Dict] = None) -> None:
+def pump_batches(batches, extract, save, backlog: int = None, stats: Optional[Dict] = None, finish=None) -> None:
     """The loop of the batch driver (lhotse/cut/set.py:2365-2404): the calling thread runs ``extract(batch)`` -> arguments of ``save`` (or
-    None to skip the batch), ONE background thread runs ``save(*args)`` behind it.  At most ``backlog`` (_SAVE_BACKLOG) finished batches
-    wait for the save thread: each holds its page-locked result, and a failed save (disk full) stops the run at the next batch instead
-    of after the whole corpus (the reference collects its futures at the very end, cut/set.py:2400-2404).  ``stats`` (optional) receives
-    the seconds the calling thread spent extracting (``extract_s``) and blocked on the save thread (``wait_s``) -- bench.py's
-    ``--config bulk_save`` reads them to say which stage binds."""
+    None to skip the batch), ONE background thread runs ``save(*args)`` behind it -- and, with ``finish``, a second one runs
+    ``finish(*save's result)`` behind that (the archive write and the manifest lines of a batch cost about the same, and neither needs
+    the other's thread: measured on the MI355X box, profiles/r04_bulk_save.json).  Both keep submission order.  At most ``backlog``
+    (_SAVE_BACKLOG) finished batches wait for the save thread: each holds its page-locked result, and a failed save (disk full) stops the
+    run at the next batch instead of after the whole corpus (the reference collects its futures at the very end, cut/set.py:2400-2404).
+    ``stats`` (optional) receives the seconds the calling thread spent extracting (``extract_s``) and blocked on the background threads
+    (``wait_s``) -- bench.py's ``--config bulk_save`` reads them to say which stage binds."""
     import time
     from collections import deque
 
     backlog = _SAVE_BACKLOG if backlog is None else backlog
     futures = deque()
     t_ext = t_wait = 0.0
-    with ThreadPoolExecutor(max_workers=1) as saver:
+    with ThreadPoolExecutor(max_workers=1) as saver, ThreadPoolExecutor(max_workers=1) as finisher:
+
+        def stage(*item):
+            res = save(*item)
+            return None if finish is None else finisher.submit(finish, *res)
+
+        def collect(fut):
+            inner = fut.result()
+            if inner is not None:
+                inner.result()
+
         for batch in batches:
             t0 = time.perf_counter()
             item = extract(batch)
@@ -342,13 +354,13 @@ def pump_batches(batches, extract, save, backlog: int = None, stats: Optional[Di
             t_ext += t1 - t0
             if item is None:
                 continue
-            futures.append(saver.submit(save, *item))
-            while len(futures) > backlog or (futures and futures[0].done()):
-                futures.popleft().result()
+            futures.append(saver.submit(stage, *item))
+            while len(futures) > backlog or (futures and futures[0].done() and (futures[0].exception() is not None or futures[0].result() is None or futures[0].result().done())):
+                collect(futures.popleft())
             t_wait += time.perf_counter() - t1
         t1 = time.perf_counter()
         while futures:
-            futures.popleft().result()
+            collect(futures.popleft())
         t_wait += time.perf_counter() - t1
     if stats is not None:
         stats["extract_s"] = stats.get("extract_s", 0.0) + t_ext
@@ -392,7 +404,7 @@ def compute_and_store_features_batch(
     loader = DataLoader(UnsupervisedWaveformDataset(collate=collate), batch_size=None, sampler=sampler, num_workers=num_workers)
     rec_cache: Dict[str, Tuple[object, Dict]] = {}
 
-    def save(writer, batch_cuts, host: np.ndarray, frames: List[int], template: Dict) -> None:
+    def save(writer, batch_cuts, host: np.ndarray, frames: List[int], template: Dict):
         # the frame-count contract of validate_features (qa.py:286-301), for the whole batch
         for c, t in zip(batch_cuts, frames):
             if isinstance(c, PaddingCut):
@@ -411,9 +423,14 @@ def compute_and_store_features_batch(
             keys = [None] * len(batch_cuts)
             for i in stored:
                 keys[i] = writer.write(batch_cuts[i].id, host[int(bounds[i]) : int(bounds[i + 1])])
+        if hasattr(writer, "flush"):
+            writer.flush()
+        return batch_cuts, frames, keys, int(host.shape[1]), template  # -> write_manifests, on the second background thread
+
+    def write_manifests(batch_cuts, frames: List[int], keys: List[str], num_features: int, template: Dict) -> None:
         for i, c in enumerate(batch_cuts):
             if isinstance(c, PaddingCut):
-                manifest.write(fastcopy(c, num_frames=frames[i], num_features=host.shape[1], frame_shift=frame_shift))
+                manifest.write(fastcopy(c, num_frames=frames[i], num_features=num_features, frame_shift=frame_shift))
                 continue
             fd = _features_dict(template, c, frames[i], keys[i])
             # (an in-memory manifest -- no manifest_path -- keeps the objects it is given: no templates there)
@@ -429,8 +446,6 @@ def compute_and_store_features_batch(
                 else:
                     out = fastcopy(c, features=fm)
             manifest.write(out)
-        if hasattr(writer, "flush"):
-            writer.flush()
         if getattr(manifest, "file", None) is not None:
             manifest.file.flush()  # one flush per batch
 
@@ -455,5 +470,5 @@ def compute_and_store_features_batch(
                                      "storage_type": writer.name, "storage_path": str(writer.storage_path)}
             return writer, list(batch_cuts), host, frames, state["template"]
 
-        pump_batches(loader, extract, save)
+        pump_batches(loader, extract, save, finish=write_manifests)
     return manifest.open_manifest()

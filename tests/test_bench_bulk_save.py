@@ -32,7 +32,7 @@ def test_bulk_save_workload_writes_what_the_extractor_computes(monkeypatch):
     w.step()
     assert not os.path.exists(first) and os.path.isdir(w.last_root)  # one run on disk at a time
     st = w.stats
-    assert st["manifest_lines"] == 120 and st["archive_bytes"] == 120 * 100 * 80 * 4 and st["extract_s"] > 0 and st["save_s"] > 0
+    assert st["manifest_lines"] == 120 and st["archive_bytes"] == 120 * 100 * 80 * 4 and st["extract_s"] > 0 and st["save_s"] > 0 and st["manifest_s"] > 0
     with gzip.open(os.path.join(w.last_root, "cuts.jsonl.gz"), "rt") as f:
         lines = [json.loads(ln) for ln in f]
     d = lines[61]
