@@ -2,7 +2,7 @@
 """profiles/traffic.json from a PMC summary (tools/pmc_profile.sh -> summary.txt): HBM bytes per cut and VALU instructions per frame of the
 bench kernel, stamped with the sha256 of the kernel sources they were measured on (bench.py refuses the numbers once those files change).
 
-    python tools/make_traffic_json.py <summary.txt> <cuts per dispatch> [label of the summary file in profiles/]"""
+    python tools/make_traffic_json.py <summary.txt> <cuts per dispatch> [label of the summary file in profiles/] [power probe json line file]"""
 import json
 import os
 import re
@@ -50,6 +50,11 @@ def main():
         "source_files": SOURCES,
         "source_sha256_16": bench.kernel_source_hash(SOURCES),
     }
+    if len(sys.argv) > 4:  # shader clock the chip held while the bench kernel ran for seconds (rocm-smi samples, tools/r4_collect.sh)
+        probe = json.loads(open(sys.argv[4]).readline())
+        out["sclk_MHz_under_load"] = probe["sclk_MHz_median"]
+        out["package_power_W_under_load"] = probe["package_power_W_median"]
+        out["power_probe"] = sys.argv[4]
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
