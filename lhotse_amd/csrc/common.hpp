@@ -95,6 +95,20 @@ __device__ __forceinline__ const int32_t* block_cut_map(const CutDesc* __restric
   return reinterpret_cast<const int32_t*>(cuts + num_cuts);
 }
 
+// A descriptor whose index is wave-uniform, every dword through v_readfirstlane: the fields then live in SGPRs (addresses, loop bounds and
+// the "interior span" test of the kernels stay scalar) even where the compiler cannot prove the index uniform.
+__device__ __forceinline__ CutDesc load_cut_uniform(const CutDesc* __restrict__ p) {
+  static_assert(sizeof(CutDesc) == 32, "descriptor size");
+  const int* w = reinterpret_cast<const int*>(p);
+  union {
+    int w[8];
+    CutDesc d;
+  } u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) u.w[i] = __builtin_amdgcn_readfirstlane(w[i]);
+  return u.d;
+}
+
 // Locate the cut that owns workgroup `blk` (binary search over first_block): layouts without the map.
 __device__ __forceinline__ int find_cut(const CutDesc* __restrict__ cuts, int num_cuts, int blk) {
   int lo = 0, hi = num_cuts - 1;

@@ -164,6 +164,8 @@ struct hipfeat_layout {
   bool owns = true;
   std::vector<int64_t> num_frames;
   std::vector<int32_t> block_cut;  // ragged batches: owner of every workgroup (uploaded behind the descriptors; uniform_bpc = -1)
+  bool flat = false;               // ragged batch laid out by frame quads (fft512c FLAT instances): first_block = a cut's first quad
+  int64_t total_quads = 0;
   // Whisper (variant 9): per-cut normalisation scratch behind the descriptors, kNormSlots copies handed out round-robin so that
   // launches of one layout that overlap on different streams do not share one (each copy re-arms itself at the end of its launch)
   // copy k: [total_blocks][2] float workgroup statistics, then [batch] uint32 completion counters (armed = 0)
@@ -367,19 +369,26 @@ static std::vector<float> build_dct_operands(const hipfeat_config& c, const floa
 // --------------------------------------------------------------------------------------
 // fft512 wave-autonomous fbank kernel (kernel_fft512c.hpp); its filterbank schedule is built in mel4_schedule.hpp
 // --------------------------------------------------------------------------------------
-template <int NROWS, int NFULL, int MODE>
+template <int NROWS, int NFULL, int MODE, bool FLAT = false>
 static const void* fft512c_entry() {
-  return reinterpret_cast<const void*>(&fft512c_kernel<NROWS, NFULL, MODE>);
+  return reinterpret_cast<const void*>(&fft512c_kernel<NROWS, NFULL, MODE, FLAT>);
 }
 
 // (rows, frame length, mode) -> kernel instance; `launch` == false only returns the entry point
+// the (rows, frame length) that have a FLAT instance (ragged batches by frame quads, kernel_fft512c.hpp): the 25 ms @ 16 kHz default
+static bool fft512c_has_flat(int nrows, int N) { return nrows == 13 && N >= 384; }
+
 template <int MODE>
-static const void* fft512c_pick(int nrows, int N, bool launch, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const Fft512cParams* fp) {
+static const void* fft512c_pick(int nrows, int N, bool launch, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const Fft512cParams* fp, bool flat = false) {
   // 25 ms at 16 kHz (N = 400: 12 full rows of 32 samples + a partial one) gets the instance without length masks on the full rows
 #define HF_C_CASE(R, F)                                                                                   \
   {                                                                                                       \
     if (launch) hipLaunchKernelGGL((fft512c_kernel<R, F, MODE>), grid, block, lds, stream, *fp);          \
     return fft512c_entry<R, F, MODE>();                                                                   \
+  }
+  if (flat && fft512c_has_flat(nrows, N)) {
+    if (launch) hipLaunchKernelGGL((fft512c_kernel<13, 12, MODE, true>), grid, block, lds, stream, *fp);
+    return fft512c_entry<13, 12, MODE, true>();
   }
   if (nrows == 10) HF_C_CASE(10, 0)
   if (nrows == 13 && N >= 384) HF_C_CASE(13, 12)
@@ -387,10 +396,12 @@ static const void* fft512c_pick(int nrows, int N, bool launch, dim3 grid, dim3 b
   HF_C_CASE(16, 0)
 #undef HF_C_CASE
 }
-static const void* fft512c_dispatch(int mode, int nrows, int N, bool launch, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const Fft512cParams* fp) {
-  return mode == 0 ? fft512c_pick<0>(nrows, N, launch, grid, block, lds, stream, fp)
-                   : (mode == 1 ? fft512c_pick<1>(nrows, N, launch, grid, block, lds, stream, fp)
-                                : (mode == 2 ? fft512c_pick<2>(nrows, N, launch, grid, block, lds, stream, fp) : fft512c_pick<3>(nrows, N, launch, grid, block, lds, stream, fp)));
+static const void* fft512c_dispatch(int mode, int nrows, int N, bool launch, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const Fft512cParams* fp,
+                                    bool flat = false) {
+  return mode == 0 ? fft512c_pick<0>(nrows, N, launch, grid, block, lds, stream, fp, flat)
+                   : (mode == 1 ? fft512c_pick<1>(nrows, N, launch, grid, block, lds, stream, fp, flat)
+                                : (mode == 2 ? fft512c_pick<2>(nrows, N, launch, grid, block, lds, stream, fp, flat)
+                                             : fft512c_pick<3>(nrows, N, launch, grid, block, lds, stream, fp, flat)));
 }
 
 // Returns HIPFEAT_OK with p->variant == 7 when the configuration takes the wave-autonomous kernel, HIPFEAT_OK with the
@@ -1455,21 +1466,67 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
     }
     fpb = plan->fpb_unit * rounds;
   }
-  for (int64_t b = 0; b < batch; ++b) {
-    if (blocks > INT32_MAX - (1 << 24)) return fail(HIPFEAT_ERR_INVALID, "batch too large for one launch");
-    descs[(size_t)b].first_block = (int32_t)blocks;
-    const int64_t nb = (lay->num_frames[(size_t)b] + fpb - 1) / fpb;
-    blocks += nb;
-    if (uniform == -1) uniform = (int)nb;
-    else if (uniform != (int)nb) uniform = 0;
+  // Ragged batch on the 16 kHz default kernel: laid out by frame quads instead of by cuts (kernel_fft512c.hpp, FLAT) -- no half-empty last
+  // workgroup per cut, long workgroups whatever the cuts' lengths
+  bool ragged = false;
+  for (int64_t b = 1; b < batch && !ragged; ++b) ragged = lay->num_frames[(size_t)b] != lay->num_frames[0];
+  static const bool no_flat = getenv("HIPFEAT_NO_FLAT") != nullptr;
+  lay->flat = ragged && !no_flat && plan->variant == 7 && fft512c_has_flat(plan->nrows, c.frame_length);
+  lay->total_quads = 0;
+  lay->block_cut.clear();
+  if (lay->flat) {
+    int64_t quads = 0;
+    for (int64_t b = 0; b < batch; ++b) {
+      if (quads > INT32_MAX - (1 << 24)) return fail(HIPFEAT_ERR_INVALID, "batch too large for one launch");
+      descs[(size_t)b].first_block = (int32_t)quads;
+      quads += (lay->num_frames[(size_t)b] + 3) / 4;
+    }
+    static const int forced = getenv("HIPFEAT_ROUNDS") ? atoi(getenv("HIPFEAT_ROUNDS")) : 0;
+    const int64_t slots = 256LL * std::max(plan->blocks_per_cu, 1);
+    const int waves_per_wg = plan->fpb_unit / 4;  // a wave takes one quad per round
+    int rounds = plan->c_rounds_max;
+    if (forced >= 1 && forced <= plan->c_rounds_max) {
+      rounds = forced;
+    } else {
+      double best = -1.0;
+      for (int r = std::min(2, plan->c_rounds_max); r <= plan->c_rounds_max; ++r) {
+        const int64_t nb = (quads + (int64_t)waves_per_wg * r - 1) / ((int64_t)waves_per_wg * r);
+        const double waves = nb >= 8 * slots ? (double)nb / (double)slots : (double)((nb + slots - 1) / slots);
+        const double cost = waves * (0.64 + r);
+        if (best < 0.0 || cost <= best * (1.0 + 1e-9)) {
+          best = cost;
+          rounds = r;
+        }
+      }
+    }
+    fpb = plan->fpb_unit * rounds;
+    const int64_t qpw = (int64_t)waves_per_wg * rounds;
+    blocks = (quads + qpw - 1) / qpw;
+    lay->total_quads = quads;
+    lay->block_cut.resize((size_t)blocks);
+    int64_t cutp = 0;
+    for (int64_t g = 0; g < blocks; ++g) {  // the cut that holds a workgroup's first quad
+      const int64_t q = g * qpw;
+      while (cutp + 1 < batch && descs[(size_t)cutp + 1].first_block <= q) ++cutp;
+      lay->block_cut[(size_t)g] = (int32_t)cutp;
+    }
+    uniform = 0;
+  } else {
+    for (int64_t b = 0; b < batch; ++b) {
+      if (blocks > INT32_MAX - (1 << 24)) return fail(HIPFEAT_ERR_INVALID, "batch too large for one launch");
+      descs[(size_t)b].first_block = (int32_t)blocks;
+      const int64_t nb = (lay->num_frames[(size_t)b] + fpb - 1) / fpb;
+      blocks += nb;
+      if (uniform == -1) uniform = (int)nb;
+      else if (uniform != (int)nb) uniform = 0;
+    }
   }
   lay->batch = batch;
   lay->total_frames = row;
   lay->total_blocks = blocks;
   lay->out_row_stride = out_row_stride;
   lay->uniform_bpc = uniform > 0 ? uniform : -1;  // -1: ragged, the workgroup -> cut map sits behind the descriptor table (common.hpp)
-  lay->block_cut.clear();
-  if (uniform <= 0) {
+  if (uniform <= 0 && !lay->flat) {
     lay->block_cut.resize((size_t)blocks);
     for (int64_t b = 0; b < batch; ++b) {
       const int64_t b0 = descs[(size_t)b].first_block, b1 = b + 1 < batch ? descs[(size_t)b + 1].first_block : blocks;
@@ -1789,10 +1846,11 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
     fp.xs_floats = plan->c_xs_floats;
     fp.dct_tab = plan->d_dct_consts;
     fp.C = c.num_ceps;
+    fp.total_quads = (int32_t)lay->total_quads;
     DeviceGuard g(plan->device);
     const dim3 grid((unsigned)lay->total_blocks), block(64 * kCWaves);
     set_lds_poison(plan->fast_lds_bytes);
-    fft512c_dispatch(plan->c_mode, plan->nrows, c.frame_length, true, grid, block, plan->fast_lds_bytes, stream, &fp);
+    fft512c_dispatch(plan->c_mode, plan->nrows, c.frame_length, true, grid, block, plan->fast_lds_bytes, stream, &fp, lay->flat);
     HIP_TRY(hipGetLastError());
     return HIPFEAT_OK;
   }
@@ -2711,7 +2769,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* 
   h.feature_dim = F;
   h.pad_value = pad_value;
   h.feature_blocks = (int32_t)s.lay.total_blocks;
-  h.pad_ = 0;
+  h.quads_per_wg = s.lay.flat ? (int32_t)(s.lay.fpb / 4) : 0;
   s.lay.uniform_bpc = -1;  // (the map is always there, uniform or not)
   auto fill_blob = [&](unsigned char* dst) {
     if (res_bytes) std::memcpy(dst, s.res.data(), res_bytes);
@@ -2722,6 +2780,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* 
   hipError_t e1 = hipSuccess;
   auto fill_map = [&](unsigned char* dst) {
     int32_t* m = reinterpret_cast<int32_t*>(dst);
+    if (s.lay.flat) {  // (laid out by frame quads: the map build_descs computed)
+      std::memcpy(m, s.lay.block_cut.data(), s.lay.block_cut.size() * sizeof(int32_t));
+      return;
+    }
     for (int64_t b = 0; b < batch; ++b) {
       const int64_t b0 = s.descs[(size_t)b].first_block, b1 = b + 1 < batch ? s.descs[(size_t)b + 1].first_block : s.lay.total_blocks;
       std::fill(m + b0, m + b1, (int32_t)b);

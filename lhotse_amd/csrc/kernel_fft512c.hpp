@@ -57,6 +57,7 @@ struct Fft512cParams {
   // MFCC (MODE 2): [kCDctChunks][64 lanes][4] DCT operands (lane = cepstral coefficient, step = filter; layers.py:697-706), then [64] lifter
   const float* dct_tab;
   int32_t C;
+  int32_t total_quads;  // FLAT instances: frame quads (4 frames of one cut) of the whole batch; CutDesc::first_block then is a cut's first quad
 };
 
 #ifdef HIPFEAT_PHASE_TIMERS
@@ -72,7 +73,14 @@ __device__ __forceinline__ int mul24(int a, int b) { return (int)__umul24((unsig
 // MODE 0: log-mel filterbank on 2 accumulator sets x 16 steps (many narrow filters: the 80-filter default); 1: log-mel on 1 set x 32
 // steps (few, wide filters: 23 / 40); 2: MFCC = mode 1 + the DCT as a second run of 4 x 4 x 1 blocks (Wav2MFCC, layers.py:708-724);
 // 3: MFCC with <= 24 filters (the 23-filter default): 6 instead of 10 chunks of DCT operands, and the split-step twiddles in registers
-template <int NROWS, int NFULL, int MODE>
+//
+// FLAT (round 4; ragged batches): the waves of the launch take the frame QUADS of the whole batch round-robin -- workgroup g owns quads
+// [g, g + 1) x 8 rounds, wave wv of it quad 8 r + wv in round r -- instead of every cut having workgroups of its own.  A cut's last
+// workgroup used to be half empty on average and short workgroups paid the start-up (constant image, first span) for a few rounds of
+// work: 17 % of a LibriSpeech-like batch.  A wave keeps the descriptor of the cut it is in and steps to the next one when its quad index
+// passes the cut's last quad (CutDesc::first_block = first quad of the cut; one wave-uniform compare per round, a descriptor load per
+// crossing); the workgroup's first cut comes from the workgroup -> cut map (common.hpp).  The four frames of a quad always belong to ONE cut.
+template <int NROWS, int NFULL, int MODE, bool FLAT = false>
 __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   HF_POISON_LDS(smem);
@@ -88,15 +96,17 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
 
   const int blk = blockIdx.x;
   int cut, fb;
-  if (p.uniform_bpc > 0) {
+  if (FLAT) {
+    cut = __builtin_amdgcn_readfirstlane(block_cut_map(p.cuts, p.num_cuts)[blk]);
+    fb = 0;
+  } else if (p.uniform_bpc > 0) {
     cut = blk / p.uniform_bpc;
     fb = blk - cut * p.uniform_bpc;
   } else {
     cut = p.uniform_bpc < 0 ? block_cut_map(p.cuts, p.num_cuts)[blk] : find_cut(p.cuts, p.num_cuts, blk);
     fb = blk - p.cuts[cut].first_block;
   }
-  const CutDesc cd = p.cuts[cut];
-  const float* __restrict__ w = p.wave + cd.wave_off;
+  CutDesc cd = FLAT ? load_cut_uniform(p.cuts + cut) : p.cuts[cut];  // (FLAT: the cut of the CURRENT round; it changes as the wave walks through the batch)
   const int N = p.N, shift = p.shift;
 
   for (int i = tid; i < p.shared_floats; i += 64 * kCWaves) smem[i] = p.shared_consts[i];
@@ -109,7 +119,8 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
   // Stage the span of the four frames starting at f0 into this wave's buffer.  Interior rounds: LDS-DMA (lane i supplies
   // the global address of its 16 bytes, the hardware writes piece base + 16 i).  Rounds touching a cut edge (reflection,
   // zero padding of a batch row): per-lane loads through the edge rule.
-  auto stage_span = [&](int f0, unsigned lane4) {
+  auto stage_span = [&](const CutDesc& cd, int f0, unsigned lane4) {  // (the descriptor of the round that is being staged)
+    const float* __restrict__ w = p.wave + cd.wave_off;
     const int64_t j0 = (int64_t)f0 * shift - p.npad_left;
     if (j0 >= 0 && j0 + p.xs_floats <= cd.num_samples) {
       const char* src = reinterpret_cast<const char*>(w + j0);  // uniform
@@ -131,8 +142,29 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
 
   // the waves of a workgroup take the frame quads round-robin, so that a short cut still spreads over all of them
   const int first_frame = fb * p.frames_per_block + 4 * wv;
+  // FLAT: this wave's quad of round 0, the cut it lies in (a workgroup may span several short cuts), and the same for the round after
+  // the current one (its span is requested a round ahead)
+  int quad = 0, next_first = 0, f0_flat = 0;
+  int cut_n = 0, quad_n = 0, next_first_n = 0, f0_n = 0;
+  CutDesc cd_n = cd;
+  auto advance = [&](int q, int& c, CutDesc& d, int& nfirst) {  // the cut of quad q >= the current one (wave-uniform)
+    while (c + 1 < p.num_cuts && q >= nfirst) {
+      ++c;
+      d = load_cut_uniform(p.cuts + c);
+      nfirst = c + 1 < p.num_cuts ? __builtin_amdgcn_readfirstlane(p.cuts[c + 1].first_block) : p.total_quads;
+    }
+  };
+  if (FLAT) {
+    quad = blk * (p.frames_per_block >> 2) + wv;
+    next_first = cut + 1 < p.num_cuts ? __builtin_amdgcn_readfirstlane(p.cuts[cut + 1].first_block) : p.total_quads;
+    advance(quad, cut, cd, next_first);
+    f0_flat = 4 * (quad - cd.first_block);
+    cut_n = cut, cd_n = cd, next_first_n = next_first, quad_n = quad + kCWaves;
+    advance(quad_n, cut_n, cd_n, next_first_n);
+    f0_n = 4 * (quad_n - cd_n.first_block);
+  }
   __syncthreads();  // the constant tables are in place (the only workgroup barrier of the kernel)
-  if (first_frame < cd.num_frames) stage_span(first_frame, (unsigned)lane * 4u);
+  if (FLAT ? quad < p.total_quads : first_frame < cd.num_frames) stage_span(cd, FLAT ? f0_flat : first_frame, (unsigned)lane * 4u);
 
   // Both twiddle tables of this lane (15 + 8 complex values) live in registers for the whole kernel where the register budget of 4 waves
   // per SIMD allows it (not in MFCC mode, whose DCT operands take that room): 24 LDS reads less per round, + 4.9 % (same-call A/B).  The
@@ -162,8 +194,8 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
   unsigned long long hfc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hfc_last = __builtin_readcyclecounter();
 #endif
   for (int r = 0; r < p.rounds; ++r) {
-    const int f0 = first_frame + 4 * kCWaves * r;
-    if (f0 >= cd.num_frames) break;
+    const int f0 = FLAT ? f0_flat : first_frame + 4 * kCWaves * r;
+    if (FLAT ? quad >= p.total_quads : f0 >= cd.num_frames) break;
     const int nf = min(4, cd.num_frames - f0);
 
     // this round's span was requested a round ago by this very wave: its own vmcnt covers the LDS-DMA, the in-order LDS
@@ -200,7 +232,11 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
       // the samples are in flight to registers; once they have arrived the buffer is free for the next round's span
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       HFC_T(1);  // sample + window reads
-      if (r + 1 < p.rounds && f0 + 4 * kCWaves < cd.num_frames) stage_span(f0 + 4 * kCWaves, (unsigned)lane_o * 4u);
+      if (FLAT) {
+        if (r + 1 < p.rounds && quad_n < p.total_quads) stage_span(cd_n, f0_n, (unsigned)lane_o * 4u);
+      } else if (r + 1 < p.rounds && f0 + 4 * kCWaves < cd.num_frames) {
+        stage_span(cd, f0 + 4 * kCWaves, (unsigned)lane_o * 4u);
+      }
 
       // samples at or beyond N (the frame length) are not part of the frame (uniform test per row, lane mask only in
       // the boundary rows)
@@ -473,6 +509,12 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
     hfc_acc[7] += 1;
 #endif
     // the next round's exchange writes follow this round's power-row reads in the wave's own LDS queue (in order)
+    if (FLAT) {  // the staged round becomes the current one; locate the one after it
+      quad = quad_n, cut = cut_n, cd = cd_n, next_first = next_first_n, f0_flat = f0_n;
+      quad_n += kCWaves;
+      advance(quad_n, cut_n, cd_n, next_first_n);
+      f0_n = 4 * (quad_n - cd_n.first_block);
+    }
   }
 #ifdef HIPFEAT_PHASE_TIMERS
   if (lane == 0 && g_phase_buf) {

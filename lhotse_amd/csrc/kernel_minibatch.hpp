@@ -45,7 +45,8 @@ struct MbHeader {
   int32_t num_cuts, num_res, fill_items, res_items;
   int32_t table_bytes, copy_descs, feature_dim;
   float pad_value;
-  int32_t feature_blocks, pad_;  // workgroups of the feature launch (its workgroup -> cut map is written next to the descriptor table)
+  int32_t feature_blocks, quads_per_wg;  // workgroups of the feature launch (its workgroup -> cut map is written next to the descriptor table);
+                                         // > 0: the launch is laid out by frame quads (fft512c FLAT), CutDesc::first_block = a cut's first quad
 };
 struct MbInlineArgs {
   MbHeader h;
@@ -90,9 +91,21 @@ __device__ __forceinline__ void minibatch_prep_body(const MbHeader& h, const uns
     for (int k = threadIdx.x; k < n4; k += 256) dst[k] = src[k];
     // ... and its workgroup -> cut map behind it (common.hpp::block_cut_map): one lane per cut writes the cut's run of workgroups
     int32_t* map = reinterpret_cast<int32_t*>(h.cuts_dst + h.num_cuts);
-    for (int c = threadIdx.x; c < h.num_cuts; c += 256) {
-      const int b0 = cds[c].first_block, b1 = c + 1 < h.num_cuts ? cds[c + 1].first_block : h.feature_blocks;
-      for (int b = b0; b < b1; ++b) map[b] = c;
+    if (h.quads_per_wg > 0) {  // one lane per workgroup: the cut that holds its first quad (bisection over the cuts' first quads)
+      for (int g = threadIdx.x; g < h.feature_blocks; g += 256) {
+        const int q = g * h.quads_per_wg;
+        int lo = 0, hi = h.num_cuts - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (cds[mid].first_block <= q) lo = mid; else hi = mid - 1;
+        }
+        map[g] = lo;
+      }
+    } else {
+      for (int c = threadIdx.x; c < h.num_cuts; c += 256) {
+        const int b0 = cds[c].first_block, b1 = c + 1 < h.num_cuts ? cds[c + 1].first_block : h.feature_blocks;
+        for (int b = b0; b < b1; ++b) map[b] = c;
+      }
     }
   }
   const int total = h.fill_items + h.res_items;
