@@ -349,9 +349,8 @@ class Fbank16k:
         # only the rows the parity leg reads: zeroing the whole 3.2 GB output between the warm-up and the timed steps is a millisecond of
         # low-power work after which the package ramps up again -- the first ~5 timed launches then run ~20 % slower, a quarter of the driver's
         # 20 steps (tools/launch_ramp2.py: bare synchronize no ramp, whole-buffer zero_() ramp, 64 cuts' rows no ramp)
-        for i in fbank16k_parity_indices(self.C, self.rank):
-            self.out[int(i) * FRAMES_PER_CUT : (int(i) + 1) * FRAMES_PER_CUT].zero_()
-        self.out[:FRAMES_PER_CUT].zero_()
+        idx = self.torch.from_numpy(self.np.union1d(fbank16k_parity_indices(self.C, self.rank), [0])).to(self.out.device)
+        self.out.view(self.C, FRAMES_PER_CUT * NUM_MELS).index_fill_(0, idx, 0.0)  # (one small launch)
 
     def parity(self, rank):
         from oracle.kaldi_ref import RefConfig, RefExtractor

@@ -280,6 +280,20 @@ class _Rendezvous:
                 pass
 
 
+class _OwnedCuts:
+    """The cuts of `cuts` whose input index `owner_of` assigns to `rank`, lazily (one pass over the source per iteration)."""
+
+    def __init__(self, cuts, owner_of, rank: int):
+        self.cuts, self.owner_of, self.rank = cuts, owner_of, rank
+
+    def __iter__(self):
+        owner_of, rank = self.owner_of, self.rank
+        return (c for i, c in enumerate(self.cuts) if owner_of[i] == rank)
+
+    def __len__(self) -> int:
+        return int((self.owner_of == self.rank).sum())
+
+
 def shard_paths(storage_path, manifest_path, rank: int):
     """(storage, manifest) of one rank: `<storage_path>/feats-<rank>` as the reference names its per-job storages
     (lhotse/cut/set.py:2141-2153) and `cuts-<rank>.jsonl.gz` next to the combined manifest."""
@@ -385,16 +399,18 @@ def compute_and_store_features_sharded(
             return i % world
 
     else:
+        # one pass over the durations (nothing else of a cut is kept), then the rank's cuts are yielded lazily by a second pass when the
+        # batch driver iterates -- the corpus is never materialised (it used to be, twice per rank)
+        import numpy as np
+
         parts = shard_by_duration([c.duration for c in cuts], world)
-        owner_of = {}
+        owner_of = np.zeros(sum(len(ix) for ix in parts), dtype=np.int32)
         for r, idx in enumerate(parts):
-            for i in idx:
-                owner_of[i] = r
-        keep = set(parts[rank])
-        mine = CutSet.from_cuts(c for i, c in enumerate(cuts) if i in keep) if world > 1 else cuts
+            owner_of[idx] = r
+        mine = CutSet(_OwnedCuts(cuts, owner_of, rank)) if world > 1 else cuts
 
         def owner(i, cut):
-            return owner_of[i]
+            return int(owner_of[i])
 
     sub_storage, sub_manifest = shard_paths(storage_path, manifest_path, rank)
     meet = _Rendezvous(manifest_path.parent, rank, world, barrier_timeout, device_index)
