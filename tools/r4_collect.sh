@@ -8,6 +8,7 @@ mkdir -p "$OUT"
 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 python bench.py > "$OUT/bench_default_steps.json" 2> /dev/null
 python bench.py --config mfcc40_libri > "$OUT/bench_mfcc40_libri.json" 2> "$OUT/bench_mfcc40_libri.err"
+HIPFEAT_NO_FLAT=1 python bench.py --config mfcc40_libri --no-cpu-baseline --no-extra > "$OUT/bench_mfcc40_libri_noflat.json" 2> /dev/null
 python bench.py --config onthefly > "$OUT/bench_onthefly.json" 2> "$OUT/bench_onthefly.err"
 python bench.py --config onthefly --prefetch 4 --streams 2 --no-cpu-baseline --no-extra > "$OUT/bench_onthefly_prefetch4.json" 2> /dev/null
 python bench.py --config bulk_save --no-cpu-baseline > "$OUT/bench_bulk_save.json" 2> "$OUT/bench_bulk_save.err"
@@ -36,6 +37,8 @@ HIPFEAT_NO_FIXED_SCHEDULE=1 python tools/bench_librosa.py --cuts 4000 --steps 20
 { python tools/bench_whisper.py --cuts 4000 --steps 20; python tools/bench_whisper.py --cuts 60 --steps 50; } > "$OUT/whisper.txt" 2>&1
 python tools/bench_speed_fbank.py > "$OUT/speed_fbank.txt" 2>&1
 python tools/parity_probe.py 64 > "$OUT/parity_probe.txt" 2>&1
+python tools/launch_ramp2.py > "$OUT/launch_ramp.txt" 2>&1
+python __graft_entry__.py --smoke > "$OUT/smoke.txt" 2>&1
 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.txt" 2>&1
 cp gpurun_out/parity_report.json "$OUT/parity_report.json" 2>/dev/null
 tail -2 "$OUT/pytest_gpu.txt"; tail -c 400 "$OUT/bench.json"; head -5 "$OUT/host_profile_minibatch.txt"
