@@ -429,6 +429,7 @@ class Mfcc40Libri:
         self.units = C
         self.audio_seconds = float(self.lens.sum()) / SR
         self.algo_bytes = int(self.lens.sum()) * 4 + int(self.rows[-1]) * self.F * 4
+        self.settle = SETTLE_LAUNCHES  # as for the headline workload (settle_device)
         self.kernel = self.plan.kernel_name
         self.workload = (f"BASELINE configs[3] stand-in: {C} cuts per GPU per step with LibriSpeech-like lengths (log-normal, 1-35 s, mean "
                          f"{self.audio_seconds / C:.1f} s; the corpus is not available offline), 40-dim MFCC (40 mel filters, 40 cepstra, lifter 22), "

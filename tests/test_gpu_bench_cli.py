@@ -45,3 +45,13 @@ def test_total_cuts_is_the_same_corpus_and_the_same_rate_as_the_default_form():
     for k in ("rel_l2_max", "max_abs_max", "hip_vs_f64_max_abs"):
         assert strong["parity"][k] == weak["parity"][k], k
     assert abs(strong["value"] / weak["value"] - 1.0) < 0.08, (strong["value"], weak["value"])
+
+
+@pytest.mark.parametrize("flags", [("--config", "mfcc40_libri", "--cuts", "600", "--steps", "3"), ("--config", "onthefly", "--cuts", "6", "--steps", "2", "--no-extra"),
+                                   ("--config", "onthefly", "--cuts", "8", "--steps", "2", "--prefetch", "4", "--streams", "2", "--no-extra"),
+                                   ("--config", "bulk_save", "--cuts", "2", "--steps", "1", "--no-extra")])
+def test_the_other_configs_run_and_pass_their_in_run_parity(flags):
+    """Small instances of every `--config`: one JSON line, in-run oracle parity `pass`, the contract's keys."""
+    res, err = _bench(*flags)
+    assert res["parity"]["pass"] is True, (res["parity"], err[-1500:])
+    assert res["config"]["name"] == flags[1] and res["value"] > 0 and res["roofline"]["frac"] > 0 and res["unit"] == "cuts/s"
