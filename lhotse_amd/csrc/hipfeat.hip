@@ -2636,9 +2636,11 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_plan(hipfeat_speed_bank*
     if (L < 0 || L > INT32_MAX / 2) return fail(HIPFEAT_ERR_INVALID, "cut %lld: %lld samples out of range", (long long)b, (long long)L);
     if (idx >= bank->num) return fail(HIPFEAT_ERR_INVALID, "cut %lld: bank index %d of %d", (long long)b, idx, bank->num);
     int64_t o = h_offsets[b], n = L;
+    if (h_offsets[b] < 0 || h_offsets[b] + L > tail_start)  // (also the unperturbed cuts: the tail is about to be written)
+      return fail(HIPFEAT_ERR_INVALID, "cut %lld (offset %lld, %lld samples) reaches into the arena's tail (tail_start %lld)", (long long)b, (long long)h_offsets[b],
+                  (long long)L, (long long)tail_start);
     if (idx >= 0) {
       const int64_t ol = hipfeat_resampled_length(L, bank->orig[idx], bank->nw[idx]);
-      if (h_offsets[b] + L > tail_start) return fail(HIPFEAT_ERR_INVALID, "cut %lld reaches into the arena's tail (tail_start %lld)", (long long)b, (long long)tail_start);
       s.res.push_back(ResCut{h_offsets[b], tail, (int32_t)L, (int32_t)ol, (int32_t)blocks, bank->kind[idx]});
       blocks += (ol + bank->outs[idx] - 1) / bank->outs[idx];
       if (blocks > INT32_MAX - (1 << 24)) return fail(HIPFEAT_ERR_INVALID, "batch too large for one launch");

@@ -122,6 +122,8 @@ def test_errors_and_ticket_discipline():
     idx = bank.index_of(fac)
     with pytest.raises(_lib.HipFeatError, match="arena holds"):
         bank.extract_collated(ex.plan, arena[: front + 64], offs, lens, idx, front, LOG_EPSILON)
+    with pytest.raises(_lib.HipFeatError, match="reaches into the arena's tail"):  # (an unperturbed cut beyond tail_start would be overwritten)
+        bank.extract_collated(ex.plan, arena, offs, lens, idx, front - 8, LOG_EPSILON)
     short = lens.copy()
     short[3] = 50
     with pytest.raises(_lib.HipFeatError, match="TOO_SHORT"):
