@@ -1229,10 +1229,10 @@ def main():
                 "clk_per_instr": clk_per_instr,
                 "achieved_frac": round(frames_per_s * float(ipf) * clk_per_instr / (NUM_SIMDS * MAX_CLOCK), 4),
                 "achieved_frac_at_measured_clock": None if not mhz else round(frames_per_s * float(ipf) * clk_per_instr / (NUM_SIMDS * mhz * 1e6), 4),
-                "shader_clock": sclk if sclk else ({"median_MHz": mhz, "source": "profiles/traffic.json (power probe of the committed PMC run; sysfs not readable in this run)"} if mhz else None),
+                "shader_clock": sclk if sclk else ({"median_MHz": mhz, "source": "profiles/traffic.json: rocm-smi samples over a 7 s run of this kernel on the box of the committed PMC run (profiles/r04_power_probe.txt)"} if mhz else None),
                 "what": "wave-level VALU instructions per frame (committed PMC run: SQ_INSTS_VALU / frames) x issue clocks per instruction "
                         "/ (1024 SIMDs x clock): the share of the chip's VALU issue slots this launch rate needs -- at the nominal 2.4 GHz "
-                        "(achieved_frac) and at the shader clock the chip actually held under its power cap during the timed loop",
+                        "(achieved_frac) and at the shader clock the chip holds under its 1.4 kW power cap while this kernel runs for seconds (`shader_clock`)",
             }
         if world == 1:
             extra = {} if args.no_extra else w.extra(args)
