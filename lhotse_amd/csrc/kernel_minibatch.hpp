@@ -50,8 +50,9 @@ struct MbHeader {
 };
 struct MbInlineArgs {
   MbHeader h;
-  unsigned char blob[kMbInlineBytes];
+  alignas(16) unsigned char blob[kMbInlineBytes];  // (read back 16 bytes per lane)
 };
+static_assert(offsetof(MbInlineArgs, blob) % 16 == 0 && sizeof(MbInlineArgs) <= 3584, "kernel-argument layout");
 
 typedef int mb_i4 __attribute__((ext_vector_type(4)));
 
