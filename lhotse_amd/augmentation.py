@@ -305,7 +305,11 @@ class HipSpeedBank:
         self.factors = sorted({float(f) for f in factors if float(f) != 1.0})
         self.resamplers = [get_or_create_resampler(round(sampling_rate * f), sampling_rate, device) for f in self.factors]
         self.lib = _lib.load()
-        self.device = self.resamplers[0].device if self.resamplers else torch.device("cuda", torch.cuda.current_device())
+        if self.resamplers:
+            self.device = self.resamplers[0].device
+        else:  # a bank without resamplers (plain collated extraction through the launch pair): the device is the caller's
+            dev = torch.device("cuda" if device is None else device)
+            self.device = torch.device("cuda", torch.cuda.current_device() if dev.index is None else dev.index)
         handles = np.array([r.handle for r in self.resamplers], dtype=np.uint64)
         out = np.zeros(1, dtype=np.uint64)
         self.handle = 0

@@ -2666,7 +2666,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_plan(hipfeat_speed_bank*
   if (st != HIPFEAT_OK) return st;
   s.lay.owns = false;
   s.res_blocks = blocks;
-  s.arena_need = tail;
+  s.arena_need = s.res.empty() ? tail_start : tail;  // (nothing to resample: the tail is not touched, its 16-byte alignment slack not needed)
   s.max_frames = 0;
   s.total_rows = 0;
   s.rows.resize((size_t)batch);

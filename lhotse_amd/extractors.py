@@ -247,6 +247,7 @@ class _Plan:
             _lib.addr(out),
         )
         self.handle = int(out[0])
+        self._pair_ok = os.environ.get("HIPFEAT_COLLATED_NO_PAIR") is None
         self.feature_dim = int(self.lib.raw("hipfeat_plan_feature_dim", self.handle))
         self.kernel_name = self.lib.string("hipfeat_plan_kernel_name", self.handle)
         self.snip_edges = int(cfg.snip_edges)
@@ -315,6 +316,19 @@ class _Plan:
         assert wave.dtype == torch.float32 and wave.is_contiguous() and wave.device == self.device
         wave = self._dithered(wave)
         lengths, offsets = _lib.i64(lengths), _lib.i64(offsets)
+        # Round 4: the launch pair of the on-the-fly mini-batch (hipfeat_minibatch_*, a bank without resamplers) also serves the plain
+        # collated extraction -- the padding rows and the descriptor tables travel with the first launch (for up to ~90 cuts in its kernel
+        # arguments: no host -> device copy in front of the feature launch), where hipfeat_extract_collated stages the descriptors through
+        # pinned memory and fills the padding in a third launch.  Same kernels on the same operands: bit-identical.
+        if len(lengths) and self._pair_ok and (padded is None or bool((_lib.i64(padded) == int(lengths.max())).all())) and wave.ndim == 1:
+            try:
+                out, frames, _, _ = self._pair_bank().extract_collated(self, wave, offsets, lengths, np.full(len(lengths), -1, dtype=np.int32), wave.numel(),
+                                                                       pad_value, zero_pad_batch=padded is not None)
+                return out, frames
+            except _lib.HipFeatError as e:
+                if e.status != _lib.ERR_UNSUPPORTED:
+                    raise
+                self._pair_ok = False  # (Whisper / librosa plans keep the three-launch route)
         n, shift, snip = self.n, self.shift, self.snip_edges
         frames = self.num_frames_many(lengths)
         if padded is not None:
@@ -330,7 +344,18 @@ class _Plan:
         assert np.array_equal(got, frames)
         return out, frames
 
+    def _pair_bank(self):
+        bank = self.__dict__.get("_bank")
+        if bank is None:
+            from .augmentation import HipSpeedBank
+
+            bank = self.__dict__["_bank"] = HipSpeedBank([], 16000, self.device)  # (no resamplers: the rate is irrelevant)
+        return bank
+
     def close(self):
+        bank = self.__dict__.pop("_bank", None)
+        if bank is not None:
+            bank.close()
         if self.handle:
             try:
                 self.lib.raw("hipfeat_plan_destroy", self.handle)
