@@ -146,54 +146,6 @@ def cpu_baseline(seconds: float = 12.0, procs: int = 0, mode: str = "", what: st
     return out
 
 
-class ClockSampler:
-    """Shader clock while the timed loop runs: a thread polling the driver's sysfs view (pp_dpm_sclk, the starred line) every 2 ms.
-    None where the box does not expose it.  (The VALU-issue share of `roofline.secondary` is stated at the NOMINAL 2.4 GHz and at this
-    clock: under the 1.4 kW cap the chip runs the kernel at ~1.8-2.0 GHz)"""
-
-    def __init__(self):
-        import glob
-        import threading
-
-        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.samples, self._stop, self._thread = [], threading.Event(), None
-        if self.paths:
-            self._thread = threading.Thread(target=self._run, daemon=True)
-
-    def _read(self):
-        best = None
-        for p in self.paths:
-            try:
-                with open(p) as f:
-                    for line in f:
-                        if "*" in line:
-                            mhz = int("".join(ch for ch in line.split(":")[1] if ch.isdigit()))
-                            best = mhz if best is None else max(best, mhz)  # (the busy card is the one at the higher clock)
-            except (OSError, ValueError, IndexError):
-                pass
-        return best
-
-    def _run(self):
-        while not self._stop.is_set():
-            v = self._read()
-            if v:
-                self.samples.append(v)
-            time.sleep(0.002)
-
-    def start(self):
-        if self._thread is not None:
-            self._thread.start()
-
-    def stop(self):
-        if self._thread is not None:
-            self._stop.set()
-            self._thread.join(timeout=1.0)
-        if not self.samples:
-            return None
-        xs = sorted(self.samples)
-        return {"median_MHz": xs[len(xs) // 2], "min_MHz": xs[0], "max_MHz": xs[-1], "samples": len(xs)}
-
-
 def kernel_source_hash(files) -> str:
     h = hashlib.sha256()
     for rel in files:
@@ -202,13 +154,18 @@ def kernel_source_hash(files) -> str:
     return h.hexdigest()[:16]
 
 
-def load_profile_constants(kernel_name: str):
+def load_profile_constants(kernel_name: str, config_name: str = "fbank16k"):
     """HBM bytes per cut and VALU instructions per frame from the committed PMC profile -- only if it was measured on THIS kernel source
-    (profiles/traffic.json carries the sha256 of the files it names; a changed kernel body invalidates the numbers instead of re-labelling them)."""
+    (profiles/traffic.json carries the sha256 of the files it names; a changed kernel body invalidates the numbers instead of re-labelling them).
+    The top level of the file is the headline kernel; `configs[<name>]` holds the entries of the other BASELINE configs (same hash rule)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
+        if config_name != "fbank16k":
+            t = (t.get("configs") or {}).get(config_name) or {}
+            if not t:
+                return {}
         if kernel_name.split(" ")[0] != t.get("kernel"):  # plan.kernel_name = "<kernel> lds=... blocks/CU=..."
             return {}
         if t.get("source_sha256_16") != kernel_source_hash(t.get("source_files", [])):
@@ -218,11 +175,11 @@ def load_profile_constants(kernel_name: str):
         return {}
 
 
-def compare(got, want, truth, log_mel=True):
+def compare(got, want, truth, log_mel=True, alt32=None):
     """Error figures of one cut (oracle/parity_bar.py::figures -- the checker's module, imported by the parity leg only)."""
     from oracle import parity_bar
 
-    return parity_bar.figures(got, want, truth, log_mel=log_mel)
+    return parity_bar.figures(got, want, truth, log_mel=log_mel, alt32=alt32)
 
 
 def fold(stats):
@@ -234,7 +191,7 @@ def fold(stats):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------------------------
-SETTLE_LAUNCHES = 150  # untimed launches at construction of the headline workload (~0.5 s): the package's steady power state
+SETTLE_LAUNCHES = int(os.environ.get("BENCH_SETTLE", "150"))  # (BENCH_SETTLE=0: counter passes, tools/r5_traffic.sh) untimed launches at construction of the headline workload (~0.5 s): the package's steady power state
 FILL_CHUNK = 500  # cuts per uniform_() call: part of the definition of the synthetic input (the generator's stream position)
 
 
@@ -357,19 +314,22 @@ class Fbank16k:
 
     def parity(self, rank):
         from oracle.kaldi_ref import RefConfig, RefExtractor
+        from oracle.kaldi_torch import reference_f32
 
         np = self.np
         chk = self.out[:FRAMES_PER_CUT].float()
         assert self.torch.isfinite(chk).all() and float(chk.std()) > 0.1
         idx = fbank16k_parity_indices(self.C, rank)
-        o32, o64 = RefExtractor(RefConfig(kind="fbank"), np.float32), RefExtractor(RefConfig(kind="fbank"), np.float64)
+        # ref32 = the reference's own float32 torch call sequence; numpy32 = kaldi_ref's float32 mode (float64 FFT rounded down: the
+        # ref32 of rounds 1-4, carried side by side); f64 = truth
+        r32, n32, o64 = reference_f32(RefConfig(kind="fbank")), RefExtractor(RefConfig(kind="fbank"), np.float32), RefExtractor(RefConfig(kind="fbank"), np.float64)
         stats = []
         for i in idx:
             x = self.wave[int(i)].cpu().numpy()
             got = self.out[int(i) * FRAMES_PER_CUT : (int(i) + 1) * FRAMES_PER_CUT].cpu().numpy()
-            want, truth = o32.extract(x), o64.extract(x)
+            want, truth = r32.extract(x), o64.extract(x)
             assert got.shape == want.shape, (got.shape, want.shape)
-            stats.append(compare(got, want, truth))
+            stats.append(compare(got, want, truth, alt32=n32.extract(x)))
         return fold(stats)
 
     def extra(self, args):
@@ -448,12 +408,13 @@ class Mfcc40Libri:
 
     def parity(self, rank):
         from oracle.kaldi_ref import RefConfig, RefExtractor
+        from oracle.kaldi_torch import reference_f32
 
         np = self.np
         rs = np.random.RandomState(4321 + rank)
         idx = np.sort(rs.choice(self.C, size=min(PARITY_CUTS, self.C), replace=False))
         rc = RefConfig(kind="mfcc", num_filters=40, num_ceps=40, cepstral_lifter=22)
-        o32, o64 = RefExtractor(rc, np.float32), RefExtractor(rc, np.float64)
+        o32, o64 = reference_f32(rc), RefExtractor(rc, np.float64)  # ref32 = Wav2MFCC's own float32 torch calls (oracle/kaldi_torch.TorchMfcc)
         stats = []
         for i in idx:
             o, n = int(self.offs[i]), int(self.lens[i])
@@ -542,6 +503,11 @@ class OnTheFly:
         self.audio_seconds = audio_in / SR
         # resampler: reads the perturbed cuts' inputs, writes their outputs; fbank: reads every (perturbed) cut once, writes its rows once
         self.algo_bytes = 4 * (in_samples + out_samples) + 4 * all_out + 4 * NUM_MELS * frames
+        # ... and priced as ONE pass: every input sample read once, every feature written once (the perturbed waveforms in between
+        # are this implementation's intermediate, not algorithmic traffic) -- roofline.frac_end_to_end
+        self.algo_bytes_end_to_end = 4 * audio_in + 4 * NUM_MELS * frames
+        self.algo_parts = {"resampler_read": 4 * in_samples, "resampler_write": 4 * out_samples, "feature_read": 4 * all_out, "feature_write": 4 * NUM_MELS * frames,
+                           "feature_launches_per_step": len(self.batches)}
         self.kernel = self.plan.kernel_name + " + minibatch_prep_" + ("inline_" if K == 1 else "") + "kernel (mixed-factor resample_fast_block + padding rows + descriptor tables)"
         self.workload = (f"BASELINE configs[4]: {NB} mini-batches of 600 s per GPU per step ({ncuts} cuts U(1,30) s, {self.audio_seconds:.0f} s of audio), "
                          "each cut speed-perturbed by 0.9 / 1.0 / 1.1 on the device, then 80-dim log-mel Fbank written straight into the padded "
@@ -589,9 +555,13 @@ class OnTheFly:
         from oracle import resample_ref as R
         from oracle.kaldi_ref import RefConfig, RefExtractor
 
+        from oracle.kaldi_torch import TorchSpeed, reference_f32
+
         np = self.np
         rs = np.random.RandomState(4321 + rank)
-        o32, o64 = RefExtractor(RefConfig(kind="fbank"), np.float32), RefExtractor(RefConfig(kind="fbank"), np.float64)
+        # ref32 = the reference's own float32 torch calls end to end: Speed (F.pad + conv1d(stride), resample.py:284-315) then Fbank
+        o32, o64 = reference_f32(RefConfig(kind="fbank")), RefExtractor(RefConfig(kind="fbank"), np.float64)
+        sp32 = {f: TorchSpeed(SR, f) for f in (0.9, 1.1)}
         stats = []
         for _ in range(PARITY_CUTS):
             b = int(rs.randint(len(self.batches)))
@@ -605,7 +575,7 @@ class OnTheFly:
                 row = i
             x = bt["arena"][int(bt["offs"][i]) : int(bt["offs"][i]) + int(bt["lens"][i])].cpu().numpy()
             fac = float(bt["fac"][i])
-            y32 = R.speed(x, SR, fac, np.float32) if fac != 1.0 else x
+            y32 = sp32[fac](x) if fac != 1.0 else x
             y64 = R.speed(x.astype(np.float64), SR, fac, np.float64) if fac != 1.0 else x.astype(np.float64)
             assert len(y32) == int(pl[i]), (len(y32), int(pl[i]))
             want, truth = o32.extract(y32), o64.extract(y64)
@@ -848,8 +818,10 @@ class BulkSave:
 
         from oracle.kaldi_ref import RefConfig, RefExtractor
 
+        from oracle.kaldi_torch import reference_f32
+
         np, S = self.np, self.S
-        o32, o64 = RefExtractor(RefConfig(kind="fbank"), np.float32), RefExtractor(RefConfig(kind="fbank"), np.float64)
+        o32, o64 = reference_f32(RefConfig(kind="fbank")), RefExtractor(RefConfig(kind="fbank"), np.float64)
         with gzip.open(os.path.join(self.last_root, "cuts.jsonl.gz"), "rt") as f:
             lines = [json.loads(ln) for ln in f]
         assert len(lines) == self.units and [d["id"] for d in lines[:3]] == [c.id for c in self.batches[0][0][:3]]
@@ -1020,6 +992,259 @@ def init_dist(backend: str, dev):
     return dist, backend
 
 
+def bind_numa(local_rank: int, mode: str):
+    """Bind this rank (and every thread it starts later: packing threads, the save thread, pinned-staging first touch) to the CPUs of
+    the NUMA node its GPU hangs off -- lhotse_amd.sharding.bind_to_gpu_numa_node, the helper compute_and_store_features_sharded uses.
+    `mode`: "auto" = bind when N > 1 (8 ranks that all run on node 0's cores would share one socket's memory controllers and cross the
+    inter-socket link for half the GPUs' H2D copies), "on", "off".  Returns what was done, for `config.numa`."""
+    from lhotse_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if mode == "off" or (mode == "auto" and world == 1):
+        return {"bound": False, "why": f"--numa {mode}" + (" and N = 1" if mode == "auto" else "")}
+    return sharding.bind_to_gpu_numa_node(local_rank)
+
+
+def timed_region(w, steps: int, warmup: int, dev, dist, cdev, world: int):
+    """The contract's timed region for workload `w`: (settle,) `warmup` untimed steps, barrier + synchronize, exactly `steps` steps each
+    bracketed by HIP events on the launch stream, barrier + synchronize; elapsed = MAX over ranks."""
+    import numpy as np
+    import torch
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # everything the timed region needs is prepared BEFORE the warm-up: a device that idles for a millisecond between the warm-up and the
+    # timed steps (host-side set-up, a big memset) drops out of its steady power state, and the first ~5 timed launches then run ~20 % slower
+    # -- a quarter of the driver's 20 steps (tools/launch_ramp2.py).  Between the two there is only the contract's barrier.
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if hasattr(w, "settle_device"):
+        w.settle_device()
+    for _ in range(warmup):
+        w.step()
+    barrier()
+    if not os.environ.get("BENCH_NO_CLEAR"):
+        w.clear()  # the parity check reads what the TIMED steps wrote
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        w.step()
+        b.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_launch = [a.elapsed_time(b) for a, b in evs]
+    launch_ms = float(np.mean(per_launch))
+    if os.environ.get("BENCH_SHOW_LAUNCHES"):
+        print("[bench] per-launch ms:", " ".join(f"{x:.3f}" for x in per_launch[:40]), file=sys.stderr, flush=True)
+    if getattr(w, "host_bound", False):  # the step runs on side streams and host threads: the events on this stream see none of it
+        launch_ms = elapsed / steps * 1e3
+    rank_launch_ms = [launch_ms]
+    units_total, audio_total = float(w.units), float(w.audio_seconds)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        lm = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(lm, torch.tensor([launch_ms], dtype=torch.float64, device=cdev))
+        rank_launch_ms = [float(x.item()) for x in lm]
+        s = torch.tensor([units_total, audio_total], dtype=torch.float64, device=cdev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        units_total, audio_total = float(s[0]), float(s[1])
+    return {"elapsed": elapsed, "launch_ms": launch_ms, "rank_launch_ms": rank_launch_ms, "units_total": units_total, "audio_total": audio_total}
+
+
+PARITY_MAX_KEYS = ["rel_l2_max", "max_abs_max", "oracle_f32_vs_f64_rel_l2_max", "oracle_f32_vs_f64_max_abs", "hip_vs_f64_max_abs",
+                   "oracle_f32_vs_f64_rms", "hip_vs_f64_rms", "lin_margin_max"]
+PARITY_ALT_KEYS = ["numpy32_vs_f64_max_abs", "hip_vs_numpy32_max_abs", "numpy32_vs_ref32_max_abs"]
+
+
+def parity_leg(w, rank: int, dist, cdev, log_mel: bool = True):
+    """The in-run parity leg on every rank's TIMED output buffer, worst over all ranks -> (JSON block, verdict)."""
+    import torch
+
+    from oracle import parity_bar
+    from oracle.kaldi_torch import REF32_NAME
+
+    par = w.parity(rank)
+    if dist is not None:
+        keys = PARITY_MAX_KEYS + [k for k in PARITY_ALT_KEYS if k in par]
+        mx = torch.tensor([par[k] for k in keys] + [-par["frac_within"]], dtype=torch.float64, device=cdev)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        cnt = torch.tensor([float(par["n"]), float(par["lin_bad"]), float(par["n_over_2e-3"]), float(par["n_values"])], dtype=torch.float64, device=cdev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        local = par
+        par = {k: float(v) for k, v in zip(keys, mx[:-1])}
+        par.update(frac_within=-float(mx[-1]), n=int(cnt[0].item()), lin_bad=int(cnt[1].item()))
+        par.update({"n_over_2e-3": int(cnt[2].item()), "n_values": int(cnt[3].item()), "over_ref_value_max": local["over_ref_value_max"]})  # (the last one: rank 0's own sample)
+    # the ONE parity statement of the repository (oracle/parity_bar.py; the GPU suite enforces the same three clauses on the same inputs)
+    v = parity_bar.verdict(par)
+    sig = lambda x: float(f"{x:.3e}")  # noqa: E731
+    parity = {
+        "ref32": REF32_NAME,
+        "rel_l2_max": sig(par["rel_l2_max"]),
+        "max_abs_max": sig(par["max_abs_max"]),  # max|hip - reference32|
+        "hip_vs_f64_max_abs": sig(par["hip_vs_f64_max_abs"]),
+        "oracle_f32_vs_f64_max_abs": sig(par["oracle_f32_vs_f64_max_abs"]),  # max|reference32 - f64|: the reference's own floor
+        "elementwise_bar": sig(v["elementwise_bar"]),
+        "K_measured": round(v["K_measured"], 2),
+        "K_allowed": v["K_allowed"],
+        "hip_vs_f64_rms": sig(par["hip_vs_f64_rms"]),
+        "oracle_f32_vs_f64_rms": sig(par["oracle_f32_vs_f64_rms"]),
+        "frac_within_rtol1e-4_atol1e-3": par["frac_within"],
+        "values_over_2e-3": {"count": par["n_over_2e-3"], "of": par["n_values"], "largest_reference_value_among_them": par["over_ref_value_max"],
+                             "log_mel_floor": -15.942385},  # elements over 2e-3 sit within a few nats of the log(eps) clamp: DESIGN section 2
+        "linear_domain_outside_rtol1e-4_atol_eps": par["lin_bad"],  # values with |exp(hip) - exp(ref32)| > 1e-4 exp(ref32) + eps (the reference's own mel floor)
+        "linear_domain_worst_share_of_tolerance": round(par["lin_margin_max"], 4),  # max |exp(hip) - exp(ref32)| / (1e-4 exp(ref32) + eps)
+        "n": par["n"],
+        "oracle_f32_vs_f64_rel_l2_max": sig(par["oracle_f32_vs_f64_rel_l2_max"]),
+        "pass_rel_l2": v["pass_rel_l2"],
+        "pass_linear": v["pass_linear"] if log_mel else None,
+        "pass_elementwise": v["pass_elementwise"],
+        "pass": v["pass"],
+        "what": f"{PARITY_CUTS} cuts per rank sampled from the timed output buffer vs the oracle, worst over all ranks; max_abs_max = max|hip - ref32|; "
+                + parity_bar.STATEMENT,
+    }
+    if "numpy32_vs_f64_max_abs" in par:
+        parity["numpy32_floor_of_rounds_1_to_4"] = {
+            "numpy32_vs_f64_max_abs": sig(par["numpy32_vs_f64_max_abs"]), "hip_vs_numpy32_max_abs": sig(par["hip_vs_numpy32_max_abs"]),
+            "numpy32_vs_ref32_max_abs": sig(par["numpy32_vs_ref32_max_abs"]), "K_against_numpy32_floor": round(v["K_against_numpy32_floor"], 2),
+            "what": "oracle/kaldi_ref.py's float32 mode (numpy's float64 rfft rounded to complex64), the ref32 of rounds 1-4: NOT the reference's "
+                    "arithmetic, ~4x closer to float64 than the reference is; side by side for the record, not part of `pass`"}
+    # clauses (1) and (2) stop the run; clause (3) is a tail statistic of a maximum: it is reported in `pass` (and enforced on these
+    # very inputs by the GPU suite) rather than allowed to cost the driver its bench line
+    assert v["pass_rel_l2"] and v["pass_linear"], parity
+    return parity, v
+
+
+def roofline_block(w, launch_ms: float, config_name: str):
+    achieved = w.algo_bytes / (launch_ms * 1e-3)
+    prof = load_profile_constants(w.kernel, config_name)
+    traffic, src = None, None
+    if prof.get("stale"):
+        src = "profiles/traffic.json is stale: the kernel source changed since the PMC run"
+    elif prof.get("hbm_bytes_per_cut") is not None:  # fixed-size cuts: bytes per cut x cuts
+        traffic = round(float(prof["hbm_bytes_per_cut"]) * w.units)
+    elif prof.get("hbm_bytes_per_algorithmic_byte") is not None:  # ragged workloads: the profiled launch's counter bytes / its algorithmic bytes
+        traffic = round(float(prof["hbm_bytes_per_algorithmic_byte"]) * w.algo_bytes)
+    if traffic is not None:
+        src = "profiles/traffic.json (committed rocprofv3 PMC run of this kernel source, not measured in this run)"
+    r = {
+        "bound": "hbm",
+        "achieved": round(achieved / 1e9, 2),
+        "peak": HBM_PEAK / 1e9,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK, 4),
+        "traffic": traffic,
+        "traffic_source": src,
+        "launch_ms": round(launch_ms, 4),
+        "algorithmic_bytes_per_launch": w.algo_bytes,
+    }
+    if getattr(w, "algo_parts", None):
+        r["algorithmic_bytes_parts"] = w.algo_parts
+    for k in ("per_kernel", "infinity_cache_note"):
+        if prof.get(k) and traffic is not None:
+            r["traffic_" + k] = prof[k]
+    e2e = getattr(w, "algo_bytes_end_to_end", None)
+    if e2e:
+        # the same step priced as ONE pass: every input sample read once, every feature written once -- the intermediate (perturbed
+        # waveforms written by the resampler and read back by the feature kernel) is an implementation cost, not algorithmic traffic
+        r["frac_end_to_end"] = round(e2e / (launch_ms * 1e-3) / HBM_PEAK, 4)
+        r["algorithmic_bytes_end_to_end"] = e2e
+        r["frac_note"] = ("`frac` prices the two launches separately (resampler in + out, feature kernel in + out: the unfused intermediate counts); "
+                          "`frac_end_to_end` prices the step as one pass (input samples once + features once)")
+    return r, prof
+
+
+def sub_config(name: str, args, dev, rank: int, dist, cdev, world: int):
+    """One of the other BASELINE configs inside the default run (after the headline's timed region and parity, so that it cannot perturb
+    them): the same contract -- settle, warm-up, barrier, K event-bracketed steps, barrier, MAX over ranks -- and the same parity leg."""
+    import copy
+
+    a = copy.copy(args)
+    a.cuts, a.total_cuts, a.prefetch, a.streams, a.route, a.input = 0, 0, 1, 3, "pair", "uniform"
+    steps = {"mfcc40_libri": 60, "onthefly": 30}[name]
+    w = WORKLOADS[name](dev, rank, a)
+    try:
+        tr = timed_region(w, steps, args.warmup, dev, dist, cdev, world)
+        out = {
+            "metric": w.metric,
+            "value": round(tr["units_total"] * steps / tr["elapsed"], 1),
+            "unit": "cuts/s",
+            "audio_seconds_per_s": round(tr["audio_total"] * steps / tr["elapsed"], 1),
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(tr["elapsed"] / steps * 1e3, 4),
+            "workload": w.workload,
+            "kernel": w.kernel,
+            "cuts_per_gpu_per_step": w.units,
+            "rank_launch_ms": [round(x, 4) for x in tr["rank_launch_ms"]],
+        }
+        out["roofline"], _ = roofline_block(w, tr["launch_ms"], name)
+        if not args.no_parity:
+            p, _ = parity_leg(w, rank, dist, cdev, log_mel=(name != "mfcc40_libri"))
+            out["parity"] = {k: p[k] for k in ("pass", "pass_rel_l2", "pass_linear", "pass_elementwise", "rel_l2_max", "max_abs_max", "hip_vs_f64_max_abs",
+                                               "oracle_f32_vs_f64_max_abs", "K_measured", "K_allowed", "n")}
+        return out
+    finally:
+        w.close()
+
+
+def after_idle(w, dev, idle_s: float = 2.0, launches: int = 25):
+    """The OTHER regime (VERDICT r4 / ADVICE r4): the package idles for `idle_s`, then `launches` back-to-back launches with no settle --
+    the per-launch times of the ramp, and the rate the contract's 5 warm-ups + 20 steps see on their own."""
+    import torch
+
+    torch.cuda.synchronize(dev)
+    time.sleep(idle_s)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+    for a, b in evs:
+        a.record()
+        w.step()
+        b.record()
+    torch.cuda.synchronize(dev)
+    ms = [a.elapsed_time(b) for a, b in evs]
+    tail = ms[5:]
+    return {"first_launches_after_idle_ms": [round(x, 4) for x in ms[:10]],
+            "contract_only": {"value": round(w.units / (sum(tail) / len(tail) * 1e-3), 1), "unit": "cuts/s", "launch_ms": round(sum(tail) / len(tail), 4),
+                              "what": f"no settle launches: {idle_s:.0f} s of idle, then 5 untimed + {len(tail)} event-timed launches back to back (device time, rank 0) -- what a "
+                                      "caller that launches after an idle gap sees; `value` of the line is the sustained rate"}}
+
+
+def gather_extras(local, dist, world: int):
+    """Host-fed legs run on ALL ranks at once (barrier in, barrier out): rank 0 gets every rank's dict and the sums of the numeric leaves."""
+    if dist is None or world == 1:
+        return local
+    objs = [None] * world
+    dist.all_gather_object(objs, local)
+
+    def total(path):
+        vals = []
+        for o in objs:
+            for k in path:
+                o = o.get(k) if isinstance(o, dict) else None
+            if isinstance(o, (int, float)):
+                vals.append(float(o))
+        return round(sum(vals), 1) if len(vals) == world else None
+
+    agg = {}
+    def walk(d, path):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                walk(v, path + [k])
+            elif isinstance(v, (int, float)) and not isinstance(v, bool):
+                node = agg
+                for q in path:
+                    node = node.setdefault(q, {})
+                node[k] = total(path + [k])
+    walk(objs[0] or {}, [])
+    return {"aggregate_over_ranks": agg, "per_rank": objs,
+            "what": f"host-fed legs of all {world} ranks running CONCURRENTLY (barrier in, barrier out): aggregate = sum over ranks of each rank's own rate -- "
+                    "the curve that can bend with N (PCIe root complexes, host memory bandwidth, NUMA), unlike the device-resident `value`"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1037,6 +1262,9 @@ def main():
     ap.add_argument("--no-host-fed", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (`extra`) altogether: A/B runs")
+    ap.add_argument("--no-other-configs", action="store_true", help="fbank16k: do not append BASELINE configs[3] / [4] (`extra.configs`)")
+    ap.add_argument("--numa", default="auto", choices=["auto", "on", "off"], help="bind every rank to the CPUs of its GPU's NUMA node before any pinned allocation "
+                    "(auto = when N > 1); logged in config.numa")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="host processes of the CPU baseline (default: best of a sweep over cores/8, cores/4, cores/2)")
     ap.add_argument("--input", default="uniform", choices=["uniform", "zeros", "sine"], help="fbank16k: synthetic input (the metric is defined on `uniform`; the others exist to expose power/DVFS effects)")
@@ -1048,7 +1276,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)  # does not return
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1059,6 +1287,8 @@ def main():
     # one GPU per rank; ranks wrap around when fewer devices are visible (a launcher that narrows *_VISIBLE_DEVICES per rank, or the
     # gloo self-test where all ranks share the one GPU of the box)
     local_rank = local_rank % torch.cuda.device_count()
+    all_cpus = sorted(os.sched_getaffinity(0))
+    numa = bind_numa(local_rank, args.numa)  # before the first pinned allocation and before any worker thread exists
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist, backend_used = None, None
@@ -1070,106 +1300,37 @@ def main():
         ap.error("--total-cuts is defined for --config fbank16k")
     w = WORKLOADS[args.config](dev, rank, args)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # everything the timed region needs is prepared BEFORE the warm-up: a device that idles for a millisecond between the warm-up and the
-    # timed steps (host-side set-up, a big memset) drops out of its steady power state, and the first ~5 timed launches then run ~20 % slower
-    # -- a quarter of the driver's 20 steps (tools/launch_ramp2.py).  Between the two there is only the contract's barrier and one small launch.
-    # per-step device time: HIP events on the launch stream (torch's current stream)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    clock = None  # (ClockSampler: a polling thread next to a 70 ms timed region is a risk to the wall clock; the clock comes from the committed power probe)
-    if hasattr(w, "settle_device"):
-        w.settle_device()
-    for _ in range(args.warmup):
-        w.step()
-    barrier()
-    if not os.environ.get("BENCH_NO_CLEAR"):
-        w.clear()  # the parity check below reads what the TIMED steps wrote
-    barrier()
-    if clock is not None:
-        clock.start()
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
-        w.step()
-        b.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    sclk = clock.stop() if clock is not None else None
-    per_launch = [a.elapsed_time(b) for a, b in evs]
-    launch_ms = float(np.mean(per_launch))
-    if os.environ.get("BENCH_SHOW_LAUNCHES"):
-        print("[bench] per-launch ms:", " ".join(f"{x:.3f}" for x in per_launch[:40]), file=sys.stderr, flush=True)
-    if getattr(w, "host_bound", False):  # the step runs on side streams and host threads: the events on this stream see none of it
-        launch_ms = elapsed / args.steps * 1e3
-    rank_launch_ms = [launch_ms]
-    units_total, audio_total = float(w.units), float(w.audio_seconds)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        lm = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
-        dist.all_gather(lm, torch.tensor([launch_ms], dtype=torch.float64, device=cdev))
-        rank_launch_ms = [float(x.item()) for x in lm]
-        s = torch.tensor([units_total, audio_total], dtype=torch.float64, device=cdev)
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        units_total, audio_total = float(s[0]), float(s[1])
+    tr = timed_region(w, args.steps, args.warmup, dev, dist, cdev, world)
+    elapsed, launch_ms = tr["elapsed"], tr["launch_ms"]
 
     # ---- parity in the same run, on every rank, on the timed output buffer
     parity = None
     if not args.no_parity:
-        par = w.parity(rank)
-        if dist is not None:
-            keys = ["rel_l2_max", "max_abs_max", "oracle_f32_vs_f64_rel_l2_max", "oracle_f32_vs_f64_max_abs", "hip_vs_f64_max_abs",
-                    "oracle_f32_vs_f64_rms", "hip_vs_f64_rms", "lin_margin_max"]
-            mx = torch.tensor([par[k] for k in keys] + [-par["frac_within"]], dtype=torch.float64, device=cdev)
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            cnt = torch.tensor([float(par["n"]), float(par["lin_bad"]), float(par["n_over_2e-3"]), float(par["n_values"])], dtype=torch.float64, device=cdev)
-            dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-            local = par
-            par = {k: float(v) for k, v in zip(keys, mx[:-1])}
-            par.update(frac_within=-float(mx[-1]), n=int(cnt[0].item()), lin_bad=int(cnt[1].item()))
-            par.update({"n_over_2e-3": int(cnt[2].item()), "n_values": int(cnt[3].item()), "over_ref_value_max": local["over_ref_value_max"]})  # (the last one: rank 0's own sample)
-        # the ONE parity statement of the repository (oracle/parity_bar.py; the GPU suite enforces the same three clauses on the same inputs)
-        from oracle import parity_bar
+        parity, _ = parity_leg(w, rank, dist, cdev, log_mel=(args.config != "mfcc40_libri"))
 
-        v = parity_bar.verdict(par)
-        parity = {
-            "rel_l2_max": float(f"{par['rel_l2_max']:.3e}"),
-            "max_abs_max": float(f"{par['max_abs_max']:.3e}"),
-            "hip_vs_f64_max_abs": float(f"{par['hip_vs_f64_max_abs']:.3e}"),
-            "oracle_f32_vs_f64_max_abs": float(f"{par['oracle_f32_vs_f64_max_abs']:.3e}"),
-            "elementwise_bar": float(f"{v['elementwise_bar']:.3e}"),
-            "K_measured": round(v["K_measured"], 2),
-            "K_allowed": v["K_allowed"],
-            "hip_vs_f64_rms": float(f"{par['hip_vs_f64_rms']:.3e}"),
-            "oracle_f32_vs_f64_rms": float(f"{par['oracle_f32_vs_f64_rms']:.3e}"),
-            "frac_within_rtol1e-4_atol1e-3": par["frac_within"],
-            "values_over_2e-3": {"count": par["n_over_2e-3"], "of": par["n_values"], "largest_reference_value_among_them": par["over_ref_value_max"],
-                                 "log_mel_floor": -15.942385},  # elements over 2e-3 sit within a few nats of the log(eps) clamp: DESIGN section 2
-            "linear_domain_outside_rtol1e-4_atol_eps": par["lin_bad"],  # values with |exp(hip) - exp(ref32)| > 1e-4 exp(ref32) + eps (the reference's own mel floor)
-            "linear_domain_worst_share_of_tolerance": round(par["lin_margin_max"], 4),  # max |exp(hip) - exp(ref32)| / (1e-4 exp(ref32) + eps)
-            "n": par["n"],
-            "oracle_f32_vs_f64_rel_l2_max": float(f"{par['oracle_f32_vs_f64_rel_l2_max']:.3e}"),
-            "pass_rel_l2": v["pass_rel_l2"],
-            "pass_linear": v["pass_linear"],
-            "pass_elementwise": v["pass_elementwise"],
-            "pass": v["pass"],
-            "what": f"{PARITY_CUTS} cuts per rank sampled from the timed output buffer vs the oracle, worst over all ranks; max_abs_max = max|hip - ref32|; "
-                    + parity_bar.STATEMENT,
-        }
-        # clauses (1) and (2) stop the run; clause (3) is a tail statistic of a maximum: it is reported in `pass` (and enforced on these
-        # very inputs by the GPU suite) rather than allowed to cost the driver its bench line
-        assert v["pass_rel_l2"] and v["pass_linear"], parity
+    # ---- the other BASELINE configs under the same (driver) clock: configs[3] and configs[4], every rank, same contract
+    other = {}
+    if args.config == "fbank16k" and not args.no_other_configs and not args.no_extra and not args.total_cuts and args.input == "uniform":
+        for name in ("mfcc40_libri", "onthefly"):
+            other[name] = sub_config(name, args, dev, rank, dist, cdev, world)
+
+    # ---- PCIe-inclusive legs: all ranks at once
+    extra = {}
+    if not args.no_extra:
+        if dist is not None:
+            dist.barrier()
+        local = w.extra(args)
+        if dist is not None:
+            dist.barrier()
+        extra = gather_extras(local, dist, world) if local else {}
+        if args.config == "fbank16k" and hasattr(w, "settle_device"):
+            extra.update(after_idle(w, dev))
+    if other:
+        extra["configs"] = other
 
     if rank == 0:
-        value = units_total * args.steps / elapsed
-        achieved = w.algo_bytes / (launch_ms * 1e-3)
-        prof = load_profile_constants(w.kernel) if args.config == "fbank16k" else {}
-        bytes_per_cut = prof.get("hbm_bytes_per_cut")
+        value = tr["units_total"] * args.steps / elapsed
+        roof, prof = roofline_block(w, launch_ms, args.config)
         res = {
             "metric": w.metric,
             "value": round(value, 1),
@@ -1187,59 +1348,49 @@ def main():
                 "workload": w.workload,
                 "name": args.config,
                 "cuts_per_gpu_per_step": w.units,
-                "audio_seconds_per_s": round(audio_total * args.steps / elapsed, 1),
+                "audio_seconds_per_s": round(tr["audio_total"] * args.steps / elapsed, 1),
                 "sharding": "cuts sharded across ranks, no data-path collective",
                 "scaling": (f"strong: {args.total_cuts} cuts in total per step, ceil(total / world) per rank" if args.total_cuts
                             else "weak: the same number of cuts per GPU per step for every N"),
                 "kernel": w.kernel,
                 "settle": (f"{w.settle} untimed launches directly in front of the contract's warm-up: sustained-throughput metric, the first launches "
-                           "after start-up run 1-4 % slower while the package reaches its steady power state (tools/launch_ramp.py)") if getattr(w, "settle", 0) else None,
+                           "after start-up run 1-4 % slower while the package reaches its steady power state (tools/launch_ramp.py); the rate WITHOUT them "
+                           "is extra.contract_only, the ramp itself extra.first_launches_after_idle_ms") if getattr(w, "settle", 0) else None,
                 "world_size": world,
                 "dist_backend": None if dist is None else ("rccl" if backend_used == "nccl" else backend_used),
-                "rank_launch_ms": [round(x, 4) for x in rank_launch_ms],
+                "rank_launch_ms": [round(x, 4) for x in tr["rank_launch_ms"]],
+                "numa": numa,
             },
             "parity": parity,
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved / 1e9, 2),
-                "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK, 4),
-                "traffic": None if bytes_per_cut is None else round(float(bytes_per_cut) * w.units),
-                "traffic_source": ("profiles/traffic.json is stale: the kernel source changed since the PMC run" if prof.get("stale") else None) if bytes_per_cut is None
-                else "profiles/traffic.json (committed rocprofv3 PMC run of this kernel source, not measured in this run)",
-                "launch_ms": round(launch_ms, 4),
-                "algorithmic_bytes_per_launch": w.algo_bytes,
-            },
+            "roofline": roof,
         }
         if getattr(w, "host_bound", False):
             res["roofline"]["note"] = ("host-, PCIe- and file-system-bound configuration: `achieved` is algorithmic feature-kernel bytes per wall second of the "
                                        "whole step, not a kernel rate; the stage split is in extra")
             res["data"] = "synthetic (host-resident waveforms: PCIe-inclusive)"
-        ipf = prof.get("valu_instr_per_frame")
+        ipf = prof.get("valu_instr_per_frame") if args.config == "fbank16k" else None
         if ipf:
             # every wave64 VALU instruction occupies its SIMD's issue port for >= 2 clk (packed f32 ones 3, measured:
             # tools/ubench/valu_rate.hip); a wave instruction covers `frames_per_wave_instr` frames
             clk_per_instr = float(prof.get("valu_clk_per_instr", 2.0))
             frames_per_s = w.units * FRAMES_PER_CUT / (launch_ms * 1e-3)
-            mhz = (sclk or {}).get("median_MHz") or prof.get("sclk_MHz_under_load")
+            mhz = prof.get("sclk_MHz_under_load")
             res["roofline"]["secondary"] = {
                 "bound": "valu_f32",
                 "instr_per_frame": ipf,
                 "clk_per_instr": clk_per_instr,
                 "achieved_frac": round(frames_per_s * float(ipf) * clk_per_instr / (NUM_SIMDS * MAX_CLOCK), 4),
                 "achieved_frac_at_measured_clock": None if not mhz else round(frames_per_s * float(ipf) * clk_per_instr / (NUM_SIMDS * mhz * 1e6), 4),
-                "shader_clock": sclk if sclk else ({"median_MHz": mhz, "source": "profiles/traffic.json: rocm-smi samples over a 7 s run of this kernel on the box of the committed PMC run (profiles/r04_power_probe.txt)"} if mhz else None),
+                "shader_clock": {"median_MHz": mhz, "source": f"profiles/traffic.json: rocm-smi samples over a 7 s run of this kernel on the box of the committed PMC run ({prof.get('power_probe')})"} if mhz else None,
                 "what": "wave-level VALU instructions per frame (committed PMC run: SQ_INSTS_VALU / frames) x issue clocks per instruction "
                         "/ (1024 SIMDs x clock): the share of the chip's VALU issue slots this launch rate needs -- at the nominal 2.4 GHz "
                         "(achieved_frac) and at the shader clock the chip holds under its 1.4 kW power cap while this kernel runs for seconds (`shader_clock`)",
             }
-        if world == 1:
-            extra = {} if args.no_extra else w.extra(args)
-            if extra:
-                res["extra"] = extra
-            if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.cpu_procs, w.cpu_mode, w.cpu_what)
+        if extra:
+            res["extra"] = extra
+        if world == 1 and not args.no_cpu_baseline:
+            os.sched_setaffinity(0, all_cpus)  # the CPU baseline's worker processes get the whole host, whatever --numa did to this rank
+            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.cpu_procs, w.cpu_mode, w.cpu_what)
         print(json.dumps(res), flush=True)
     w.close()
     if dist is not None:

@@ -39,6 +39,20 @@ using namespace hipfeat;
 // --------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
+// Environment switches, two classes:
+//   route_env  ROUTING switches choose among kernels / launch routes that ALL meet the parity bar (HIPFEAT_FORCE_GENERIC, *_VARIANT,
+//              HIPFEAT_NO_FIXED_SCHEDULE, HIPFEAT_NO_WAVE_*, HIPFEAT_NO_FLAT, HIPFEAT_RESAMPLE_GENERIC, HIPFEAT_MB_NO_INLINE): the GPU
+//              suite uses them to compare the instances of ONE library against each other, bit for bit where the arithmetic is the same.
+//   exp_env    EXPERIMENT switches skip work or retune launch shapes (HIPFEAT_MB_SKIP = deliberately wrong results, HIPFEAT_MB_SLOTS,
+//              HIPFEAT_ROUNDS, HIPFEAT_ROUNDS_R3).  They exist only in builds with -DHIPFEAT_EXPERIMENTS (tools/variants.py); in the
+//              product library the names are never read, so no environment can make it emit wrong results.
+static inline const char* route_env(const char* name) { return getenv(name); }
+#ifdef HIPFEAT_EXPERIMENTS
+static inline const char* exp_env(const char* name) { return getenv(name); }
+#else
+static inline const char* exp_env(const char*) { return nullptr; }
+#endif
+
 static hipfeat_status fail(hipfeat_status st, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -498,7 +512,7 @@ static hipfeat_status setup_fft512c(hipfeat_plan* p, const float* h_window, cons
 static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const float* h_mel, const float* h_dct,
                                    const float* h_lifter) {
   const hipfeat_config& c = p->cfg;
-  const char* force = getenv("HIPFEAT_FORCE_GENERIC");
+  const char* force = route_env("HIPFEAT_FORCE_GENERIC");
   if (force && force[0] == '1') return HIPFEAT_OK;
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
   const bool mfcc = c.kind == HIPFEAT_MFCC;
@@ -512,7 +526,7 @@ static hipfeat_status setup_fft512(hipfeat_plan* p, const float* h_window, const
   if (ntiles > 8) return HIPFEAT_OK;
 
   if (!spec) {  // log-mel filterbank / MFCC: the wave-autonomous kernel, unless the schedule or the LDS budget says no
-    const char* var = getenv("HIPFEAT_FFT512_VARIANT");
+    const char* var = route_env("HIPFEAT_FFT512_VARIANT");
     if (!(var && var[0] == 'b')) {  // HIPFEAT_FFT512_VARIANT=b: the 16-frame-tile kernel for these too (tests compare the two)
       hipfeat_status stc = setup_fft512c(p, h_window, h_mel, nrows, h_dct, h_lifter);
       if (stc != HIPFEAT_OK || p->variant == 7) return stc;
@@ -610,7 +624,7 @@ static const void* fft1024c_entry() {
 // 3 = <20, 24,24,8> (22.05 kHz), 4 = <32, 16,16,8, PLAIN> (the librosa default: n_fft 1024 @ 22.05 kHz, 80 slaney filters, no DC removal,
 // no pre-emphasis); 0 = generic
 static int fft1024c_fixed_id(int nrows, int nsets, const int* steps, bool plain) {
-  if (nsets != 3 || getenv("HIPFEAT_NO_FIXED_SCHEDULE")) return 0;
+  if (nsets != 3 || route_env("HIPFEAT_NO_FIXED_SCHEDULE")) return 0;
   if (nrows == 32) return plain && steps[0] == 16 && steps[1] == 16 && steps[2] == 8 ? 4 : 0;
   if (nrows == 20 && steps[0] == 24 && steps[1] == 16 && steps[2] == 8) return 1;
   if (nrows == 26 && steps[0] == 24 && steps[1] == 16 && steps[2] == 8) return 2;
@@ -623,7 +637,7 @@ static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, con
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
   const bool librosa = c.kind == HIPFEAT_LIBROSA_FBANK;  // centred frames, |X| or |X|^2, log10 (librosa_fbank.py:66-137)
   if (p->variant != 0 || (c.kind != HIPFEAT_FBANK && !librosa) || c.fft_length != 1024 || (shift & 1) || N < 32 * 17 || c.use_energy ||
-      (c.use_fft_mag && !librosa) || getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_AUTONOMOUS"))
+      (c.use_fft_mag && !librosa) || route_env("HIPFEAT_FORCE_GENERIC") || route_env("HIPFEAT_NO_WAVE_AUTONOMOUS"))
     return HIPFEAT_OK;
   const int need = (N + 31) / 32;
   const int nrows = need <= 20 ? 20 : (need <= 26 ? 26 : 32);
@@ -803,7 +817,7 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
   const bool mfcc = c.kind == HIPFEAT_MFCC;
   const bool spec = c.kind == HIPFEAT_SPECTROGRAM || c.kind == HIPFEAT_LOG_SPECTROGRAM;
   if (c.kind > HIPFEAT_MFCC || c.fft_length != 256 || (shift & 1) || N < 16 || c.use_energy || (!spec && c.use_fft_mag) ||
-      getenv("HIPFEAT_FORCE_GENERIC"))
+      route_env("HIPFEAT_FORCE_GENERIC"))
     return HIPFEAT_OK;
   if (mfcc && (M > 8 * kMaxDctGroups || c.num_ceps > 64)) return HIPFEAT_OK;
   const int need = (N + 15) / 16;
@@ -811,8 +825,8 @@ static hipfeat_status setup_fft256(hipfeat_plan* p, const float* h_window, const
   const int ntiles = spec ? 0 : (M + 15) / 16;
   if (ntiles > 8) return HIPFEAT_OK;
   if (!mfcc && !spec) {  // log-mel filterbank: the wave-autonomous kernel, unless the schedule or the LDS budget says no
-    const char* var = getenv("HIPFEAT_FFT256_VARIANT");
-    if (!(var && var[0] == 'b') && !getenv("HIPFEAT_NO_WAVE_AUTONOMOUS")) {  // HIPFEAT_FFT256_VARIANT=b: the 32-frame-tile kernel (tests compare the two)
+    const char* var = route_env("HIPFEAT_FFT256_VARIANT");
+    if (!(var && var[0] == 'b') && !route_env("HIPFEAT_NO_WAVE_AUTONOMOUS")) {  // HIPFEAT_FFT256_VARIANT=b: the 32-frame-tile kernel (tests compare the two)
       hipfeat_status stc = setup_fft256c(p, h_window, h_mel, nrows);
       if (stc != HIPFEAT_OK || p->variant == 11) return stc;
     }
@@ -904,7 +918,7 @@ static const void* wave_entry() {
 static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
   const hipfeat_config& c = p->cfg;
   const bool librosa = c.kind == HIPFEAT_LIBROSA_FBANK;
-  if (p->variant != 0 || !p->pow2 || (c.kind > HIPFEAT_MFCC && !librosa) || getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_KERNEL"))
+  if (p->variant != 0 || !p->pow2 || (c.kind > HIPFEAT_MFCC && !librosa) || route_env("HIPFEAT_FORCE_GENERIC") || route_env("HIPFEAT_NO_WAVE_KERNEL"))
     return HIPFEAT_OK;
   const int H = p->H;
   // H = 128 (fft 256) stays on the radix-2 kernel: measured 0.92 M vs 0.72 M cuts/s there; H = 256: 0.46 vs 0.48 M
@@ -972,7 +986,7 @@ static hipfeat_status setup_wave(hipfeat_plan* p, const float* h_mel) {
 static hipfeat_status setup_whisper2(hipfeat_plan* p, const float* h_mel) {
   const hipfeat_config& c = p->cfg;
   if (c.kind != HIPFEAT_WHISPER || c.frame_length != kW2N || c.frame_shift != kW2Shift || c.num_filters > 16 * kW2MaxMelTiles ||
-      getenv("HIPFEAT_FORCE_GENERIC"))
+      route_env("HIPFEAT_FORCE_GENERIC"))
     return HIPFEAT_OK;
   const int M = c.num_filters, nmt = (M + 15) / 16;
   std::vector<float> cs(288);
@@ -1060,7 +1074,7 @@ static hipfeat_status setup_fft2048c(hipfeat_plan* p, const float* h_window, con
   const int N = c.frame_length, shift = c.frame_shift, M = c.num_filters;
   const bool librosa = c.kind == HIPFEAT_LIBROSA_FBANK;  // centred frames, |X| or |X|^2, log10 (librosa_fbank.py:66-137)
   if (p->variant != 0 || (c.kind != HIPFEAT_FBANK && !librosa) || c.fft_length != 2048 || N <= 1024 || c.use_energy ||
-      (c.use_fft_mag && !librosa) || getenv("HIPFEAT_FORCE_GENERIC") || getenv("HIPFEAT_NO_WAVE_AUTONOMOUS"))
+      (c.use_fft_mag && !librosa) || route_env("HIPFEAT_FORCE_GENERIC") || route_env("HIPFEAT_NO_WAVE_AUTONOMOUS"))
     return HIPFEAT_OK;
   const bool odd = (shift & 1) != 0;
   const int need = (N + 63) / 64;
@@ -1119,7 +1133,7 @@ static hipfeat_status setup_fft2048c(hipfeat_plan* p, const float* h_window, con
   // runs 12 waves per workgroup (3 waves/SIMD) without a span prefetch, the span buffer aliasing the exchange / power region (at 48 kHz that
   // layout measured 3 % slower than 8 waves with the prefetch)
   const bool fixed = sch.nsets == 3 && sch.steps[0] == 52 && sch.steps[1] == 28 && sch.steps[2] == 16 && sch.step0[1] == 52 && sch.step0[2] == 80 &&
-                     (odd ? nrows == 18 : nrows == 19) && !getenv("HIPFEAT_NO_FIXED_SCHEDULE");
+                     (odd ? nrows == 18 : nrows == 19) && !route_env("HIPFEAT_NO_FIXED_SCHEDULE");
   const bool w12 = fixed && odd && p->c_xs_floats <= kXRegion && ((size_t)p->c_shared_floats + (size_t)kXWavesFixed * kXRegion) * sizeof(float) <= 160 * 1024;
   int waves = w12 ? kXWavesFixed : kXMaxWaves;
   auto lds_of = [&](int wv) { return ((size_t)p->c_shared_floats + (size_t)wv * (w12 ? kXRegion : p->c_xs_floats + kXRegion)) * sizeof(float); };
@@ -1175,7 +1189,7 @@ static const void* whisper3_entry() {
 static hipfeat_status setup_whisper3(hipfeat_plan* p, const float* h_window, const float* h_mel) {
   const hipfeat_config& c = p->cfg;
   if (p->variant != 6) return HIPFEAT_OK;  // setup_whisper2 decides whether this is the Whisper fast-path configuration
-  const char* v = getenv("HIPFEAT_WHISPER_VARIANT");
+  const char* v = route_env("HIPFEAT_WHISPER_VARIANT");
   if (v && v[0] == '2') return HIPFEAT_OK;
   const int M = c.num_filters;
   Mel4Schedule sch;
@@ -1436,8 +1450,8 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
   // cuts of the batch (a transient layout is built per call).
   int fpb = plan->fpb;
   if (plan->fpb_unit > 0) {
-    static const int forced = getenv("HIPFEAT_ROUNDS") ? atoi(getenv("HIPFEAT_ROUNDS")) : 0;
-    static const bool old_rule = getenv("HIPFEAT_ROUNDS_R3") != nullptr;
+    static const int forced = exp_env("HIPFEAT_ROUNDS") ? atoi(exp_env("HIPFEAT_ROUNDS")) : 0;
+    static const bool old_rule = exp_env("HIPFEAT_ROUNDS_R3") != nullptr;
     const int64_t slots = 256LL * std::max(plan->blocks_per_cu, 1);
     const int64_t stride = std::max<int64_t>(1, batch / 512);
     auto workgroups = [&](int rounds, int64_t step) {  // (estimate for step > 1)
@@ -1470,7 +1484,7 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
   // workgroup per cut, long workgroups whatever the cuts' lengths
   bool ragged = false;
   for (int64_t b = 1; b < batch && !ragged; ++b) ragged = lay->num_frames[(size_t)b] != lay->num_frames[0];
-  static const bool no_flat = getenv("HIPFEAT_NO_FLAT") != nullptr;
+  static const bool no_flat = route_env("HIPFEAT_NO_FLAT") != nullptr;
   lay->flat = ragged && !no_flat && plan->variant == 7 && fft512c_has_flat(plan->nrows, c.frame_length);
   lay->total_quads = 0;
   lay->block_cut.clear();
@@ -1481,7 +1495,7 @@ static hipfeat_status build_descs(const hipfeat_plan* plan, int64_t batch, const
       descs[(size_t)b].first_block = (int32_t)quads;
       quads += (lay->num_frames[(size_t)b] + 3) / 4;
     }
-    static const int forced = getenv("HIPFEAT_ROUNDS") ? atoi(getenv("HIPFEAT_ROUNDS")) : 0;
+    static const int forced = exp_env("HIPFEAT_ROUNDS") ? atoi(exp_env("HIPFEAT_ROUNDS")) : 0;
     const int64_t slots = 256LL * std::max(plan->blocks_per_cu, 1);
     const int waves_per_wg = plan->fpb_unit / 4;  // a wave takes one quad per round
     int rounds = plan->c_rounds_max;
@@ -2393,7 +2407,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_resampler_create(int32_t orig_freq
     return st;
   }
   // speed 0.9 / 1.1 / 0.95 / 1.05 at any rate, and the 1:2, 2:1, 3:1 rate conversions
-  const bool fast = !getenv("HIPFEAT_RESAMPLE_GENERIC") &&
+  const bool fast = !route_env("HIPFEAT_RESAMPLE_GENERIC") &&
                     (pick_resample_fast<9, 10, 7>(r) || pick_resample_fast<11, 10, 7>(r) || pick_resample_fast<19, 20, 7>(r) ||
                      pick_resample_fast<21, 20, 7>(r) || pick_resample_fast<1, 2, 7>(r) || pick_resample_fast<2, 1, 13>(r) ||
                      pick_resample_fast<3, 1, 19>(r));
@@ -2535,6 +2549,7 @@ struct MbSlot {
 
 struct hipfeat_speed_bank {
   int device = 0;
+  bool device_set = false;  // a bank without resamplers learns its device from the first plan it serves
   int num = 0;
   int kind[kMbMaxResamplers] = {};  // kernel_minibatch.hpp's switch index of resampler i
   int orig[kMbMaxResamplers] = {}, nw[kMbMaxResamplers] = {}, outs[kMbMaxResamplers] = {};
@@ -2569,7 +2584,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_speed_bank_create(const hipfeat_re
       return fail(HIPFEAT_ERR_UNSUPPORTED, "resampler %d (%d -> %d) is not one of the compile-time ratios of the mixed launch (9:10, 11:10 = speed 0.9 / 1.1), "
                   "or lives on another device: use hipfeat_resample per factor", i, o, n);
     }
-    if (i == 0) b->device = r->device;
+    if (i == 0) {
+      b->device = r->device;
+      b->device_set = true;
+    }
     b->kind[i] = k;
     b->orig[i] = r->orig;
     b->nw[i] = r->nw;
@@ -2578,13 +2596,17 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_speed_bank_create(const hipfeat_re
     b->lds_bytes = std::max(b->lds_bytes, lds_floats[k] * sizeof(float));
   }
   b->num = num;
-  b->allow_inline = getenv("HIPFEAT_MB_NO_INLINE") == nullptr;
+  b->allow_inline = route_env("HIPFEAT_MB_NO_INLINE") == nullptr;
   *out = b;
   return HIPFEAT_OK;
 }
 
 extern "C" HIPFEAT_API hipfeat_status hipfeat_speed_bank_destroy(hipfeat_speed_bank* b) {
   if (!b) return HIPFEAT_OK;
+  if (!b->device_set) {  // never served a plan: no slot was ever allocated, and there is no device to touch
+    delete b;
+    return HIPFEAT_OK;
+  }
   DeviceGuard g(b->device);
   for (auto& s : b->slots) {
     if (s.busy && s.ev) (void)hipEventSynchronize(s.ev);
@@ -2607,9 +2629,13 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_plan(hipfeat_speed_bank*
   if (batch <= 0 || !h_offsets || !h_num_samples || batch > 65535) return fail(HIPFEAT_ERR_INVALID, "bad batch arguments (1 ... 65535 cuts)");
   if (plan->variant == 9 || plan->cfg.kind == HIPFEAT_WHISPER || plan->cfg.kind == HIPFEAT_LIBROSA_FBANK)
     return fail(HIPFEAT_ERR_UNSUPPORTED, "the mini-batch launch pair serves the Kaldi-style plans (spectrogram / fbank / mfcc)");
-  if (bank->num > 0 && plan->device != bank->device) return fail(HIPFEAT_ERR_INVALID, "plan and bank live on different devices");
   if (num_groups < 0 || (num_groups > 0 && !h_group_sizes)) return fail(HIPFEAT_ERR_INVALID, "bad group arguments");
   std::lock_guard<std::mutex> lk(bank->mu);
+  if (!bank->device_set) {  // a bank without resamplers (plain collated extraction): its slots live on the device of the plans it serves
+    bank->device = plan->device;
+    bank->device_set = true;
+  }
+  if (plan->device != bank->device) return fail(HIPFEAT_ERR_INVALID, "plan (device %d) and bank (device %d) live on different devices", plan->device, bank->device);
   const int64_t ticket = bank->next_ticket++;
   MbSlot& s = bank->slots[ticket % kMbSlots];
   s.planned = false;
@@ -2700,7 +2726,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_plan(hipfeat_speed_bank*
 extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* bank, int64_t ticket, float* d_arena, int64_t arena_floats,
                                                             float* d_out, int64_t rows_per_cut, float pad_value, void* stream) {
   if (!bank || !d_arena || !d_out) return fail(HIPFEAT_ERR_INVALID, "NULL argument");
-  static const int dbg_skip = getenv("HIPFEAT_MB_SKIP") ? atoi(getenv("HIPFEAT_MB_SKIP")) : 0;  // experiments: 1 = no feature launch, 2 = no prep launch
+  static const int dbg_skip = exp_env("HIPFEAT_MB_SKIP") ? atoi(exp_env("HIPFEAT_MB_SKIP")) : 0;  // experiments: 1 = no feature launch, 2 = no prep launch
   std::lock_guard<std::mutex> lk(bank->mu);
   MbSlot& s = bank->slots[((ticket % kMbSlots) + kMbSlots) % kMbSlots];
   if (s.ticket != ticket || !s.planned)
@@ -2752,7 +2778,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* 
   }
   s.lay.d_cuts = static_cast<CutDesc*>(s.d);
   // a few workgroups per CU take the items round-robin; the grid is the smallest one that gives every workgroup the same number of items
-  static const int64_t mb_slots = getenv("HIPFEAT_MB_SLOTS") ? std::max(1, atoi(getenv("HIPFEAT_MB_SLOTS"))) : 1792;
+  static const int64_t mb_slots = exp_env("HIPFEAT_MB_SLOTS") ? std::max(1, atoi(exp_env("HIPFEAT_MB_SLOTS"))) : 1792;
   const int64_t items = fill_items + s.res_blocks, per_wg = std::max<int64_t>(1, (items + mb_slots - 1) / mb_slots);
   const unsigned grid = (unsigned)std::max<int64_t>(1, (items + per_wg - 1) / per_wg);
   MbInlineArgs args;  // (header + 3.3 KB; only the used part of the blob is written)

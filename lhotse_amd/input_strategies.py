@@ -33,6 +33,20 @@ import torch
 
 from .compat import HAVE_LHOTSE, LOG_EPSILON
 
+
+BANK_RATIOS = ((9, 10), (11, 10))  # orig : new of the mixed launch's compile-time resamplers (hipfeat_speed_bank_create) = speed 0.9 / 1.1
+
+
+def _bank_ratio_ok(sampling_rate: int, factor: float) -> bool:
+    """Speed(factor) resamples round(sr * factor) -> sr (lhotse/augmentation/torchaudio.py:37-42); the mixed launch serves the ratios
+    of BANK_RATIOS after reduction by the gcd (resample.py:219-222)."""
+    import math
+
+    orig, new = int(round(sampling_rate * factor)), int(sampling_rate)
+    g = math.gcd(orig, new)
+    return g > 0 and (orig // g, new // g) in BANK_RATIOS
+
+
 if HAVE_LHOTSE:  # pragma: no cover - authoring container only
     from lhotse.audio.utils import suppress_audio_loading_errors  # type: ignore
     from lhotse.dataset.collation import collate_vectors, read_audio_from_cuts  # type: ignore
@@ -182,13 +196,19 @@ if HAVE_LHOTSE:  # pragma: no cover - authoring container only
             bank = cache.get(key)
             if bank is None or not need <= set(bank.factors):
                 have = set() if bank is None else set(bank.factors)
+                # only the factors whose resampling ratio round(sr * f) : sr reduces to one of the mixed launch's compile-time ratios can be
+                # served by a bank; every other factor is refused ON ITS OWN (a mini-batch with {0.9, 0.95} used to blacklist 0.9
+                # as well, and every later 0.9 / 1.1 mini-batch silently fell back to the three-launch route)
+                bad = {f for f in need - have if not _bank_ratio_ok(sr, f)}
+                if bad:
+                    refused |= bad
+                    return None
                 try:
                     bank = cache[key] = HipSpeedBank(sorted(have | need), sr, device)
                 except HipFeatError as e:
                     if e.status != ERR_UNSUPPORTED:
                         raise
-                    refused |= need - have  # (one of them is outside the mixed launch's ratios: per-factor launches from now on)
-                    return None
+                    return None  # (this mini-batch goes per factor; nothing is blacklisted on a guess)
             return bank
 
         def _perturb_and_extract(self, audios: List[torch.Tensor], factors: List[float], wants: List[int], sr: int):

@@ -80,6 +80,114 @@ def all_reduce_stats(num_cuts: int, elapsed: float, device=None) -> Tuple[int, f
     return num_cuts, elapsed
 
 
+# ---- NUMA placement of a rank ----------------------------------------------------------------------------------------------
+def _parse_cpulist(text: str) -> List[int]:
+    """"0-31,128-159" -> [0, ..., 31, 128, ..., 159] (the format of /sys/.../local_cpulist and node*/cpulist)."""
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _gpu_pci_address(device_index: int, sysfs: str = "/sys"):
+    """PCI address "dddd:bb:dd.f" of HIP device `device_index` as this process sees it (visible-device masks applied by the runtime):
+    torch's device properties first; else the KFD topology in enumeration order (GPU nodes only), which is HIP's order when no mask is set."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            p = torch.cuda.get_device_properties(device_index)
+            if all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+                return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+    except Exception:  # noqa: BLE001
+        pass
+    if any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        return None  # the index no longer maps onto the topology order
+    nodes = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    gpus = []
+    try:
+        for n in sorted(os.listdir(nodes), key=int):
+            props = {}
+            with open(os.path.join(nodes, n, "properties")) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    props[k] = v.strip()
+            if int(props.get("simd_count", "0")) > 0:
+                loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+                gpus.append(f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}")
+    except (OSError, ValueError):
+        return None
+    return gpus[device_index] if device_index < len(gpus) else None
+
+
+def bind_to_gpu_numa_node(device_index: int, sysfs: str = "/sys", apply: bool = True) -> dict:
+    """Pin this process -- every existing thread, and so every thread started later: the packing pool, the save thread, torch's
+    intra-op pool -- to the CPUs of the NUMA node GPU `device_index` is attached to.  Called before the first pinned allocation:
+    under Linux's default local-allocation policy the staging buffers are then first-touched on that node, so H2D / D2H copies do not
+    cross the inter-socket link and the ranks of a node spread over its memory controllers instead of all starting on node 0.
+    (The reference has no counterpart: its workers are CPU-only, lhotse/cut/set.py:2141-2195; 8 GPU ranks with pinned staging are
+    where placement starts to matter.)
+
+    Never raises: returns {"bound": bool, "node": int | None, "cpus": n, "pci": str | None, "why": str} for the caller's log.
+    HIPFEAT_NUMA_BIND=0 switches it off."""
+    info = {"bound": False, "node": None, "cpus": 0, "pci": None, "why": ""}
+    if os.environ.get("HIPFEAT_NUMA_BIND", "1") in ("0", "off", "false"):
+        info["why"] = "HIPFEAT_NUMA_BIND=0"
+        return info
+    if not hasattr(os, "sched_setaffinity"):
+        info["why"] = "no sched_setaffinity on this platform"
+        return info
+    pci = _gpu_pci_address(device_index, sysfs)
+    info["pci"] = pci
+    if pci is None:
+        info["why"] = "PCI address of the GPU unknown"
+        return info
+    base = os.path.join(sysfs, "bus/pci/devices", pci)
+    try:
+        with open(os.path.join(base, "numa_node")) as f:
+            node = int(f.read().strip())
+    except (OSError, ValueError):
+        info["why"] = f"{base}/numa_node unreadable"
+        return info
+    info["node"] = node
+    if node < 0:
+        info["why"] = "the platform reports no NUMA affinity for this GPU (numa_node = -1: single node, or a VM without topology)"
+        return info
+    cpus: List[int] = []
+    for path in (os.path.join(sysfs, f"devices/system/node/node{node}/cpulist"), os.path.join(base, "local_cpulist")):
+        try:
+            with open(path) as f:
+                cpus = _parse_cpulist(f.read())
+            if cpus:
+                break
+        except (OSError, ValueError):
+            continue
+    allowed = set(os.sched_getaffinity(0))
+    cpus = sorted(c for c in cpus if c in allowed)  # never widen a cgroup / taskset restriction
+    if not cpus:
+        info["why"] = f"node {node} has no CPU this process may run on"
+        return info
+    info["cpus"] = len(cpus)
+    if not apply:
+        info["why"] = "dry run"
+        return info
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    for tid in tids or [0]:
+        try:
+            os.sched_setaffinity(tid, cpus)
+        except OSError:
+            pass  # a thread that has just exited
+    info["bound"] = True
+    info["why"] = f"{len(tids)} thread(s) pinned to the {len(cpus)} CPUs of NUMA node {node} (GPU {device_index} at {pci})"
+    return info
+
+
 # ---- the sharded extraction driver --------------------------------------------------------------------------------------
 class _Rendezvous:
     """The two barriers of the sharded driver (everybody has extracted / rank 0 has combined).  In order of preference: the caller's
@@ -347,6 +455,7 @@ def compute_and_store_features_sharded(
     rank: int = None,
     world: int = None,
     barrier_timeout: float = 3600.0,
+    numa_bind: bool = True,
 ):
     """Feature extraction of one CutSet over the GPUs of a node: the multi-GPU form of ``compute_and_store_features_batch``.
 
@@ -357,6 +466,10 @@ def compute_and_store_features_sharded(
     batch driver on GPU ``LOCAL_RANK`` into its own storage ``<storage_path>/feats-r`` and manifest ``cuts-r.jsonl.gz`` (per-shard
     resume included: an interrupted run continues where each rank stopped), and after a barrier rank 0 merges the shard manifests into
     ``manifest_path`` in input order.  NO collective touches the data path; the barrier is the only communication.
+
+    ``numa_bind`` (default on, for world > 1): before the extractor touches its GPU -- i.e. before any pinned staging buffer exists and
+    before the packing / save threads start -- the rank is pinned to the CPUs of its GPU's NUMA node (``bind_to_gpu_numa_node``;
+    a no-op with a logged reason where the platform reports no topology).  ``HIPFEAT_NUMA_BIND=0`` overrides.
 
     Returns the combined CutSet on rank 0 and the rank's own shard CutSet elsewhere."""
     from pathlib import Path
@@ -388,9 +501,14 @@ def compute_and_store_features_sharded(
                 device_index %= torch.cuda.device_count()
         except ImportError:  # pragma: no cover
             pass
-        extractor.to(f"cuda:{device_index}")
     elif dev.startswith("cuda:"):
         device_index = int(dev.split(":")[1])
+    if numa_bind and world > 1 and device_index is not None:
+        import logging
+
+        logging.getLogger(__name__).info("rank %d: NUMA placement: %s", rank, bind_to_gpu_numa_node(device_index))
+    if dev == "cuda" and world > 1:
+        extractor.to(f"cuda:{device_index}")
 
     if balance == "round_robin":
         mine = CutSet(LazySlicer(cuts.data, k=rank, n=world)) if world > 1 else cuts

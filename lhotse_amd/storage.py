@@ -336,7 +336,10 @@ def pump_batches(batches, extract, save, backlog: int = None, stats: Optional[Di
     backlog = _SAVE_BACKLOG if backlog is None else backlog
     futures = deque()
     t_ext = t_wait = 0.0
-    with ThreadPoolExecutor(max_workers=1) as saver, ThreadPoolExecutor(max_workers=1) as finisher:
+    # the finisher is the OUTER context: on the way out (also on an exception) the saver drains first, while the finisher still accepts
+    # what its stages submit -- the other order shut the finisher down under queued stages, whose rows then reached the archive without
+    # manifest lines
+    with ThreadPoolExecutor(max_workers=1) as finisher, ThreadPoolExecutor(max_workers=1) as saver:
 
         def stage(*item):
             res = save(*item)
@@ -347,21 +350,29 @@ def pump_batches(batches, extract, save, backlog: int = None, stats: Optional[Di
             if inner is not None:
                 inner.result()
 
-        for batch in batches:
-            t0 = time.perf_counter()
-            item = extract(batch)
+        try:
+            for batch in batches:
+                t0 = time.perf_counter()
+                item = extract(batch)
+                t1 = time.perf_counter()
+                t_ext += t1 - t0
+                if item is None:
+                    continue
+                futures.append(saver.submit(stage, *item))
+                while len(futures) > backlog or (futures and futures[0].done() and (futures[0].exception() is not None or futures[0].result() is None or futures[0].result().done())):
+                    collect(futures.popleft())
+                t_wait += time.perf_counter() - t1
             t1 = time.perf_counter()
-            t_ext += t1 - t0
-            if item is None:
-                continue
-            futures.append(saver.submit(stage, *item))
-            while len(futures) > backlog or (futures and futures[0].done() and (futures[0].exception() is not None or futures[0].result() is None or futures[0].result().done())):
+            while futures:
                 collect(futures.popleft())
             t_wait += time.perf_counter() - t1
-        t1 = time.perf_counter()
-        while futures:
-            collect(futures.popleft())
-        t_wait += time.perf_counter() - t1
+        except BaseException:
+            # a failed run: batches that have not started saving are dropped (nothing of them reaches the archive); the one being saved
+            # finishes with its manifest lines.  Rows of the batch that FAILED may be in the archive without lines -- harmless for the
+            # readers (they go by the manifest) and overwritten space-wise by nothing: a resumed run appends behind them.
+            for f in futures:
+                f.cancel()
+            raise
     if stats is not None:
         stats["extract_s"] = stats.get("extract_s", 0.0) + t_ext
         stats["wait_s"] = stats.get("wait_s", 0.0) + t_wait

@@ -13,10 +13,18 @@ itself (oracle/make_golden.py) in the authoring container, and against the
 known-answer table of SURVEY.md section 8c.
 
 Two arithmetic modes:
-  * ``dtype=np.float32`` follows the reference's op order in float32
-    (what the reference computes on CPU),
-  * ``dtype=np.float64`` is the same algorithm in double precision: the
-    "truth" both float32 implementations are measured against.
+  * ``dtype=np.float64`` is the reference's algorithm in double precision: the
+    "truth" both float32 implementations are measured against,
+  * ``dtype=np.float32`` follows the reference's op order in float32 EXCEPT
+    in the FFT: numpy has no float32 FFT, so ``np.fft.rfft`` runs in float64
+    and its result is rounded to complex64 ("float64 FFT rounded to
+    float32").  That is NOT the reference's arithmetic (torch.fft.rfft on a
+    float32 tensor, layers.py:32-42) and sits ~4x closer to float64 than
+    the reference does (4e-4 vs 1.3e-3 ... 2.1e-3 max abs on 10 s
+    of noise).  It remains the general-purpose checker (every kind, window,
+    edge rule; rel-L2 differences to the reference ~1e-6), but `ref32` of the
+    headline parity statements is oracle/kaldi_torch.reference_f32(), which
+    is bit-equal to the live reference.
 
 All citations are path:line relative to /root/reference/.
 """
@@ -294,7 +302,8 @@ class RefExtractor:
         return num_frames(num_samples, self.n, self.shift, self.cfg.snip_edges)
 
     def _spec(self, frames: np.ndarray) -> np.ndarray:
-        """layers.py:32-42: rfft then |X|^2 (or |X|)."""
+        """layers.py:32-42: rfft then |X|^2 (or |X|).  NB float32 mode: numpy's rfft computes in float64; the result is rounded to
+        complex64 (module docstring) -- closer to float64 than the reference's float32 FFT is."""
         X = np.fft.rfft(frames, axis=-1)
         if self.dtype == np.float32:
             X = X.astype(np.complex64)

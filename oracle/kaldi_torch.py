@@ -1,7 +1,8 @@
 """
 TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
 
-The CPU baseline of bench.py: the reference's CPU Fbank path restated with the SAME library calls the reference makes
+`ref32` of every parity statement of this repository (round 5) AND the CPU baseline of bench.py: the reference's CPU Fbank /
+MFCC / Speed path restated with the SAME library calls the reference makes
 (torch.as_strided framing on a flip/cat-padded waveform, torch.mean, F.pad(replicate) pre-emphasis, window multiply,
 zero pad, torch.fft.rfft, abs()**2, matmul with the mel matrix, log) -- lhotse/features/kaldi/layers.py:151-187,
 :565-578, :727-772 as called by Fbank.extract (lhotse/features/kaldi/extractors.py:92-115).  It exists because
@@ -9,8 +10,16 @@ zero pad, torch.fft.rfft, abs()**2, matmul with the mel matrix, log) -- lhotse/f
 path; being the same sequence of ATen kernels, its speed is the reference's (BASELINE.md section 2 probe: ~150 cuts/s per
 single-threaded process in the authoring container).
 
+Why this module and not oracle/kaldi_ref.py is "the reference's float32 arithmetic": numpy has no float32 FFT (np.fft.rfft
+computes in float64; kaldi_ref's float32 mode rounds that result to complex64), so kaldi_ref's float32 output is CLOSER to
+float64 than the reference ever is -- on 16 x 10 s of U(-0.5, 0.5): max|reference - f64| 1.3e-3 ... 2.1e-3, max|kaldi_ref32 - f64|
+4e-4.  torch.fft.rfft on a float32 tensor IS what layers.py:32-42 runs; `reference_f32()` below is therefore what
+bench.py's parity legs, tests/test_gpu_parity.py and __graft_entry__.smoke() take `ref32` from.  kaldi_ref's float64 mode stays
+the truth both float32 implementations are measured against.
+
 Parity status: PINNED -- tests/test_oracle.py::test_torch_baseline_equals_golden checks it against the reference's own
-outputs (tests/golden/fbank_default*.npz).
+outputs (tests/golden/fbank_default*.npz) and tests/test_oracle.py::test_torch_ref32_is_the_live_reference_bit_for_bit
+(authoring container) against the live reference on 16 full-size cuts per extractor: array_equal.
 """
 from __future__ import annotations
 
@@ -88,16 +97,28 @@ class TorchMfcc(TorchFbank):
     own filterbank, then `@ dct`, then `* lifter` -- the CPU baseline of bench.py --config mfcc40_libri.  Pinned by
     tests/test_oracle.py::test_torch_mfcc_baseline_equals_golden against the reference's own output (golden `mfcc40x40`)."""
 
-    def __init__(self, num_filters: int = 40, num_ceps: int = 40, cepstral_lifter: int = 22):
-        cfg = K.RefConfig(kind="mfcc", num_filters=num_filters, num_ceps=num_ceps, cepstral_lifter=cepstral_lifter)
+    def __init__(self, num_filters: int = 40, num_ceps: int = 40, cepstral_lifter: int = 22, cfg: K.RefConfig = None):
+        cfg = cfg or K.RefConfig(kind="mfcc", num_filters=num_filters, num_ceps=num_ceps, cepstral_lifter=cepstral_lifter)
+        num_filters, num_ceps, cepstral_lifter = cfg.num_filters, cfg.num_ceps, cfg.cepstral_lifter
+        assert cfg.kind == "mfcc" and not cfg.snip_edges and not cfg.use_energy and cfg.window_type == "povey"
+        assert cfg.remove_dc_offset and cfg.preemph_coeff != 0.0
         self.device = torch.device("cpu")
         self.cfg = cfg
         self.n, self.shift, self.fft = K.window_sizes(cfg)
         self.window = torch.hann_window(self.n, periodic=False).pow(0.85)
         self.fb = torch.from_numpy(np.ascontiguousarray(K.mel_matrix(cfg, np.float32).astype(np.float32)))
         self.eps = torch.tensor(torch.finfo(torch.float32).eps)
-        self.dct = torch.from_numpy(np.ascontiguousarray(K.dct_matrix(num_ceps, num_filters, np.float32).astype(np.float32)))  # (M, C)
-        self.lifter = torch.from_numpy(K.lifter(num_ceps, cepstral_lifter, np.float32).astype(np.float32))
+        # layers.py:697-706 / :681-695 with torch's own float32 cos / sin on float32 arguments, as the reference builds them (the float64
+        # tables of kaldi_ref.dct_matrix rounded to float32 differ in the last bit, which moves cepstra by up to 3e-4)
+        import math
+
+        n = torch.arange(float(num_filters)).unsqueeze(1)
+        k = torch.arange(float(num_ceps))
+        dct = torch.cos(math.pi / float(num_filters) * (n + 0.5) * k)  # (M, C)
+        dct[:, 0] *= 1.0 / math.sqrt(2.0)
+        dct *= math.sqrt(2.0 / float(num_filters))
+        self.dct = dct
+        self.lifter = 1 + 0.5 * cepstral_lifter * torch.sin(math.pi * torch.arange(num_ceps, dtype=torch.float32) / cepstral_lifter) if cepstral_lifter else None
 
     @torch.no_grad()
     def extract(self, samples: np.ndarray) -> np.ndarray:
@@ -112,7 +133,7 @@ class TorchMfcc(TorchFbank):
         mel = torch.max(torch.matmul(pow_spec, self.fb), self.eps).log()
         mfcc = torch.matmul(mel, self.dct)  # layers.py:717
         if c.cepstral_lifter > 0:
-            mfcc = mfcc * self.lifter       # layers.py:718-719
+            mfcc *= self.lifter             # layers.py:718-719
         return mfcc[0].numpy()
 
 
@@ -140,3 +161,19 @@ class TorchSpeed:
         y = torch.nn.functional.conv1d(w[:, None], self.kernel, stride=self.orig)
         y = y.transpose(1, 2).reshape(1, -1)
         return y[0, : self._len(length, self.orig, self.new)].numpy()
+
+
+def reference_f32(cfg: K.RefConfig = None):
+    """`ref32` of the parity statements: an object with `.extract(samples) -> (T, F) float32` that runs the reference's own float32
+    torch call sequence for `cfg` (fbank or mfcc; povey window, per-item reflect edges, no energy column -- the configurations
+    of BASELINE.json).  Anything else has no torch restatement here and raises."""
+    cfg = cfg or K.RefConfig(kind="fbank")
+    if cfg.kind == "fbank":
+        return TorchFbank(cfg)
+    if cfg.kind == "mfcc":
+        return TorchMfcc(cfg=cfg)
+    raise NotImplementedError(f"no torch restatement of kind {cfg.kind!r}")
+
+
+REF32_NAME = ("oracle/kaldi_torch.py (the reference's own float32 torch call sequence: as_strided framing, torch.fft.rfft, abs()**2, matmul, log; "
+              "array_equal to the live reference on full-size cuts, tests/test_oracle.py::test_torch_ref32_is_the_live_reference_bit_for_bit)")

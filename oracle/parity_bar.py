@@ -11,17 +11,23 @@ logarithm this is read as three clauses, all of which must hold on the pooled va
                        with eps = 1.1920929e-07, the constant at which the reference itself clamps every mel energy
                        (layers.py:536-538, 572: `max(mel, eps).log()`), i.e. what it treats as nothing
   (3) element-wise, log domain, against float64 truth:
-                       max|hip - f64| <= max(2e-3, K * max|ref32 - f64|),   K = 10
-                       i.e. the HIP kernel's worst value is at most K times as far from the float64 result as the reference
-                       arithmetic's own worst value on the same cuts (or inside the flat 2e-3 bar of the goldens).
+                       max|hip - f64| <= max(2e-3, K * max|ref32 - f64|),   K = 3
+                       i.e. the HIP kernel's worst value is at most 3 times as far from the float64 result as the reference's
+                       own worst value on the same cuts (or inside the flat 2e-3 bar of the goldens) -- the same
+                       `max(2e-3, 3 x floor)` escape the golden suite has used since round 1.
 
-Why (3) is not the flat 2e-3 everywhere (measured, profiles/r03_parity_probe.txt, profiles/r04_parity.json): on 10 s of
-uniform noise a few values in a million are mel energies within ~4 nats of the clamp (1e-7 of the row's median, after
-pre-emphasis has pushed the low bins 36 dB under the near-Nyquist ones).  There both float32 pipelines sit at their
-rounding floor: the reference arithmetic is off by 5-9e-4 from float64, the packed real FFT of the kernels (complex FFT
-of half the size + split step, which cancels the near-Nyquist energy out of the low bins) by 1.8-3.8e-3: K = 2 ... 7.6 over
-the seeds of the suite (6.8 on bench.py's seed), rms ratio 1.4-1.5.  K = 10 is that measured range plus head room for
-the maximum of a heavy tail; the reference's own tolerance precedent is decimal=3 (test/features/test_kaldifeat_features.py:103-116).
+ref32 (round 5): the reference's REAL float32 arithmetic -- oracle/kaldi_torch.reference_f32(), the reference's own
+torch call sequence (torch.fft.rfft on float32 frames, layers.py:32-42), array_equal to the live reference on full-size cuts.
+Rounds 1-4 took ref32 from oracle/kaldi_ref.py's float32 mode, whose FFT is numpy's float64 rfft rounded to complex64: its floor
+max|ref32 - f64| (4-5e-4 on 10 s of noise) understated the reference's own error (1.3e-3 ... 2.1e-3) about 4x, which is where round 4's
+"K = 2 ... 7.6, K_allowed = 10" came from.  K went back to 3 in the same change that swapped the floor, BEFORE the re-measurement
+(a tolerance is not to be fitted to the implementation's error); `figures(..., alt32=)` carries the numpy floor
+next to the real one so that profiles/r05_parity.json shows both.
+
+What (3) is about (profiles/r03_parity_probe.txt): on 10 s of uniform noise a few values in a million are mel energies within
+~4 nats of the clamp (1e-7 of the row's median, after pre-emphasis has pushed the low bins 36 dB under the near-Nyquist ones).
+There every float32 pipeline sits at its rounding floor; the reference's own tolerance precedent is decimal=3
+(test/features/test_kaldifeat_features.py:103-116).
 """
 from __future__ import annotations
 
@@ -33,12 +39,13 @@ REL_L2_TOL = 1e-4
 LIN_RTOL = 1e-4
 LIN_ATOL = 1.1920929e-07  # the reference's mel floor (layers.py:536)
 ABS_TOL = 2e-3
-K_FLOOR = 10.0
+K_FLOOR = 3.0
 
 
-def figures(got: np.ndarray, want: np.ndarray, truth: np.ndarray, log_mel: bool = True) -> Dict:
-    """Error figures of ONE cut: hip (`got`) vs the float32 oracle (`want` = the reference's arithmetic) and both against the
-    float64 oracle (`truth`)."""
+def figures(got: np.ndarray, want: np.ndarray, truth: np.ndarray, log_mel: bool = True, alt32: np.ndarray = None) -> Dict:
+    """Error figures of ONE cut: hip (`got`) vs ref32 (`want` = the reference's float32 arithmetic, oracle/kaldi_torch.py) and both
+    against the float64 oracle (`truth`).  `alt32` (optional) = oracle/kaldi_ref.py's float32 mode (float64 FFT rounded to float32,
+    the ref32 of rounds 1-4): its floor and the kernel's distance to it are recorded next to the real ones."""
     got64, want64 = got.astype(np.float64), want.astype(np.float64)
     d = np.abs(got64 - want64)
     fl = np.abs(want64 - truth)
@@ -49,7 +56,13 @@ def figures(got: np.ndarray, want: np.ndarray, truth: np.ndarray, log_mel: bool 
         m = np.abs(np.exp(got64) - ew) / (LIN_RTOL * ew + LIN_ATOL)
         lin_margin, lin_bad = float(m.max()), int((m > 1.0).sum())
     over = d > ABS_TOL
+    alt = {}
+    if alt32 is not None:
+        alt64 = alt32.astype(np.float64)
+        alt = {"alt_floor_abs": float(np.abs(alt64 - truth).max()), "alt_abs": float(np.abs(got64 - alt64).max()),
+               "alt_vs_ref32_abs": float(np.abs(alt64 - want64).max())}
     return {
+        **alt,
         "rel": float(np.linalg.norm(got64 - want64) / np.linalg.norm(want64)),
         "abs": float(d.max()),
         "within": int((d <= 1e-3 + 1e-4 * np.abs(want64)).sum()),
@@ -69,7 +82,12 @@ def figures(got: np.ndarray, want: np.ndarray, truth: np.ndarray, log_mel: bool 
 def fold(stats: List[Dict]) -> Dict:
     """Pool the per-cut figures of one comparison (one rank's sample)."""
     n = max(1, sum(s["total"] for s in stats))
+    alt = {}
+    if stats and all("alt_floor_abs" in s for s in stats):
+        alt = {"numpy32_vs_f64_max_abs": max(s["alt_floor_abs"] for s in stats), "hip_vs_numpy32_max_abs": max(s["alt_abs"] for s in stats),
+               "numpy32_vs_ref32_max_abs": max(s["alt_vs_ref32_abs"] for s in stats)}
     return {
+        **alt,
         "rel_l2_max": max(s["rel"] for s in stats),
         "max_abs_max": max(s["abs"] for s in stats),
         "frac_within": sum(s["within"] for s in stats) / n,
@@ -100,9 +118,12 @@ def verdict(f: Dict) -> Dict:
         "K_allowed": K_FLOOR,
     }
     v["pass"] = v["pass_rel_l2"] and v["pass_linear"] and v["pass_elementwise"]
+    if "numpy32_vs_f64_max_abs" in f:  # the floor rounds 1-4 used, side by side (not part of the verdict)
+        v["K_against_numpy32_floor"] = float(f["hip_vs_f64_max_abs"] / max(f["numpy32_vs_f64_max_abs"], 1e-30))
     return v
 
 
 STATEMENT = ("pass = per-cut rel_l2(hip, ref32) <= 1e-4  AND  every value: |exp(hip) - exp(ref32)| <= 1e-4 exp(ref32) + 1.19e-7 (the reference's "
-             "own mel floor)  AND  max|hip - f64| <= max(2e-3, 10 x max|ref32 - f64|); ref32 = the reference's float32 arithmetic (oracle), "
-             "f64 = the same in float64; oracle/parity_bar.py, enforced on the same inputs by tests/test_gpu_parity.py::test_headline_parity_multi_seed")
+             "own mel floor)  AND  max|hip - f64| <= max(2e-3, 3 x max|ref32 - f64|); ref32 = the reference's own float32 torch call sequence "
+             "(oracle/kaldi_torch.py, array_equal to the live reference), f64 = the same algorithm in float64 (oracle/kaldi_ref.py); "
+             "oracle/parity_bar.py, enforced on the same inputs by tests/test_gpu_parity.py::test_headline_parity_multi_seed")

@@ -41,7 +41,8 @@ def test_bulk_save_workload_writes_what_the_extractor_computes(monkeypatch):
     assert d["custom"] == {"dataloading_info": {"rank": 0, "world_size": 1, "worker_id": None}}
     assert os.path.getsize(d["features"]["storage_path"]) == 120 * 100 * 80 * 4
     par = w.parity(0)
-    assert par["n"] == 8 and par["rel_l2_max"] == 0.0  # stored == what the (oracle-backed) plan computed, bit for bit
+    # stored == what the (numpy-oracle-backed) plan computed; ref32 of the parity leg is the torch restatement since round 5: rounding apart
+    assert par["n"] == 8 and par["rel_l2_max"] < 1e-5
     # the half-precision archive variant of `extra` leaves binary16 rows
     st16 = {}
     root = w._one_pass("float32", "hip_archive_f16", st16)  # (int16 PCM is converted on the device: GPU box only)

@@ -26,17 +26,20 @@ def _bench(*flags, env=None):
 def test_the_process_group_leg_runs_on_rccl():
     """BENCH_FORCE_DIST=1: the N > 1 code path (barrier, MAX of the elapsed time, gathered launch times, parity maxima) on a
     single-rank RCCL group.  A silent fall-back to gloo on a box whose RCCL works would hide a broken RCCL path until the 8-GPU run."""
-    res, err = _bench("--steps", "3", "--cuts", "2000", env={"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29417",
+    res, err = _bench("--steps", "3", "--cuts", "2000", "--no-other-configs", env={"BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29417",
                                                               "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert res["config"]["dist_backend"] == "rccl", (res["config"], err[-2000:])
     assert res["n_gpus"] == 1 and res["scaling"] == "weak" and res["parity"]["pass"] is True
     assert len(res["config"]["rank_launch_ms"]) == 1
+    assert "kaldi_torch" in res["parity"]["ref32"] and res["parity"]["K_allowed"] <= 3.0  # VERDICT r4: the reference's real float32 floor, K <= 3
+    assert res["parity"]["numpy32_floor_of_rounds_1_to_4"]["numpy32_vs_f64_max_abs"] < res["parity"]["oracle_f32_vs_f64_max_abs"]
+    assert "bound" in res["config"]["numa"]
 
 
 def test_total_cuts_is_the_same_corpus_and_the_same_rate_as_the_default_form():
     """`--total-cuts T` at N = 1 holds exactly the cuts of the default form (one generator stream), reports strong scaling, and its rate
     agrees with the weak form's (the same launch over the same data)."""
-    weak, _ = _bench("--steps", "20", "--cuts", "4000")
+    weak, _ = _bench("--steps", "20", "--cuts", "4000", "--no-other-configs")
     strong, _ = _bench("--steps", "20", "--total-cuts", "4000")
     assert strong["scaling"] == "strong" and weak["scaling"] == "weak"
     assert strong["config"]["cuts_per_gpu_per_step"] == weak["config"]["cuts_per_gpu_per_step"] == 4000
@@ -55,3 +58,21 @@ def test_the_other_configs_run_and_pass_their_in_run_parity(flags):
     res, err = _bench(*flags)
     assert res["parity"]["pass"] is True, (res["parity"], err[-1500:])
     assert res["config"]["name"] == flags[1] and res["value"] > 0 and res["roofline"]["frac"] > 0 and res["unit"] == "cuts/s"
+
+
+def test_the_default_line_carries_the_other_baseline_configs_and_both_regimes():
+    """The driver's form of the command (`--steps 20 --warmup 5`, default config): ONE line whose `extra.configs` holds BASELINE configs[3]
+    and [4] measured under the same contract with their own in-run parity, on-the-fly priced both ways (`frac` and `frac_end_to_end`),
+    and the after-idle regime next to the sustained `value` (VERDICT r4 tasks 2 and 6)."""
+    res, err = _bench("--steps", "20", "--warmup", "5")
+    cfgs = res["extra"]["configs"]
+    assert set(cfgs) == {"mfcc40_libri", "onthefly"}
+    for name, c in cfgs.items():
+        assert c["parity"]["pass_rel_l2"] is True and c["value"] > 0 and c["roofline"]["frac"] > 0 and c["steps"] > 0, (name, c)
+        assert c["ms_per_step"] * c["steps"] < 5000  # a few seconds of GPU together
+    otf = cfgs["onthefly"]["roofline"]
+    assert 0 < otf["frac_end_to_end"] < otf["frac"] and otf["algorithmic_bytes_end_to_end"] < otf["algorithmic_bytes_per_launch"]
+    ramp = res["extra"]["first_launches_after_idle_ms"]
+    assert len(ramp) == 10 and all(x > 0 for x in ramp)
+    assert 0.7 * res["value"] < res["extra"]["contract_only"]["value"] < 1.05 * res["value"]
+    assert res["parity"]["pass_rel_l2"] and res["parity"]["pass_linear"]

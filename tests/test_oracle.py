@@ -181,3 +181,43 @@ def test_torch_speed_baseline_equals_golden():
         for i, (kind, num, seed) in enumerate(inputs):
             y = sp(make_signal(kind, num, seed))
             assert y.shape == z[f"out{i}"].shape and np.abs(y - z[f"out{i}"]).max() <= 5e-6
+
+
+@pytest.mark.reference
+def test_torch_ref32_is_the_live_reference_bit_for_bit():
+    """`ref32` of the parity statements (oracle/kaldi_torch.reference_f32: bench.py's in-run leg, test_headline_parity_multi_seed, smoke())
+    IS the reference: array_equal to the live reference's Fbank / Mfcc(40, 40) / Speed outputs on 16 full-size cuts each (VERDICT r4 --
+    oracle/kaldi_ref.py's float32 mode is not: its FFT is numpy's float64 one)."""
+    import torch
+
+    from oracle.kaldi_torch import TorchSpeed, reference_f32
+    from oracle.make_golden import build, import_reference
+
+    mod = import_reference()
+    g = torch.Generator().manual_seed(0)
+    x = ((torch.rand(16, 160000, generator=g) * 2 - 1) * 0.5).numpy()
+    for kind, cfg in [("fbank", {}), ("mfcc", {"num_filters": 40, "num_ceps": 40})]:
+        ref = build(mod, kind, cfg)
+        mine = reference_f32(RefConfig(kind=kind, **cfg))
+        n64 = RefExtractor(RefConfig(kind=kind, **cfg), np.float64)
+        worst_np, worst_ref = 0.0, 0.0
+        for i in range(16):
+            n = 160000 if kind == "fbank" else 160000 - 1234 * i  # MFCC: ragged lengths, as in bench.py --config mfcc40_libri
+            want = ref.extract(x[i, :n], 16000)
+            got = mine.extract(x[i, :n])
+            assert got.dtype == np.float32 and np.array_equal(got, want), (kind, i, np.abs(got - want).max())
+            if kind == "fbank" and i < 4:
+                truth = n64.extract(x[i])
+                worst_ref = max(worst_ref, np.abs(want - truth).max())
+                worst_np = max(worst_np, np.abs(RefExtractor(RefConfig(kind=kind), np.float32).extract(x[i]) - truth).max())
+        if kind == "fbank":  # the point of the re-basing: the reference's own floor is well above the numpy oracle's
+            assert worst_ref > 1.5 * worst_np, (worst_ref, worst_np)
+    from lhotse.augmentation import Speed
+
+    for f in (0.9, 1.1):
+        sp, live = TorchSpeed(16000, f), Speed(factor=f)
+        for i in range(16):
+            n = 16000 + 9000 * i
+            want = live(x[i, :n][None], 16000)
+            want = want[0] if isinstance(want, tuple) else want
+            assert np.array_equal(sp(x[i, :n]), np.asarray(want).reshape(-1)), (f, i)

@@ -1,5 +1,5 @@
 """
-The multi-GPU product path on CPU: lhotse_amd.compute_and_store_features_sharded run by TWO spawned ranks (a real world_size-2 group over
+The multi-GPU product path on CPU: lhotse_amd.compute_and_store_features_sharded run by TWO (and EIGHT) spawned ranks (a real world_size-2 / -8 group over
 gloo, then again with nothing but RANK / WORLD_SIZE) under the real lhotse, with the oracle-backed stand-in for the device plan (no GPU
 here).  What must hold (reference: CutSet.compute_and_store_features(num_jobs=N), lhotse/cut/set.py:2141-2195 -- LazySlicer shards,
 per-job `feats-{i}` storage, combined manifests):
@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, workdir, first, balance, q):
+def _rank_main(rank, world, port, workdir, first, balance, q, sub="sharded"):
     """One rank: a fresh process, as under torchrun."""
     try:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), HIPFEAT_RUN_ID=f"test-{port}")
@@ -48,13 +48,13 @@ def _rank_main(rank, world, port, workdir, first, balance, q):
         cuts = CutSet.from_jsonl_lazy(work / "cuts.jsonl.gz")
         if first:
             cuts = cuts.subset(first=first)
-        out = LA.compute_and_store_features_sharded(cuts, LA.HipFbank(), storage_path=work / "sharded", manifest_path=work / "sharded" / "cuts.jsonl.gz",
+        out = LA.compute_and_store_features_sharded(cuts, LA.HipFbank(), storage_path=work / sub, manifest_path=work / sub / "cuts.jsonl.gz",
                                                     batch_duration=3.0, num_workers=0, balance=balance, barrier_timeout=120.0)
         import torch.distributed as dist
 
         assert not dist.is_initialized()  # the group the driver created for its barrier is gone again
         # a second call in the same processes (everything is in the manifests already): the rendezvous must come up again
-        again = LA.compute_and_store_features_sharded(cuts, LA.HipFbank(), storage_path=work / "sharded", manifest_path=work / "sharded" / "cuts.jsonl.gz",
+        again = LA.compute_and_store_features_sharded(cuts, LA.HipFbank(), storage_path=work / sub, manifest_path=work / sub / "cuts.jsonl.gz",
                                                       batch_duration=3.0, num_workers=0, balance=balance, barrier_timeout=120.0)
         assert [c.id for c in again] == [c.id for c in out] and not dist.is_initialized()
         q.put((rank, [c.id for c in out], dict(LA.storage.TEMPLATE_STATS), None))
@@ -65,11 +65,11 @@ def _rank_main(rank, world, port, workdir, first, balance, q):
         raise
 
 
-def _run_ranks(workdir, world=2, first=0, balance="round_robin", group=True):
+def _run_ranks(workdir, world=2, first=0, balance="round_robin", group=True, sub="sharded"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port() if group else 0
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, str(workdir), first, balance, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, str(workdir), first, balance, q, sub)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -108,14 +108,14 @@ def world(tmp_path_factory):
         set_current_audio_backend(prev_backend)
 
 
-def _check_combined(work, single, sub="sharded"):
+def _check_combined(work, single, sub="sharded", ranks=2):
     from lhotse import CutSet
 
     combined = list(CutSet.from_file(work / sub / "cuts.jsonl.gz"))
     assert [c.id for c in combined] == [c.id for c in single]
     for a, b in zip(combined, single):
         da, db = a.to_dict(), b.to_dict()
-        assert da["features"]["storage_path"].endswith(f"feats-{int(a.id[3:]) % 2}.hfa") or "duration" in sub
+        assert da["features"]["storage_path"].endswith(f"feats-{int(a.id[3:]) % ranks}.hfa") or "duration" in sub
         for k in ("storage_path", "storage_key"):
             da["features"].pop(k), db["features"].pop(k)
         assert da == db
@@ -150,6 +150,23 @@ def test_two_ranks_equal_one_process_and_resume(world):
     _run_ranks(work)
     assert before == [os.path.getsize(work / "sharded" / f"feats-{r}.hfa") for r in range(2)]
     _check_combined(work, single)
+
+
+def test_eight_ranks_equal_one_process(world):
+    """The node's real shape: EIGHT ranks over gloo on the same 11-cut corpus -- ranks 0-2 own two cuts, ranks 3-7 one; the
+    combined manifest is still the single-process manifest cut for cut and feature for feature, every shard holds exactly its round-robin
+    share, and a second call in the same eight processes (everything already extracted) meets again and changes nothing."""
+    from lhotse import CutSet
+
+    work, single = world
+    res = _run_ranks(work, world=8, sub="sharded8")
+    assert res[0][0] == [c.id for c in single]
+    for r in range(8):
+        shard = list(CutSet.from_file(work / "sharded8" / f"cuts-{r}.jsonl.gz"))
+        assert [c.id for c in shard] == [f"cut{i}" for i in range(r, len(LENGTHS), 8)]
+        assert res[r][0] == [c.id for c in (single if r == 0 else shard)]
+        assert os.path.getsize(work / "sharded8" / f"feats-{r}.hfa") == sum(c.num_frames * 80 * 4 for c in shard)
+    _check_combined(work, single, sub="sharded8", ranks=8)
 
 
 def test_ranks_without_a_rendezvous_address_meet_through_marker_files(world, monkeypatch):

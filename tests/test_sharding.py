@@ -240,3 +240,72 @@ def test_bench_group_falls_back_to_gloo_under_the_launcher(mode, why):
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
     assert line and "world=2 sum=3.0" in line[0] and why in line[0], (out.stdout, out.stderr[-2000:])
+
+
+def _fake_sysfs(root, gpus, node_cpus):
+    """A miniature /sys: KFD topology (one CPU node + `gpus` GPU nodes at the given (domain, bus, dev, numa_node)), the PCI devices'
+    numa_node files and the nodes' cpulists."""
+    import os
+
+    def put(path, text):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+
+    put(f"{root}/class/kfd/kfd/topology/nodes/0/properties", "cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, (dom, bus, dev, node) in enumerate(gpus):
+        put(f"{root}/class/kfd/kfd/topology/nodes/{i + 1}/properties", f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {(bus << 8) | (dev << 3)}\ndomain {dom}\n")
+        put(f"{root}/bus/pci/devices/{dom:04x}:{bus:02x}:{dev:02x}.0/numa_node", f"{node}\n")
+    for node, text in node_cpus.items():
+        put(f"{root}/devices/system/node/node{node}/cpulist", text + "\n")
+
+
+def test_numa_binding_reads_the_topology_and_never_widens(tmp_path, monkeypatch):
+    """bind_to_gpu_numa_node on a fake /sys (no GPU here, so the PCI address comes from the KFD topology order): GPU k -> its PCI
+    device's numa_node -> that node's cpulist, intersected with the CPUs the process may already use; numa_node = -1, an unknown GPU
+    and the off switch are reported, not raised; a real application pins every thread of the process."""
+    import os
+    import threading
+
+    from lhotse_amd import sharding as S
+
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "HIPFEAT_NUMA_BIND"):
+        monkeypatch.delenv(k, raising=False)
+    allowed = sorted(os.sched_getaffinity(0))
+    lo = ",".join(str(c) for c in allowed[: max(1, len(allowed) // 2)])
+    root = str(tmp_path / "sys")
+    _fake_sysfs(root, [(0, 0x05, 0, 0), (0, 0x85, 0, 1), (1, 0xC5, 0, -1)], {0: lo + ",100000-100003", 1: "100000-100007"})
+    assert S._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and S._parse_cpulist("\n") == []
+    assert S._gpu_pci_address(1, root) == "0000:85:00.0" and S._gpu_pci_address(2, root) == "0001:c5:00.0" and S._gpu_pci_address(3, root) is None
+    dry = S.bind_to_gpu_numa_node(0, sysfs=root, apply=False)
+    assert dry["node"] == 0 and dry["pci"] == "0000:05:00.0" and dry["cpus"] == max(1, len(allowed) // 2) and not dry["bound"]
+    other = S.bind_to_gpu_numa_node(1, sysfs=root, apply=False)  # node 1's CPUs are not ours: nothing to bind to, and no widening
+    assert other["node"] == 1 and other["cpus"] == 0 and not other["bound"] and "no CPU" in other["why"]
+    none = S.bind_to_gpu_numa_node(2, sysfs=root)
+    assert none["node"] == -1 and not none["bound"] and "-1" in none["why"]
+    assert not S.bind_to_gpu_numa_node(7, sysfs=root)["bound"]
+    monkeypatch.setenv("HIPFEAT_NUMA_BIND", "0")
+    assert S.bind_to_gpu_numa_node(0, sysfs=root)["why"] == "HIPFEAT_NUMA_BIND=0"
+    monkeypatch.delenv("HIPFEAT_NUMA_BIND")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3")  # a masked index does not map onto the topology order
+    assert S._gpu_pci_address(0, root) is None
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # the real thing, on a second thread that exists already: both end up on node 0's CPUs; restored afterwards
+    seen, go, done = [], threading.Event(), threading.Event()
+
+    def worker():
+        go.wait(10)
+        seen.append(sorted(os.sched_getaffinity(0)))
+        done.set()
+
+    t = threading.Thread(target=worker)
+    t.start()
+    try:
+        got = S.bind_to_gpu_numa_node(0, sysfs=root)
+        assert got["bound"] and sorted(os.sched_getaffinity(0)) == allowed[: max(1, len(allowed) // 2)]
+        go.set()
+        assert done.wait(10) and seen[0] == allowed[: max(1, len(allowed) // 2)]
+    finally:
+        go.set()
+        t.join()
+        os.sched_setaffinity(0, allowed)

@@ -2,7 +2,8 @@
 """profiles/traffic.json from a PMC summary (tools/pmc_profile.sh -> summary.txt): HBM bytes per cut and VALU instructions per frame of the
 bench kernel, stamped with the sha256 of the kernel sources they were measured on (bench.py refuses the numbers once those files change).
 
-    python tools/make_traffic_json.py <summary.txt> <cuts per dispatch> [label of the summary file in profiles/] [power probe json line file]"""
+    python tools/make_traffic_json.py <summary.txt> <cuts per dispatch> [label of the summary file in profiles/] [power probe json line file]
+    python tools/make_traffic_json.py --config mfcc40_libri|onthefly <dir of tools/r5_traffic.sh>   (adds / replaces traffic.json["configs"][<name>])"""
 import json
 import os
 import re
@@ -19,7 +20,91 @@ spec.loader.exec_module(bench)
 SOURCES = ["lhotse_amd/csrc/kernel_fft512c.hpp", "lhotse_amd/csrc/mel4_schedule.hpp", "lhotse_amd/csrc/fft_common.hpp", "lhotse_amd/csrc/fft512_common.hpp"]
 
 
+CONFIG_SOURCES = {
+    "mfcc40_libri": SOURCES,
+    "onthefly": SOURCES + ["lhotse_amd/csrc/kernel_minibatch.hpp", "lhotse_amd/csrc/kernel_resample.hpp"],
+}
+
+
+def config_entry(name: str, root: str):
+    """One of the other BASELINE configs: counters summed over ALL dispatches of the run per kernel (the mini-batches of `onthefly` all
+    differ), divided by the passes over the workload the run made (= feature-kernel dispatches / feature launches per step), against the
+    algorithmic bytes bench.py printed for the same workload."""
+    import csv
+    import glob
+    from collections import defaultdict
+
+    tot = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        per = defaultdict(lambda: [0.0, set()])
+        for path in glob.glob(os.path.join(root, f"pass_{ctr}", "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    k = row.get("Kernel_Name", "")
+                    if "hipfeat" not in k or row["Counter_Name"] != ctr:
+                        continue
+                    k = k.split("(")[0].replace("void ", "").replace("hipfeat::", "")
+                    per[k][0] += float(row["Counter_Value"])
+                    per[k][1].add(int(row["Dispatch_Id"]))
+        tot[ctr] = {k: (v[0], len(v[1])) for k, v in per.items()}
+    line = None
+    for ln in open(os.path.join(root, "pass_FETCH_SIZE.log")):
+        if ln.startswith("{"):
+            line = json.loads(ln)
+    assert line is not None, "no bench line in pass_FETCH_SIZE.log"
+    roof = line["roofline"]
+    algo = roof["algorithmic_bytes_per_launch"]
+    parts = roof.get("algorithmic_bytes_parts") or {"feature_launches_per_step": 1}
+    feat = [k for k in tot["FETCH_SIZE"] if k.startswith("fft512c_kernel")]
+    assert len(feat) == 1, sorted(tot["FETCH_SIZE"])
+    steps = tot["FETCH_SIZE"][feat[0]][1] / parts["feature_launches_per_step"]
+    per_kernel, hbm = {}, 0.0
+    for k in sorted(tot["FETCH_SIZE"]):
+        fetch = tot["FETCH_SIZE"][k][0] * 1024 * 2 / steps  # KiB x 1024 x 2: the guide's gfx950 correction for wide coalesced reads
+        write = tot["WRITE_SIZE"].get(k, (0.0, 0))[0] * 1024 / steps
+        hbm += fetch + write
+        per_kernel[k] = {"fetch_bytes_per_step": round(fetch), "write_bytes_per_step": round(write), "dispatches_per_step": round(tot["FETCH_SIZE"][k][1] / steps, 2)}
+    for k, v in per_kernel.items():  # against the kernel's own algorithmic bytes
+        if k.startswith("fft512c_kernel"):
+            v["algorithmic_read"], v["algorithmic_write"] = parts.get("feature_read", None), parts.get("feature_write", None)
+        elif "minibatch_prep" in k:
+            v["algorithmic_read"], v["algorithmic_write"] = parts.get("resampler_read"), parts.get("resampler_write")
+    entry = {
+        "kernel": feat[0].split(",")[0] + ">" if "," in feat[0] else feat[0],
+        "device_symbols": sorted(tot["FETCH_SIZE"]),
+        "hbm_bytes_per_algorithmic_byte": round(hbm / algo, 4),
+        "hbm_bytes_per_step": round(hbm),
+        "algorithmic_bytes_per_step": algo,
+        "steps_profiled": steps,
+        "per_kernel": per_kernel,
+        "source": f"tools/r5_traffic.sh ({root}): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `bench.py --config {name} --steps 2 --warmup 1`, "
+                  "counters summed over all dispatches per kernel / passes over the workload",
+        "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 under-count of 16 B/lane coalesced reads, MI355X_MICROARCH.md HBM section; the resampler's reads are "
+                       "4 B/lane strided gathers for which the factor is uncalibrated -- its fetch figure is an upper bound); WRITE_SIZE KiB x 1024",
+        "workload": line["config"]["workload"],
+        "source_files": CONFIG_SOURCES[name],
+        "source_sha256_16": bench.kernel_source_hash(CONFIG_SOURCES[name]),
+    }
+    if name == "onthefly":
+        entry["infinity_cache_note"] = ("FETCH_SIZE / WRITE_SIZE count the L2's memory-side requests (TCC_EA0_RDREQ / WRREQ): traffic that the 256 MiB Infinity Cache "
+                                        "absorbs behind the L2 is still counted, so these counters show that the perturbed tail LEAVES THE L2 (the feature launch fetches "
+                                        "its whole input from the memory side), not whether it reaches HBM; the mini-batch's 25 MB tail fits the Infinity Cache, and no "
+                                        "counter of this rocprofv3 separates MALL hits")
+    return entry
+
+
 def main():
+    if sys.argv[1] == "--config":
+        name, root = sys.argv[2], sys.argv[3]
+        entry = config_entry(name, root)
+        path = os.path.join(ROOT, "profiles", "traffic.json")
+        with open(path) as f:
+            t = json.load(f)
+        t.setdefault("configs", {})[name] = entry
+        with open(path, "w") as f:
+            json.dump(t, f, indent=1)
+        print(json.dumps(entry, indent=1))
+        return
     path, cuts = sys.argv[1], int(sys.argv[2])
     label = sys.argv[3] if len(sys.argv) > 3 else path
     vals, kernel = {}, None
@@ -55,6 +140,13 @@ def main():
         out["sclk_MHz_under_load"] = probe["sclk_MHz_median"]
         out["package_power_W_under_load"] = probe["package_power_W_median"]
         out["power_probe"] = sys.argv[4]
+    try:  # the entries of the other configs survive a refresh of the headline entry
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            keep = json.load(f).get("configs")
+        if keep:
+            out["configs"] = keep
+    except Exception:
+        pass
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
