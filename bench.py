@@ -492,8 +492,9 @@ class OnTheFly:
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.nstreams)] if self.nstreams > 1 else []
         self.route = getattr(args, "route", "pair")
         self.step()  # sizes of the perturbed batch (for the byte count) and the first outputs
-        in_samples = out_samples = frames = audio_in = all_out = 0
+        in_samples = out_samples = frames = audio_in = all_out = pad_rows = 0
         for bt, (f, fl, po, pl) in zip(self.batches, self.feats):
+            pad_rows += sum(int(t.shape[0] * t.shape[1]) for t in (f if isinstance(f, list) else [f])) - int(fl.sum())
             pert = bt["fac"] != 1.0
             in_samples += int(bt["lens"][pert].sum())
             out_samples += int(pl[pert].sum())
@@ -507,6 +508,9 @@ class OnTheFly:
         # are this implementation's intermediate, not algorithmic traffic) -- roofline.frac_end_to_end
         self.algo_bytes_end_to_end = 4 * audio_in + 4 * NUM_MELS * frames
         self.algo_parts = {"resampler_read": 4 * in_samples, "resampler_write": 4 * out_samples, "feature_read": 4 * all_out, "feature_write": 4 * NUM_MELS * frames,
+                           # the LOG_EPSILON rows behind every cut of the padded (B, Tmax, 80) tensors: written by the prep launch; part of what the
+                           # API returns, NOT counted in `algorithmic_bytes` (the conservative reading: features once)
+                           "padding_rows_write_not_in_algorithmic_bytes": 4 * NUM_MELS * pad_rows,
                            "feature_launches_per_step": len(self.batches)}
         self.kernel = self.plan.kernel_name + " + minibatch_prep_" + ("inline_" if K == 1 else "") + "kernel (mixed-factor resample_fast_block + padding rows + descriptor tables)"
         self.workload = (f"BASELINE configs[4]: {NB} mini-batches of 600 s per GPU per step ({ncuts} cuts U(1,30) s, {self.audio_seconds:.0f} s of audio), "
