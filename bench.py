@@ -655,16 +655,18 @@ class OnTheFly:
 
 class BulkSave:
     """The offline path end to end on the GPU box (SURVEY 8d timing method iii; lhotse/cut/set.py:2307-2404): 600 s batches of HOST
-    waveforms -> the H2D / kernel / D2H pipeline (`_batch_features_on_host`) on the calling thread -> ONE background thread:
-    `write_packed` into the flat archive on tmpfs + one template manifest line per cut (gzip JSONL, flushed per batch), with the
-    back-pressure of `storage.pump_batches` -- the loop `compute_and_store_features_batch` runs, minus lhotse's loader and objects
-    (lhotse cannot travel to the GPU box; the manifest half is tested against the reference driver in tests/test_lhotse_dropin.py).
-    PCIe-, host- and file-system-inclusive: NOT a device-resident rate (the default config is)."""
+    waveforms + the halves of every cut's manifest line (what the loader's worker processes hand over: `storage.manifest_fragments`)
+    -> the H2D / kernel / D2H pipeline (`_batch_features_on_host`) on the calling thread -> background thread 1: the batch appended to
+    the flat archive on tmpfs (libhipfeat's hipfeat_archive_append, striped over `--stripes` files) -> background thread 2: the batch's
+    manifest lines spliced in libhipfeat (hipfeat_manifest_lines, which also enforces validate_features' frame-count contract), gzip,
+    write, flush -- with the back-pressure of `storage.pump_batches`: the loop `compute_and_store_features_batch` runs, minus lhotse's
+    loader and objects (lhotse cannot travel to the GPU box; the manifest half is tested against the reference driver, byte for byte
+    against the per-cut path, in tests/test_lhotse_dropin.py).  PCIe-, host- and file-system-inclusive: NOT a device-resident rate."""
 
     name = "bulk_save"
     host_bound = True
     metric = "cuts/sec (10 s @16 kHz host waveforms -> 80-dim log-mel fbank -> hip_archive on tmpfs + manifests; PCIe- and host-inclusive)"
-    default_cuts = 32  # batches of 60 cuts (600 s) per step
+    default_cuts = 64  # batches of 60 cuts (600 s) per step
     cpu_mode, cpu_what = "", "Fbank"
 
     def __init__(self, dev, rank, args):
@@ -679,6 +681,7 @@ class BulkSave:
 
         self.torch, self.np, self.S, self.dev, self.rank = torch, np, S, dev, rank
         NB = self.NB = args.cuts or self.default_cuts
+        self.stripes = max(1, int(getattr(args, "stripes", 1) or 1))
         self.ex = lhotse_amd.HipFbank(lhotse_amd.HipFbankConfig(device=f"cuda:{dev.index}"))
         self.plan = self.ex.plan
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
@@ -722,81 +725,112 @@ class BulkSave:
         pool = [(torch.rand(SAMPLES_PER_CUT, generator=g) - 0.5) for _ in range(64)]  # pageable float32, as a DataLoader hands them over
         self.pool16 = [(x * 32767).to(torch.int16) for x in pool]
         self.pool32 = pool
-        self.batches = []
+        self.cut_batches = []
         n = 0
         for b in range(NB):
             cuts = []
             for i in range(60):
                 c = Cut()
-                c.id, c.start, c.duration, c.channel, c.recording_id, c.sampling_rate = f"cut-{rank}-{n:07d}", 0.0, 10.0, 0, f"rec-{rank}-{n:07d}", SR
-                c.supervisions = [Sup(id=c.id, recording_id=c.recording_id, start=0.0, duration=10.0, text="SYNTHETIC UTTERANCE " * 4, language="English", speaker=f"spk{n % 251}")]
+                c.id, c.start, c.duration, c.channel, c.recording_id, c.sampling_rate = f"cut-{rank}-{n:07d}", 0.0, SAMPLES_PER_CUT / SR, 0, f"rec-{rank}-{n:07d}", SR
+                c.supervisions = [Sup(id=c.id, recording_id=c.recording_id, start=0.0, duration=c.duration, text="SYNTHETIC UTTERANCE " * 4, language="English", speaker=f"spk{n % 251}")]
                 c.custom = {"dataloading_info": {"rank": 0, "world_size": 1, "worker_id": None}}  # what lhotse's sampler attaches (sampling/base.py:473-487)
                 c.recording = Rec(id=c.recording_id, sources=[Src("file", [0], f"/data/corpus/{c.recording_id}.flac")], sampling_rate=SR,
-                                  num_samples=SAMPLES_PER_CUT, duration=10.0, channel_ids=[0])
+                                  num_samples=SAMPLES_PER_CUT, duration=c.duration, channel_ids=[0])
                 cuts.append(c)
                 n += 1
-            self.batches.append((cuts, [(b * 60 + i) % 64 for i in range(60)]))
+            self.cut_batches.append((cuts, [(b * 60 + i) % 64 for i in range(60)]))
+        # the loader's side of the manifests: the two halves of every cut's line (in the product they are made in the DataLoader's worker
+        # processes, next to audio decoding; here once, like the waveforms -- `fragments_per_s_per_process` in `extra` says what one costs)
+        self.template = {"type": self.ex.name, "num_features": NUM_MELS, "frame_shift": self.ex.frame_shift, "sampling_rate": SR, "storage_type": "hip_archive",
+                         "storage_path": ""}
+        rc = {}
+        t0 = time.perf_counter()
+        self.batches = [(cuts, idx, [S.manifest_fragments(c, self.template, self.ex.frame_shift, rc) for c in cuts]) for cuts, idx in self.cut_batches]
+        self.fragments_per_s = n / (time.perf_counter() - t0)
+        assert all(f is not None for _, _, fr in self.batches for f in fr)
         self.units = n
-        self.audio_seconds = 10.0 * n
+        self.audio_seconds = SAMPLES_PER_CUT / SR * n
         self.algo_bytes = ALGO_BYTES_PER_CUT * n
         self.kernel = self.plan.kernel_name
         self.stats = {}
-        self.variant = ("float32", "hip_archive")
+        self.variant = ("float32", "hip_archive", "native")
         self.workload = (f"SURVEY 8d(iii) offline path: {NB} batches of 60 x 10 s (600 s) pageable float32 host waveforms per GPU per step -> chunked H2D / "
-                         f"fft512c / D2H pipeline -> background thread 1: write_packed into a 'hip_archive' on {self.fs} -> background thread 2: one template "
-                         "MonoCut manifest line per cut (gzip JSONL, flush per batch); back-pressure of 8 batches -- compute_and_store_features_batch's loop without lhotse's loader")
+                         f"fft512c / D2H pipeline -> background thread 1: hipfeat_archive_append into a 'hip_archive' of {self.stripes} file(s) on {self.fs} -> "
+                         "background thread 2: hipfeat_manifest_lines (key splice + frame-count contract) + gzip JSONL + flush per batch; back-pressure of 8 batches "
+                         "-- compute_and_store_features_batch's loop without lhotse's loader (which hands over waveforms AND line halves)")
         self._run_id = 0
 
-    def _one_pass(self, dtype: str, storage: str, stats: dict):
+    def _one_pass(self, dtype: str, storage: str, stats: dict, route: str = "native"):
+        """One pass over the batches.  route "native": NativeArchive + spliced lines (the product's path for the hip_archive storages);
+        "per_cut": round 4's path -- write_packed by Python + one template dict + json.dumps per cut -- kept for the A/B."""
         import gzip
         import json
-        import time
 
-        S = self.S
-        wcls = S.HipArchiveF16Writer if storage == "hip_archive_f16" else S.HipArchiveWriter
-        half = getattr(wcls, "np_dtype", "<f4") == "<f2"
+        S, np = self.S, self.np
+        half = storage == "hip_archive_f16"
         pool = self.pool16 if dtype == "int16" else self.pool32
         self._run_id += 1
         root = os.path.join(self.tmp.name, f"run{self._run_id}")
         os.makedirs(root)
-        rec_cache = {}
-        frame_shift = self.ex.frame_shift
-        save_busy = [0.0, 0, 0, 0.0]  # archive-thread seconds, archive bytes, manifest lines, manifest-thread seconds
+        busy = {"save": 0.0, "lines": 0.0, "n": 0}
+        ex = self.ex
 
-        with wcls(os.path.join(root, "feats"), mode="w") as writer, gzip.open(os.path.join(root, "cuts.jsonl.gz"), "wt") as manifest:
-            template = {"type": self.ex.name, "num_features": NUM_MELS, "frame_shift": frame_shift, "sampling_rate": SR,
-                        "storage_type": writer.name, "storage_path": str(writer.storage_path)}
+        def extract(batch):
+            cuts, idx, frags = batch
+            host, frames = S._batch_features_on_host(ex, [pool[i] for i in idx], SR, None, half=half)
+            return cuts, frags, host, frames
 
-            def extract(batch):
-                cuts, idx = batch
-                host, frames = S._batch_features_on_host(self.ex, [pool[i] for i in idx], SR, None, half=half)
-                return cuts, host, frames
+        with gzip.open(os.path.join(root, "cuts.jsonl.gz"), "wb") as manifest:
+            if route == "native":
+                with S.NativeArchive(os.path.join(root, "feats"), mode="w", np_dtype="<f2" if half else "<f4", stripes=self.stripes, name=storage) as ar:
 
-            def save(cuts, host, frames):  # background thread 1: the frame-count contract and the archive
-                t0 = time.perf_counter()
-                for c, t in zip(cuts, frames):  # the frame-count contract of validate_features (lhotse/qa.py:286-301)
-                    if (int(round(c.duration * SR)) + 80) // 160 != t:
-                        raise AssertionError(f"cut {c.id}: {t} frames")
-                keys = writer.write_packed(host, frames)
-                writer.flush()
-                save_busy[0] += time.perf_counter() - t0
-                save_busy[1] = os.path.getsize(writer.storage_path)  # (flushed above)
-                return cuts, frames, keys
+                    def save(cuts, frags, host, frames):
+                        t0 = time.perf_counter()
+                        fr = np.ascontiguousarray(frames, dtype=np.int64)
+                        file_of, byte_off = ar.append(host, fr)
+                        busy["save"] += time.perf_counter() - t0
+                        return frags, fr, file_of, byte_off
 
-            def write_manifests(cuts, frames, keys):  # background thread 2: one template manifest line per cut
-                t0 = time.perf_counter()
-                for c, t, k in zip(cuts, frames, keys):
-                    d = S._mono_cut_dict(c, S._features_dict(template, c, t, k), rec_cache)
-                    manifest.write(json.dumps(d) + "\n")
-                manifest.flush()
-                save_busy[3] += time.perf_counter() - t0
-                save_busy[2] += len(cuts)
+                    def lines(frags, fr, file_of, byte_off):
+                        t0 = time.perf_counter()
+                        blob = ar.lines([f[0] for f in frags], [f[1] for f in frags], fr, np.fromiter((f[2] for f in frags), dtype=np.int64, count=len(frags)),
+                                        file_of, byte_off, NUM_MELS)
+                        manifest.write(blob)
+                        manifest.flush()
+                        busy["lines"] += time.perf_counter() - t0
+                        busy["n"] += len(frags)
 
-            S.pump_batches(self.batches, extract, save, stats=stats, finish=write_manifests)
-        stats["manifest_s"] = stats.get("manifest_s", 0.0) + save_busy[3]
-        stats["save_s"] = stats.get("save_s", 0.0) + save_busy[0]
-        stats["archive_bytes"] = stats.get("archive_bytes", 0) + save_busy[1]
-        stats["manifest_lines"] = stats.get("manifest_lines", 0) + save_busy[2]
+                    S.pump_batches(self.batches, extract, save, stats=stats, finish=lines)
+                    stats["archive_bytes"] = stats.get("archive_bytes", 0) + sum(ar.size(k) for k in range(self.stripes))
+            else:
+                wcls = S.HipArchiveF16Writer if half else S.HipArchiveWriter
+                rec_cache = {}
+                with wcls(os.path.join(root, "feats"), mode="w") as writer:
+                    template = dict(self.template, storage_type=writer.name, storage_path=str(writer.storage_path))
+
+                    def save(cuts, frags, host, frames):
+                        t0 = time.perf_counter()
+                        for c, t in zip(cuts, frames):  # the frame-count contract of validate_features (lhotse/qa.py:286-301)
+                            if S.expected_num_frames(c.duration, ex.frame_shift, SR) != t:
+                                raise AssertionError(f"cut {c.id}: {t} frames")
+                        keys = writer.write_packed(host, frames)
+                        writer.flush()
+                        busy["save"] += time.perf_counter() - t0
+                        return cuts, frames, keys
+
+                    def lines(cuts, frames, keys):
+                        t0 = time.perf_counter()
+                        for c, t, k in zip(cuts, frames, keys):
+                            manifest.write((json.dumps(S._mono_cut_dict(c, S._features_dict(template, c, t, k), rec_cache), ensure_ascii=False) + "\n").encode())
+                        manifest.flush()
+                        busy["lines"] += time.perf_counter() - t0
+                        busy["n"] += len(cuts)
+
+                    S.pump_batches(self.batches, extract, save, stats=stats, finish=lines)
+                    stats["archive_bytes"] = stats.get("archive_bytes", 0) + os.path.getsize(writer.storage_path)
+        stats["manifest_s"] = stats.get("manifest_s", 0.0) + busy["lines"]
+        stats["save_s"] = stats.get("save_s", 0.0) + busy["save"]
+        stats["manifest_lines"] = stats.get("manifest_lines", 0) + busy["n"]
         stats["manifest_bytes"] = stats.get("manifest_bytes", 0) + os.path.getsize(os.path.join(root, "cuts.jsonl.gz"))
         self.last_root = root
         return root
@@ -808,7 +842,7 @@ class BulkSave:
 
     def step(self):
         prev = getattr(self, "last_root", None)
-        self._one_pass(*self.variant, self.stats)
+        self._one_pass(self.variant[0], self.variant[1], self.stats, self.variant[2])
         if prev:
             self._drop(prev)
 
@@ -816,12 +850,11 @@ class BulkSave:
         self.stats.clear()
 
     def parity(self, rank):
-        """What the last timed pass stored, read back through the archive reader, against the oracle."""
+        """What the last timed pass stored, read back through the archive reader(s), against the oracle."""
         import gzip
         import json
 
         from oracle.kaldi_ref import RefConfig, RefExtractor
-
         from oracle.kaldi_torch import reference_f32
 
         np, S = self.np, self.S
@@ -829,41 +862,47 @@ class BulkSave:
         with gzip.open(os.path.join(self.last_root, "cuts.jsonl.gz"), "rt") as f:
             lines = [json.loads(ln) for ln in f]
         assert len(lines) == self.units and [d["id"] for d in lines[:3]] == [c.id for c in self.batches[0][0][:3]]
-        reader = S.HipArchiveReader(lines[0]["features"]["storage_path"])
+        readers = {}
         rs = np.random.RandomState(4321 + rank)
         stats = []
-        flat = [i for _, idx in self.batches for i in idx]
+        flat = [i for _, idx, _ in self.batches for i in idx]
         for j in rs.choice(self.units, size=min(PARITY_CUTS, self.units), replace=False):
             d = lines[int(j)]
-            assert d["features"]["num_frames"] == FRAMES_PER_CUT and d["features"]["storage_type"] == "hip_archive"
+            assert d["features"]["num_frames"] == FRAMES_PER_CUT and d["features"]["storage_type"] == "hip_archive" and d["type"] == "MonoCut"
+            path = d["features"]["storage_path"]
+            reader = readers.get(path) or readers.setdefault(path, S.HipArchiveReader(path))
             got = reader.read(d["features"]["storage_key"])
             x = self.pool32[flat[int(j)]].numpy()
             stats.append(compare(got, o32.extract(x), o64.extract(x)))
         return fold(stats)
 
     def extra(self, args):
-        """The other entry forms / storages, one pass each, with the stage split of every variant."""
-        import time
-
+        """The other entry forms / storages and round 4's per-cut route, a few passes each, with the stage split of every variant."""
         out = {}
-        for dtype, storage in (("float32", "hip_archive"), ("int16", "hip_archive"), ("float32", "hip_archive_f16"), ("int16", "hip_archive_f16")):
-            self._drop(self._one_pass(dtype, storage, {}))  # warm
+        for dtype, storage, route in (("float32", "hip_archive", "native"), ("int16", "hip_archive", "native"), ("float32", "hip_archive_f16", "native"),
+                                      ("int16", "hip_archive_f16", "native"), ("float32", "hip_archive", "per_cut"), ("int16", "hip_archive_f16", "per_cut")):
+            self._drop(self._one_pass(dtype, storage, {}, route))  # warm
             st = {}
             t0 = time.perf_counter()
             for _ in range(3):
-                self._drop(self._one_pass(dtype, storage, st))
+                self._drop(self._one_pass(dtype, storage, st, route))
             dt = time.perf_counter() - t0
             cuts = 3 * self.units
-            out[f"{dtype}->{storage}"] = {
+            out[f"{dtype}->{storage}" + ("" if route == "native" else " (round 4's per-cut Python route)")] = {
                 "cuts_per_s": round(cuts / dt, 1), "archive_MB_per_s": round(st["archive_bytes"] / dt / 1e6, 1),
+                "h2d_MB_per_s": round(cuts * SAMPLES_PER_CUT * (2 if dtype == "int16" else 4) / dt / 1e6, 1),
                 "manifest_bytes_per_cut": round(st["manifest_bytes"] / cuts, 1),
                 "main_thread_extract_share": round(st["extract_s"] / dt, 3), "main_thread_blocked_share": round(st["wait_s"] / dt, 3),
                 "archive_thread_busy_share": round(st["save_s"] / dt, 3), "manifest_thread_busy_share": round(st["manifest_s"] / dt, 3),
-                "binds": max((st["extract_s"], "extraction (pack to pinned + PCIe pipeline, calling thread)"), (st["save_s"], "archive thread (write_packed)"),
-                             (st["manifest_s"], "manifest thread (template dicts + json + gzip)"))[1],
+                "binds": max((st["extract_s"], "extraction (pack to pinned + PCIe pipeline, calling thread)"), (st["save_s"], "archive thread"),
+                             (st["manifest_s"], "manifest thread"))[1],
             }
+        out["fragments_per_s_per_process"] = round(self.fragments_per_s, 1)
+        out["stripes"] = self.stripes
         out["what"] = ("3 passes per variant after one warm-up; shares are of wall time: the calling thread extracts (pack to pinned + H2D + kernel + D2H), "
-                       "one background thread writes the archive, a second one the manifest lines (storage.pump_batches); the largest share binds")
+                       "one background thread appends to the archive, a second one writes the manifest lines (storage.pump_batches); the largest share binds; "
+                       "fragments_per_s_per_process = manifest line halves one (loader) process serialises per second -- that work rides on the loader's workers, "
+                       "next to audio decoding, not on this process")
         return {"bulk_save": out}
 
     def close(self):
@@ -1259,6 +1298,7 @@ def main():
     ap.add_argument("--prefetch", type=int, default=1, help="onthefly: mini-batches per call (a loader that prefetches K packs them into one arena and gets K dense tensors "
                     "from ONE pair of launches); default 1")
     ap.add_argument("--streams", type=int, default=3, help="onthefly: streams the calls alternate over (default 3)")
+    ap.add_argument("--stripes", type=int, default=1, help="bulk_save: files the archive is striped over (one writer thread each)")
     ap.add_argument("--route", default="pair", choices=["pair", "per_factor"], help="onthefly: `pair` = the two-launch mini-batch (default), `per_factor` = round 3's route")
     ap.add_argument("--total-cuts", type=int, default=0, help="fbank16k only: STRONG scaling (BASELINE configs[2]: 100000): this many cuts in total per step, "
                     "sharded round-robin over the ranks (same global corpus for every N); default 0 = weak scaling, --cuts per GPU")

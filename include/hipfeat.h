@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HIPFEAT_ABI_VERSION 3
+#define HIPFEAT_ABI_VERSION 4
 
 #if defined(HIPFEAT_BUILD)
 #define HIPFEAT_API __attribute__((visibility("default")))
@@ -292,6 +292,38 @@ HIPFEAT_API hipfeat_status hipfeat_minibatch_plan(hipfeat_speed_bank* bank, cons
                                                   int64_t* h_group_rows, int64_t* h_info);
 HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* bank, int64_t ticket, float* d_arena, int64_t arena_floats, float* d_out,
                                                  int64_t rows_per_cut, float pad_value, void* stream);
+
+/* ---- bulk save path: the per-batch host work of the offline driver ------------------------------- */
+/*
+ * What lhotse's _save_worker does per CUT in the interpreter behind compute_and_store_features_batch (lhotse/cut/set.py:2307-2363:
+ * FeaturesWriter.write of one matrix -- lhotse/features/io.py:499-525 --, a Features object, validate_features, fastcopy(cut),
+ * to_dict, json) is done per BATCH here, in plain host code that runs with the GIL released; no device is touched.
+ *
+ * hipfeat_archive_*: an append-only archive of feature rows striped over num_files flat files (1 = the single-file "hip_archive" of
+ * lhotse_amd/storage.py).  hipfeat_archive_append writes the packed (sum h_num_frames, cols) matrix of one batch exactly as it left the
+ * device (float32: bytes_per_value 4; binary16: 2): the batch is cut into num_files consecutive runs of whole cuts of about equal
+ * bytes, run k is appended to file k by its own thread (writers to different files do not share an inode's page-cache locks);
+ * h_file[b] / h_byte_offset[b] say where the rows of cut b begin.  The storage key of a cut is "<byte offset>:<rows>:<cols>[:f16]".
+ *
+ * hipfeat_manifest_lines: the JSONL lines of one batch.  Line b = head_b + mid[h_file[b]] + key_b + tail_b + "\n", where head_b / tail_b
+ * are the two halves of the cut's own serialisation up to / from the storage fields (made by the caller where the cut was loaded --
+ * lhotse's loader workers -- because they do not depend on the extraction), mid[k] = `<JSON-escaped path of file k>", "storage_key": "`
+ * and key_b the key above.  heads / tails / mids are concatenated byte strings with (n + 1) int64 offsets each.  h_expected_frames
+ * (optional; entries < 0 are skipped) is the frame count each manifest half states: a mismatch with h_num_frames is the frame-count
+ * contract validate_features asserts (lhotse/qa.py:286-301) and fails the call before anything is written.  h_out needs
+ * sum(len(head_b) + len(tail_b) + longest mid + 65) bytes; on "too small" *h_out_bytes holds that number.
+ */
+typedef struct hipfeat_archive hipfeat_archive;
+HIPFEAT_API hipfeat_status hipfeat_archive_open(const char* const* h_paths, int32_t num_files, int32_t append, hipfeat_archive** archive);
+HIPFEAT_API hipfeat_status hipfeat_archive_append(hipfeat_archive* archive, const void* h_matrix, int64_t batch, const int64_t* h_num_frames,
+                                                  int32_t cols, int32_t bytes_per_value, int32_t* h_file, int64_t* h_byte_offset);
+HIPFEAT_API int64_t hipfeat_archive_size(const hipfeat_archive* archive, int32_t file); /* bytes in file `file`, -1 if out of range */
+HIPFEAT_API hipfeat_status hipfeat_archive_close(hipfeat_archive* archive);
+HIPFEAT_API hipfeat_status hipfeat_manifest_lines(const char* h_heads, const int64_t* h_head_offsets, const char* h_tails,
+                                                  const int64_t* h_tail_offsets, int64_t batch, const int64_t* h_num_frames,
+                                                  const int64_t* h_expected_frames, const char* h_mids, const int64_t* h_mid_offsets,
+                                                  int32_t num_files, const int32_t* h_file, const int64_t* h_byte_offset, int32_t cols,
+                                                  int32_t bytes_per_value, char* h_out, int64_t out_capacity, int64_t* h_out_bytes);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import build as _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (return C type, [argument C types]) ; mirrors include/hipfeat.h one to one.
 _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
@@ -75,6 +75,15 @@ _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
          "int64_t", "const int64_t*", "int64_t*", "int64_t*", "int64_t*", "int64_t*", "int64_t*"],
     ),
     "hipfeat_minibatch_run": ("int", ["hipfeat_speed_bank*", "int64_t", "float*", "int64_t", "float*", "int64_t", "float", "void*"]),
+    "hipfeat_archive_open": ("int", ["const char* const*", "int32_t", "int32_t", "hipfeat_archive**"]),
+    "hipfeat_archive_append": ("int", ["hipfeat_archive*", "const void*", "int64_t", "const int64_t*", "int32_t", "int32_t", "int32_t*", "int64_t*"]),
+    "hipfeat_archive_size": ("int64_t", ["const hipfeat_archive*", "int32_t"]),
+    "hipfeat_archive_close": ("int", ["hipfeat_archive*"]),
+    "hipfeat_manifest_lines": (
+        "int",
+        ["const char*", "const int64_t*", "const char*", "const int64_t*", "int64_t", "const int64_t*", "const int64_t*", "const char*", "const int64_t*",
+         "int32_t", "const int32_t*", "const int64_t*", "int32_t", "int32_t", "char*", "int64_t", "int64_t*"],
+    ),
     "hipfeat_extract_host": (
         "int",
         ["const hipfeat_plan*", "const float*", "int64_t", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "int64_t", "const int64_t*", "int64_t", "void*"],

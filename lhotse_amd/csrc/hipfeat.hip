@@ -31,6 +31,7 @@
 #include "kernel_fft256.hpp"
 #include "kernel_fft256c.hpp"
 #include "kernel_wave.hpp"
+#include "host_bulk.hpp"
 
 using namespace hipfeat;
 
@@ -2841,6 +2842,83 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_minibatch_run(hipfeat_speed_bank* 
   hipError_t e2 = hipEventRecord(s.ev, st);
   s.busy = (e2 == hipSuccess);
   return rc;
+}
+
+// ---- bulk save path: per-batch host work of the offline driver (host_bulk.hpp) -------------------------------------------------
+struct hipfeat_archive {
+  hipfeat::ArchiveFiles files;
+  std::mutex mu;
+};
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_archive_open(const char* const* h_paths, int32_t num_files, int32_t append, hipfeat_archive** out) {
+  if (!out) return fail(HIPFEAT_ERR_INVALID, "archive pointer is NULL");
+  *out = nullptr;
+  if (!h_paths || num_files < 1 || num_files > 64) return fail(HIPFEAT_ERR_INVALID, "an archive has 1 ... 64 files");
+  hipfeat_archive* a = new (std::nothrow) hipfeat_archive();
+  if (!a) return fail(HIPFEAT_ERR_INVALID, "out of host memory");
+  for (int32_t k = 0; k < num_files; ++k) {
+    const int fd = h_paths[k] ? ::open(h_paths[k], O_CREAT | O_WRONLY | O_CLOEXEC | (append ? 0 : O_TRUNC), 0644) : -1;
+    const off_t end = fd >= 0 ? ::lseek(fd, 0, SEEK_END) : (off_t)-1;
+    if (fd < 0 || end < 0) {
+      const int e = errno;
+      if (fd >= 0) ::close(fd);
+      for (int f : a->files.fds) ::close(f);
+      delete a;
+      return fail(HIPFEAT_ERR_INVALID, "cannot open archive file %d (%s): %s", k, h_paths[k] ? h_paths[k] : "NULL", strerror(e));
+    }
+    a->files.fds.push_back(fd);
+    a->files.size.push_back((int64_t)end);
+  }
+  *out = a;
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_archive_append(hipfeat_archive* a, const void* h_matrix, int64_t batch, const int64_t* h_num_frames,
+                                                             int32_t cols, int32_t bytes_per_value, int32_t* h_file, int64_t* h_byte_offset) {
+  if (!a || !h_num_frames || (batch > 0 && !h_matrix) || batch < 0) return fail(HIPFEAT_ERR_INVALID, "NULL argument");
+  if (cols <= 0 || (bytes_per_value != 2 && bytes_per_value != 4)) return fail(HIPFEAT_ERR_INVALID, "rows are %d values of %d bytes: need cols > 0 and 2- or 4-byte values", cols, bytes_per_value);
+  for (int64_t i = 0; i < batch; ++i)
+    if (h_num_frames[i] < 0) return fail(HIPFEAT_ERR_INVALID, "cut %lld: %lld frames", (long long)i, (long long)h_num_frames[i]);
+  std::lock_guard<std::mutex> lk(a->mu);
+  int errfile = 0;
+  const int e = a->files.append(static_cast<const char*>(h_matrix), batch, h_num_frames, (int64_t)cols * bytes_per_value, h_file, h_byte_offset, &errfile);
+  if (e) return fail(HIPFEAT_ERR_INVALID, "write to archive file %d failed: %s", errfile, strerror(e));
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API int64_t hipfeat_archive_size(const hipfeat_archive* a, int32_t file) {
+  return (a && file >= 0 && file < (int32_t)a->files.size.size()) ? a->files.size[(size_t)file] : -1;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_archive_close(hipfeat_archive* a) {
+  if (!a) return HIPFEAT_OK;
+  int bad = 0;
+  for (int fd : a->files.fds)
+    if (::close(fd) != 0) bad = errno;
+  delete a;
+  return bad ? fail(HIPFEAT_ERR_INVALID, "closing an archive file failed: %s", strerror(bad)) : HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_manifest_lines(const char* h_heads, const int64_t* h_head_offsets, const char* h_tails,
+                                                             const int64_t* h_tail_offsets, int64_t batch, const int64_t* h_num_frames,
+                                                             const int64_t* h_expected_frames, const char* h_mids, const int64_t* h_mid_offsets,
+                                                             int32_t num_files, const int32_t* h_file, const int64_t* h_byte_offset, int32_t cols,
+                                                             int32_t bytes_per_value, char* h_out, int64_t out_capacity, int64_t* h_out_bytes) {
+  if (!h_heads || !h_head_offsets || !h_tails || !h_tail_offsets || !h_num_frames || !h_mids || !h_mid_offsets || !h_byte_offset || !h_out || !h_out_bytes)
+    return fail(HIPFEAT_ERR_INVALID, "NULL argument");
+  if (batch < 0 || num_files < 1 || cols <= 0 || (bytes_per_value != 2 && bytes_per_value != 4)) return fail(HIPFEAT_ERR_INVALID, "bad batch / file / row arguments");
+  hipfeat::BulkError err;
+  const int64_t n = hipfeat::manifest_lines(h_heads, h_head_offsets, h_tails, h_tail_offsets, batch, h_num_frames, h_expected_frames, h_mids, h_mid_offsets,
+                                            num_files, h_file, h_byte_offset, cols, bytes_per_value, h_out, out_capacity, &err);
+  if (n < 0) {
+    *h_out_bytes = err.index < 0 ? err.a : 0;
+    if (err.index >= 0 && err.what[0] == 'f' && err.what[1] == 'r')
+      return fail(HIPFEAT_ERR_INVALID, "cut %lld of the batch: %lld frames extracted, its manifest states %lld (the frame-count contract of validate_features)",
+                  (long long)err.index, (long long)err.a, (long long)err.b);
+    return fail(HIPFEAT_ERR_INVALID, "%s (cut %lld: %lld vs %lld)", err.what, (long long)err.index, (long long)err.a, (long long)err.b);
+  }
+  *h_out_bytes = n;
+  return HIPFEAT_OK;
 }
 
 #ifdef HIPFEAT_PHASE_TIMERS

@@ -261,6 +261,178 @@ def _plain_copy(v):
 # which attaches a `dataloading_info` custom field to every cut: lhotse/dataset/sampling/base.py:473-487)
 TEMPLATE_STATS = {"template": 0, "fallback": 0}
 _REC_CACHE_MAX = 4096
+# ---- manifest lines without the interpreter (round 5) --------------------------------------------------------------------------
+# A cut's manifest line depends on the extraction in ONE place: where its rows are (storage_path / storage_key).  Everything else --
+# ids, supervisions, the recording, custom fields, and also the Features fields num_frames / start / duration, which are functions of
+# the cut -- is known where the cut is LOADED.  So the line is serialised there (lhotse's loader workers: other processes, other GILs),
+# cut in two around the storage fields, and the save path only splices the key in: libhipfeat's hipfeat_manifest_lines, one call per
+# batch with the GIL released, which also enforces the frame-count contract of validate_features (lhotse/qa.py:286-301) on the
+# extractor's actual frame counts.  Per batch the main process then runs a handful of C calls (archive append, line splice, zlib,
+# write) and no per-cut Python at all -- the per-cut Python of three threads sharing one GIL was what held the offline path at
+# 10-15 k cuts/s behind an extractor that sustains 50-120 k (profiles/r04_bulk_save.json).
+PATH_TOKEN = "@@HIPFEAT_STORAGE_PATH@@"
+KEY_TOKEN = "@@HIPFEAT_STORAGE_KEY@@"
+_SPLICE = PATH_TOKEN + '", "storage_key": "' + KEY_TOKEN  # storage_path and storage_key are neighbours in Features.to_dict()
+
+
+def expected_num_frames(duration: float, frame_shift: float, sampling_rate: int) -> int:
+    """lhotse.utils.compute_num_frames (lhotse/utils.py:410-421), the count validate_features holds a Features manifest to."""
+    hop = round(frame_shift * sampling_rate)
+    return int((round(duration * sampling_rate) + hop // 2) // hop)
+
+
+def manifest_fragments(cut, template: Dict, frame_shift: float, rec_cache: Dict, mono_type=None) -> Optional[Tuple[bytes, bytes, int]]:
+    """(head, tail, frames the line states) of a MonoCut's manifest line -- `json.dumps(cut-with-features.to_dict(), ensure_ascii=False)`
+    as SequentialJsonlWriter.write produces it (lhotse/serialization.py:236-252), cut around the storage fields -- or None when the cut
+    has to go through lhotse's own objects (mixed / padding cuts, custom fields that are not plain JSON, a hop that is not a whole
+    number of samples: the checks of the per-cut path then word the error)."""
+    import json
+
+    if mono_type is not None and type(cut) is not mono_type:
+        return None
+    hop = round(frame_shift * cut.sampling_rate, ndigits=12)  # qa.py:286-291
+    if not float(hop).is_integer():
+        return None
+    frames = expected_num_frames(cut.duration, frame_shift, cut.sampling_rate)
+    t = dict(template)
+    t["storage_path"] = PATH_TOKEN
+    d = _mono_cut_dict(cut, _features_dict(t, cut, frames, KEY_TOKEN), rec_cache)
+    if d is None:
+        return None
+    line = json.dumps(d, ensure_ascii=False)
+    head, sep, tail = line.partition(_SPLICE)
+    if not sep or _SPLICE in tail or PATH_TOKEN in head or KEY_TOKEN in head:
+        return None
+    return head.encode("utf-8"), tail.encode("utf-8"), frames
+
+
+def _concat(parts: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(parts) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in parts], out=off[1:])
+    blob = np.frombuffer(b"".join(parts) or b"\0", dtype=np.uint8)
+    return blob, off
+
+
+def stripe_paths(storage_path, stripes: int) -> List[Path]:
+    """File 0 is the archive path itself (``feats.hfa``), file k > 0 ``feats.<k>.hfa``."""
+    base = _archive_path(storage_path)
+    stem = str(base)[: -len(ARCHIVE_SUFFIX)]
+    return [base] + [Path(f"{stem}.{k}{ARCHIVE_SUFFIX}") for k in range(1, int(stripes))]
+
+
+class NativeArchive:
+    """The batch driver's writer for the ``hip_archive`` / ``hip_archive_f16`` storages: libhipfeat's hipfeat_archive_* (append of a
+    whole batch, striped over ``stripes`` files by as many writer threads, off the GIL) and hipfeat_manifest_lines.  The files are what
+    ``HipArchiveWriter.write_packed`` would have written (same keys, same bytes); with one stripe there is ONE file, as before."""
+
+    def __init__(self, storage_path, mode: str = "w", np_dtype: str = "<f4", stripes: int = 1, name: str = "hip_archive"):
+        import ctypes
+        import json
+
+        from . import _lib
+
+        assert mode in ("w", "a"), mode
+        self.lib = _lib.load()
+        self.name, self.np_dtype = name, np_dtype
+        self.item = 2 if np_dtype == "<f2" else 4
+        self.paths = stripe_paths(storage_path, max(1, int(stripes)))
+        self.paths[0].parent.mkdir(parents=True, exist_ok=True)
+        raw = [str(p).encode("utf-8") for p in self.paths]
+        arr = (ctypes.c_char_p * len(raw))(*raw)
+        h = np.zeros(1, dtype=np.uint64)
+        self.handle = 0
+        self.lib.check("hipfeat_archive_open", ctypes.addressof(arr), len(raw), 1 if mode == "a" else 0, _lib.addr(h))
+        self.handle = int(h[0])
+        # mid[k] = `<JSON-escaped path k>", "storage_key": "`
+        self._mids, self._mid_off = _concat([(json.dumps(str(p), ensure_ascii=False)[1:-1] + '", "storage_key": "').encode("utf-8") for p in self.paths])
+        self._append, self._lines = self.lib.fn("hipfeat_archive_append"), self.lib.fn("hipfeat_manifest_lines")
+
+    @property
+    def storage_path(self) -> str:
+        return str(self.paths[0])
+
+    def append(self, matrix: np.ndarray, frames: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """Append the packed (sum(frames), F) matrix of a batch -> (file index, byte offset) per cut."""
+        from . import _lib
+
+        with np.errstate(over="ignore"):
+            matrix = np.ascontiguousarray(matrix, dtype=self.np_dtype)  # (no copy for what the driver hands over: the device converted already)
+        assert matrix.ndim == 2, matrix.shape
+        if self.item == 2 and matrix.size and int((matrix.view(np.uint16) & 0x7FFF).max()) >= 0x7C00:  # as write_packed
+            raise ValueError(f"{self.name}: the batch holds values that are not finite in binary16 (|x| > 65504, inf or nan); this storage is "
+                             "meant for log-domain features -- use 'hip_archive' (float32) for linear-domain ones")
+        frames = np.ascontiguousarray(frames, dtype=np.int64)
+        assert int(frames.sum()) == matrix.shape[0], (int(frames.sum()), matrix.shape)
+        file_of, byte_off = np.zeros(len(frames), dtype=np.int32), np.zeros(len(frames), dtype=np.int64)
+        st = self._append(self.handle, matrix.ctypes.data, len(frames), _lib.addr(frames), int(matrix.shape[1]), self.item, _lib.addr(file_of), _lib.addr(byte_off))
+        if st != 0:
+            raise _lib.HipFeatError(int(st), self.lib.last_error())
+        return file_of, byte_off
+
+    def lines(self, heads: Sequence[bytes], tails: Sequence[bytes], frames: np.ndarray, expected: Optional[np.ndarray], file_of: np.ndarray,
+              byte_off: np.ndarray, cols: int) -> bytes:
+        """The JSONL lines of the batch (bytes, one b"\\n"-terminated line per cut); raises when a frame count differs from `expected`."""
+        from . import _lib
+
+        hb, ho = _concat(heads)
+        tb, to = _concat(tails)
+        frames = np.ascontiguousarray(frames, dtype=np.int64)
+        exp = None if expected is None else np.ascontiguousarray(expected, dtype=np.int64)
+        cap = int(ho[-1] + to[-1]) + len(heads) * (int(np.diff(self._mid_off).max()) + 80)
+        out, n = np.empty(cap, dtype=np.uint8), np.zeros(1, dtype=np.int64)
+        st = self._lines(hb.ctypes.data, _lib.addr(ho), tb.ctypes.data, _lib.addr(to), len(heads), _lib.addr(frames), _lib.addr(exp), self._mids.ctypes.data,
+                         _lib.addr(self._mid_off), len(self.paths), _lib.addr(file_of), _lib.addr(byte_off), int(cols), self.item, out.ctypes.data, cap, _lib.addr(n))
+        if st != 0:
+            msg = self.lib.last_error()
+            if "frame-count contract" in msg:
+                raise AssertionError(msg)  # what validate_features raises in the per-cut path
+            raise _lib.HipFeatError(int(st), msg)
+        return out[: int(n[0])].tobytes()
+
+    def keys(self, frames: np.ndarray, file_of: np.ndarray, byte_off: np.ndarray, cols: int) -> List[Tuple[str, str]]:
+        """(storage_path, storage_key) per cut -- for the cuts of a batch that go through lhotse's own objects."""
+        tag = ":f16" if self.item == 2 else ""
+        return [(str(self.paths[int(k)]), f"{int(o)}:{int(t)}:{int(cols)}{tag}") for t, k, o in zip(frames, file_of, byte_off)]
+
+    def size(self, k: int = 0) -> int:
+        return int(self.lib.raw("hipfeat_archive_size", self.handle, int(k)))
+
+    def flush(self):
+        pass  # appends are pwrite()s: nothing is buffered in the process
+
+    def close(self):
+        if self.handle:
+            h, self.handle = self.handle, 0
+            self.lib.check("hipfeat_archive_close", h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args, **kwargs):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_lines(manifest, blob: bytes) -> None:
+    """Put pre-serialised JSONL lines behind what a SequentialJsonlWriter has written so far (its `file` is a text-mode handle over a
+    GzipFile or a plain file: the bytes go to the layer underneath; zlib and the file write release the GIL)."""
+    manifest._maybe_open() if hasattr(manifest, "_maybe_open") else None
+    f = manifest.file if hasattr(manifest, "file") else manifest
+    f.flush()
+    raw = getattr(f, "buffer", None)
+    if raw is not None:
+        raw.write(blob)
+    else:
+        f.write(blob if "b" in getattr(f, "mode", "") else blob.decode("utf-8"))
+    f.flush()  # one flush per batch
+
+
+
 _SAVE_BACKLOG = 8  # batches in flight between the extractor and the save thread
 
 
@@ -389,9 +561,16 @@ def compute_and_store_features_batch(
     augment_fn: Optional[Callable] = None,
     storage_type=None,
     overwrite: bool = False,
+    archive_stripes: int = 1,
 ):
     """``CutSet.compute_and_store_features_batch`` with the bulk save path of this module (same arguments; ``storage_type``
-    defaults to ``HipArchiveWriter``).  Returns the CutSet with the ``Features`` manifests attached."""
+    defaults to ``HipArchiveWriter``).  Returns the CutSet with the ``Features`` manifests attached.
+
+    With the ``hip_archive`` / ``hip_archive_f16`` storages and a ``manifest_path`` the per-batch host work runs in libhipfeat
+    (``NativeArchive``): the loader's worker processes serialise every cut's manifest line up to the storage fields
+    (``manifest_fragments``), the save threads append the batch to the archive and splice the keys in -- no per-cut Python in this
+    process.  ``archive_stripes`` > 1 stripes the archive over that many files (``feats.hfa``, ``feats.1.hfa``, ...), one writer
+    thread each (a page-cache file takes one writer's copy rate; the readers follow each cut's ``storage_path``)."""
     if not HAVE_LHOTSE:
         raise ImportError("compute_and_store_features_batch produces lhotse manifests: install lhotse")
     from lhotse import CutSet, Features, MonoCut
@@ -406,17 +585,21 @@ def compute_and_store_features_batch(
         storage_path = Path(storage_path)
         if storage_path.exists() and storage_path.is_file():
             storage_path = storage_path.with_name(f"{storage_path.name}_storage")
+    if getattr(storage_type, "np_dtype", "<f4") == "<f2" and not getattr(extractor, "log_domain", True):
+        raise ValueError(f"storage '{storage_type.name}' keeps binary16 rows, which cannot hold the linear-domain output of '{extractor.name}' "
+                         "(overflow above 65504, flush to zero below 6e-8): use 'hip_archive'")
     frame_shift = extractor.frame_shift
     manifest = CutSet.open_writer(manifest_path, overwrite=overwrite)
     # rank / world pinned: under torchrun lhotse's samplers would otherwise split (and pad with duplicated cuts) what they are given once
     # more (lhotse/dataset/sampling/base.py:152-163); sharding over GPUs is explicit here (lhotse_amd.compute_and_store_features_sharded)
     sampler = SimpleCutSampler(cuts, max_duration=batch_duration, world_size=1, rank=0)
     sampler.filter(lambda cut: cut.id not in manifest.ignore_ids)  # resume: skip what the manifest already holds
-    loader = DataLoader(UnsupervisedWaveformDataset(collate=collate), batch_size=None, sampler=sampler, num_workers=num_workers)
+    # (exactly the registered archive classes: a subclass that overrides write / write_packed is served through its own methods)
+    native = manifest_path is not None and storage_type in (HipArchiveWriter, HipArchiveF16Writer)
     rec_cache: Dict[str, Tuple[object, Dict]] = {}
 
-    def save(writer, batch_cuts, host: np.ndarray, frames: List[int], template: Dict):
-        # the frame-count contract of validate_features (qa.py:286-301), for the whole batch
+    def check_frames(batch_cuts, frames):
+        """The frame-count contract of validate_features (qa.py:286-301), for the whole batch (per-cut path)."""
         for c, t in zip(batch_cuts, frames):
             if isinstance(c, PaddingCut):
                 continue
@@ -426,24 +609,14 @@ def compute_and_store_features_batch(
             if compute_num_frames(c.duration, frame_shift, c.sampling_rate) != t:
                 raise AssertionError(f"cut {c.id}: {t} frames for {c.duration} s at frame_shift {frame_shift} (lhotse expects "
                                      f"{compute_num_frames(c.duration, frame_shift, c.sampling_rate)})")
-        stored = [i for i, c in enumerate(batch_cuts) if not isinstance(c, PaddingCut)]
-        bounds = np.concatenate([[0], np.cumsum(frames)])
-        if hasattr(writer, "write_packed") and len(stored) == len(batch_cuts):
-            keys = writer.write_packed(host, frames)
-        else:
-            keys = [None] * len(batch_cuts)
-            for i in stored:
-                keys[i] = writer.write(batch_cuts[i].id, host[int(bounds[i]) : int(bounds[i + 1])])
-        if hasattr(writer, "flush"):
-            writer.flush()
-        return batch_cuts, frames, keys, int(host.shape[1]), template  # -> write_manifests, on the second background thread
 
-    def write_manifests(batch_cuts, frames: List[int], keys: List[str], num_features: int, template: Dict) -> None:
+    def write_cut_objects(batch_cuts, frames, feature_dicts, num_features: int) -> None:
+        """One manifest per cut through Python objects: template dicts for plain MonoCuts, lhotse's own objects for the rest."""
         for i, c in enumerate(batch_cuts):
             if isinstance(c, PaddingCut):
                 manifest.write(fastcopy(c, num_frames=frames[i], num_features=num_features, frame_shift=frame_shift))
                 continue
-            fd = _features_dict(template, c, frames[i], keys[i])
+            fd = feature_dicts[i]
             # (an in-memory manifest -- no manifest_path -- keeps the objects it is given: no templates there)
             out = _mono_cut_dict(c, fd, rec_cache) if type(c) is MonoCut and manifest_path is not None else None
             TEMPLATE_STATS["fallback" if out is None else "template"] += 1
@@ -460,12 +633,7 @@ def compute_and_store_features_batch(
         if getattr(manifest, "file", None) is not None:
             manifest.file.flush()  # one flush per batch
 
-    if getattr(storage_type, "np_dtype", "<f4") == "<f2" and not getattr(extractor, "log_domain", True):
-        raise ValueError(f"storage '{storage_type.name}' keeps binary16 rows, which cannot hold the linear-domain output of '{extractor.name}' "
-                         "(overflow above 65504, flush to zero below 6e-8): use 'hip_archive'")
-    with manifest, storage_type(storage_path, mode="w" if overwrite else "a") as writer:
-        state = {"template": None}
-
+    def run(writer, loader, save, finish, half: bool, template_of):
         def extract(batch):
             batch_cuts, waves = batch["cuts"], batch["audio"]
             lens = batch["audio_lens"] if collate else None
@@ -475,11 +643,101 @@ def compute_and_store_features_batch(
             assert all(c.sampling_rate == sr for c in batch_cuts)
             if augment_fn is not None:
                 waves = [augment_fn(w, c.sampling_rate) for c, w in zip(batch_cuts, waves)]
-            host, frames = _batch_features_on_host(extractor, waves, sr, lens, half=getattr(writer, "np_dtype", "<f4") == "<f2")
+            host, frames = _batch_features_on_host(extractor, waves, sr, lens, half=half)
+            return writer, list(batch_cuts), host, frames, template_of(host, sr), batch.get("hipfeat_fragments")
+
+        pump_batches(loader, extract, save, finish=finish)
+
+    if native:
+        # ---- the native path: archive appends and manifest lines in libhipfeat, fragments from the loader's workers -------------------
+        np_dtype = getattr(storage_type, "np_dtype", "<f4")
+        with manifest, NativeArchive(storage_path, mode="w" if overwrite else "a", np_dtype=np_dtype, stripes=archive_stripes, name=storage_type.name) as archive:
+            first = next(iter(cuts), None)
+            base = None
+            if first is not None and not isinstance(first, PaddingCut):
+                base = {"type": extractor.name, "num_features": int(extractor.feature_dim(first.sampling_rate)), "frame_shift": frame_shift,
+                        "sampling_rate": first.sampling_rate, "storage_type": archive.name, "storage_path": archive.storage_path}
+
+            class _FragmentingDataset(UnsupervisedWaveformDataset):
+                """lhotse's waveform dataset + the halves of every cut's manifest line, made where the cut is loaded (the DataLoader's
+                worker processes when num_workers > 0)."""
+
+                def __getitem__(self, batch_cuts):
+                    batch = super().__getitem__(batch_cuts)
+                    cache = self.__dict__.setdefault("_hipfeat_rec_cache", {})
+                    batch["hipfeat_fragments"] = None if base is None else [manifest_fragments(c, base, frame_shift, cache, MonoCut) for c in batch["cuts"]]
+                    return batch
+
+            loader = DataLoader(_FragmentingDataset(collate=collate), batch_size=None, sampler=sampler, num_workers=num_workers)
+
+            def save(archive, batch_cuts, host: np.ndarray, frames: List[int], template: Dict, frags):
+                frames = np.ascontiguousarray(frames, dtype=np.int64)
+                with np.errstate(over="ignore"):
+                    host = np.ascontiguousarray(host, dtype=np_dtype)
+                stored = [i for i, c in enumerate(batch_cuts) if not isinstance(c, PaddingCut)]
+                if len(stored) != len(batch_cuts):  # padding cuts store nothing: their rows are cut out of the batch matrix
+                    bounds = np.concatenate([[0], np.cumsum(frames)])
+                    host = np.ascontiguousarray(np.concatenate([host[int(bounds[i]) : int(bounds[i + 1])] for i in stored], axis=0)) if stored else host[:0]
+                file_of = np.zeros(len(batch_cuts), dtype=np.int32)
+                byte_off = np.zeros(len(batch_cuts), dtype=np.int64)
+                f2, b2 = archive.append(host, frames[stored])
+                file_of[stored], byte_off[stored] = f2, b2
+                return archive, batch_cuts, frames, file_of, byte_off, int(host.shape[1]), template, frags
+
+            def finish(archive, batch_cuts, frames, file_of, byte_off, num_features: int, template: Dict, frags) -> None:
+                spliced = frags is not None and all(f is not None for f in frags) and base is not None and num_features == base["num_features"]
+                if spliced:
+                    blob = archive.lines([f[0] for f in frags], [f[1] for f in frags], frames, np.fromiter((f[2] for f in frags), dtype=np.int64, count=len(frags)),
+                                         file_of, byte_off, num_features)
+                    write_lines(manifest, blob)
+                    TEMPLATE_STATS["template"] += len(frags)
+                    TEMPLATE_STATS["native"] = TEMPLATE_STATS.get("native", 0) + len(frags)
+                    return
+                check_frames(batch_cuts, frames)
+                where = archive.keys(frames, file_of, byte_off, num_features)
+                dicts = []
+                for i, c in enumerate(batch_cuts):
+                    t = dict(template)
+                    t["storage_path"] = where[i][0]
+                    dicts.append(None if isinstance(c, PaddingCut) else _features_dict(t, c, int(frames[i]), where[i][1]))
+                write_cut_objects(batch_cuts, [int(t) for t in frames], dicts, num_features)
+
+            def template_of(host, sr):
+                return {"type": extractor.name, "num_features": int(host.shape[1]), "frame_shift": frame_shift, "sampling_rate": sr,
+                        "storage_type": archive.name, "storage_path": archive.storage_path}
+
+            run(archive, loader, save, finish, np_dtype == "<f2", template_of)
+        return manifest.open_manifest()
+
+    # ---- any other registered FeaturesWriter: per-cut write() calls, manifests through Python objects ------------------------------
+    loader = DataLoader(UnsupervisedWaveformDataset(collate=collate), batch_size=None, sampler=sampler, num_workers=num_workers)
+
+    def save(writer, batch_cuts, host: np.ndarray, frames: List[int], template: Dict, frags):
+        check_frames(batch_cuts, frames)
+        stored = [i for i, c in enumerate(batch_cuts) if not isinstance(c, PaddingCut)]
+        bounds = np.concatenate([[0], np.cumsum(frames)])
+        if hasattr(writer, "write_packed") and len(stored) == len(batch_cuts):
+            keys = writer.write_packed(host, frames)
+        else:
+            keys = [None] * len(batch_cuts)
+            for i in stored:
+                keys[i] = writer.write(batch_cuts[i].id, host[int(bounds[i]) : int(bounds[i + 1])])
+        if hasattr(writer, "flush"):
+            writer.flush()
+        return batch_cuts, frames, keys, int(host.shape[1]), template  # -> write_manifests, on the second background thread
+
+    def write_manifests(batch_cuts, frames: List[int], keys: List[str], num_features: int, template: Dict) -> None:
+        dicts = [None if isinstance(c, PaddingCut) else _features_dict(template, c, frames[i], keys[i]) for i, c in enumerate(batch_cuts)]
+        write_cut_objects(batch_cuts, frames, dicts, num_features)
+
+    with manifest, storage_type(storage_path, mode="w" if overwrite else "a") as writer:
+        state = {"template": None}
+
+        def template_of(host, sr):
             if state["template"] is None:
                 state["template"] = {"type": extractor.name, "num_features": int(host.shape[1]), "frame_shift": frame_shift, "sampling_rate": sr,
                                      "storage_type": writer.name, "storage_path": str(writer.storage_path)}
-            return writer, list(batch_cuts), host, frames, state["template"]
+            return state["template"]
 
-        pump_batches(loader, extract, save, finish=write_manifests)
+        run(writer, loader, save, write_manifests, getattr(writer, "np_dtype", "<f4") == "<f2", template_of)
     return manifest.open_manifest()

@@ -12,7 +12,8 @@ import torch
 from _dropin_support import make_cpu_plan
 
 
-def test_bulk_save_workload_writes_what_the_extractor_computes(monkeypatch):
+@pytest.mark.parametrize("stripes", [1, 3])
+def test_bulk_save_workload_writes_what_the_extractor_computes(monkeypatch, stripes):
     import bench
     import lhotse_amd.extractors as E
 
@@ -20,12 +21,9 @@ def test_bulk_save_workload_writes_what_the_extractor_computes(monkeypatch):
     monkeypatch.setattr(bench, "SAMPLES_PER_CUT", 16000)   # 1 s cuts: the oracle-backed plan is slow
     monkeypatch.setattr(bench, "FRAMES_PER_CUT", 100)
     monkeypatch.setattr(bench, "PARITY_CUTS", 8)
-    args = argparse.Namespace(cuts=2, no_host_fed=False)
+    args = argparse.Namespace(cuts=2, no_host_fed=False, stripes=stripes)
     w = bench.BulkSave(torch.device("cuda", 0), 0, args)
-    for c, _ in w.batches:  # the stand-in cuts are 10 s by construction: make them 1 s like the patched samples
-        for cut in c:
-            cut.duration = 1.0
-    assert w.units == 120
+    assert w.units == 120 and w.batches[0][0][0].duration == 1.0 and w.fragments_per_s > 0
     w.step()
     first = w.last_root
     w.clear()
@@ -39,13 +37,26 @@ def test_bulk_save_workload_writes_what_the_extractor_computes(monkeypatch):
     assert d["type"] == "MonoCut" and d["features"]["type"] == "hip-fbank" and d["features"]["storage_type"] == "hip_archive"
     assert d["recording"]["sources"][0]["source"].endswith(".flac") and d["supervisions"][0]["speaker"] == "spk61"
     assert d["custom"] == {"dataloading_info": {"rank": 0, "world_size": 1, "worker_id": None}}
-    assert os.path.getsize(d["features"]["storage_path"]) == 120 * 100 * 80 * 4
+    files = {ln["features"]["storage_path"] for ln in lines}
+    assert len(files) == stripes and sum(os.path.getsize(f) for f in files) == 120 * 100 * 80 * 4
     par = w.parity(0)
     # stored == what the (numpy-oracle-backed) plan computed; ref32 of the parity leg is the torch restatement since round 5: rounding apart
     assert par["n"] == 8 and par["rel_l2_max"] < 1e-5
+    # round 4's per-cut Python route writes the same lines (storage fields apart: its archive is one file)
+    st4 = {}
+    root4 = w._one_pass("float32", "hip_archive", st4, "per_cut")
+    with gzip.open(os.path.join(root4, "cuts.jsonl.gz"), "rt") as f:
+        lines4 = [json.loads(ln) for ln in f]
+    for a, b in zip(lines, lines4):
+        for k in ("storage_path", "storage_key"):
+            a["features"].pop(k), b["features"].pop(k)
+    assert lines == lines4
+    w._drop(root4)
     # the half-precision archive variant of `extra` leaves binary16 rows
     st16 = {}
     root = w._one_pass("float32", "hip_archive_f16", st16)  # (int16 PCM is converted on the device: GPU box only)
     assert st16["archive_bytes"] == 120 * 100 * 80 * 2
+    with gzip.open(os.path.join(root, "cuts.jsonl.gz"), "rt") as f:
+        assert json.loads(f.readline())["features"]["storage_key"].endswith(":f16")
     w._drop(root)
     w.close()

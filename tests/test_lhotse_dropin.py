@@ -564,3 +564,82 @@ def test_on_the_fly_features_with_speed_perturbed_cuts(cutset, cpu_device, monke
     assert IS.deferred_speed_factor(list(cutset)[0]) is None
     assert IS.deferred_speed_factor(list(cutset.perturb_speed(1.1).perturb_volume(2.0))[0]) is None
     assert IS.deferred_speed_factor(list(cutset.perturb_speed(1.1))[0]) == 1.1
+
+
+def _lines(path):
+    import gzip
+
+    with gzip.open(path, "rt", encoding="utf-8") as f:
+        return [ln.rstrip("\n") for ln in f]
+
+
+def test_native_manifest_lines_equal_the_per_cut_path_byte_for_byte(tmp_path, cutset, cpu_device):
+    """Round 5 (VERDICT r4 task 4): the manifest of the native path -- line halves made where the cuts are loaded, keys spliced in by
+    libhipfeat's hipfeat_manifest_lines -- is the per-cut Python path's manifest character for character (storage_path apart), with
+    and without loader workers, with supervisions that hold non-ASCII text and with lhotse's own `dataloading_info` custom field;
+    the archive bytes are the same bytes; stripes spread them over several files that lhotse's readers follow per cut."""
+    import lhotse_amd as LA
+    from lhotse import CutSet, SupervisionSegment
+
+    cuts = []
+    for k in range(4):
+        for c in cutset:
+            c = c.with_id(f"{c.id}-{k}")
+            c.supervisions = [SupervisionSegment(id=c.id, recording_id=c.recording_id, start=0.0, duration=c.duration, text=f"zażółć gęślą jaźń \"{k}\" \\ ü",
+                                                 speaker=f"spk{k}", language="pl")]
+            cuts.append(c)
+    many = CutSet.from_cuts(cuts)  # 20 cuts
+    ex = LA.HipFbank()
+
+    class PerCut(LA.HipArchiveWriter):  # a subclass is served through the generic per-cut path (its own write_packed)
+        name = "hip_archive"
+
+    plain = list(LA.compute_and_store_features_batch(many, ex, tmp_path / "plain", manifest_path=tmp_path / "plain.jsonl.gz", batch_duration=4.0,
+                                                     num_workers=0, storage_type=PerCut))
+    want = _lines(tmp_path / "plain.jsonl.gz")
+    assert len(want) == 20
+    for tag, workers, stripes in (("w0", 0, 1), ("w2", 2, 1), ("s3", 1, 3)):
+        before = dict(LA.storage.TEMPLATE_STATS)
+        got_cuts = list(LA.compute_and_store_features_batch(many, ex, tmp_path / tag, manifest_path=tmp_path / f"{tag}.jsonl.gz", batch_duration=4.0,
+                                                            num_workers=workers, archive_stripes=stripes))
+        assert LA.storage.TEMPLATE_STATS.get("native", 0) - before.get("native", 0) == 20, tag  # every line came out of the C splice
+        got = _lines(tmp_path / f"{tag}.jsonl.gz")
+        if stripes == 1:
+            assert [ln.replace(str(tmp_path / tag) + ".hfa", str(tmp_path / "plain") + ".hfa") for ln in got] == want, tag
+            assert (tmp_path / f"{tag}.hfa").read_bytes() == (tmp_path / "plain.hfa").read_bytes()
+        else:
+            files = {c.features.storage_path for c in got_cuts}
+            assert files == {str(tmp_path / "s3.hfa"), str(tmp_path / "s3.1.hfa"), str(tmp_path / "s3.2.hfa")}
+            assert sum(os.path.getsize(f) for f in files) == os.path.getsize(tmp_path / "plain.hfa")
+        for a, b in zip(got_cuts, plain):
+            assert a.id == b.id and a.supervisions[0].text == b.supervisions[0].text and np.array_equal(a.load_features(), b.load_features())
+    # resume into a striped archive: nothing is extracted twice, the files do not move
+    sizes = {f: os.path.getsize(f) for f in (tmp_path / "s3.hfa", tmp_path / "s3.1.hfa", tmp_path / "s3.2.hfa")}
+    again = list(LA.compute_and_store_features_batch(many, ex, tmp_path / "s3", manifest_path=tmp_path / "s3.jsonl.gz", batch_duration=4.0, num_workers=0,
+                                                     archive_stripes=3))
+    assert [c.id for c in again] == [c.id for c in plain] and sizes == {f: os.path.getsize(f) for f in sizes}
+
+
+def test_native_path_enforces_the_frame_count_contract_and_stops_on_write_errors(tmp_path, cutset, cpu_device, monkeypatch):
+    """validate_features' contract (lhotse/qa.py:286-301) is checked inside hipfeat_manifest_lines on the extractor's ACTUAL frame counts;
+    a failing archive append stops the run at the next batch."""
+    import lhotse_amd as LA
+    import lhotse_amd.storage as S
+
+    ex = LA.HipFbank()
+    real = S.expected_num_frames
+    monkeypatch.setattr(S, "expected_num_frames", lambda d, fs, sr: real(d, fs, sr) + (1 if abs(d - 2.0) < 1e-9 else 0))  # the 32000-sample cut
+    with pytest.raises(AssertionError, match="frame-count contract"):
+        LA.compute_and_store_features_batch(cutset, ex, tmp_path / "bad", manifest_path=tmp_path / "bad.jsonl.gz", batch_duration=10.0, num_workers=0)
+    monkeypatch.setattr(S, "expected_num_frames", real)
+    calls = {"n": 0}
+
+    def full(self, matrix, frames):
+        calls["n"] += 1
+        raise OSError("No space left on device")
+
+    monkeypatch.setattr(S.NativeArchive, "append", full)
+    many = cutset + cutset.modify_ids(lambda i: i + "_b") + cutset.modify_ids(lambda i: i + "_c")
+    with pytest.raises(OSError, match="No space left"):
+        LA.compute_and_store_features_batch(many, ex, tmp_path / "full", manifest_path=tmp_path / "full.jsonl.gz", batch_duration=0.4, num_workers=0)
+    assert calls["n"] < 15
