@@ -325,6 +325,29 @@ HIPFEAT_API hipfeat_status hipfeat_manifest_lines(const char* h_heads, const int
                                                   int32_t num_files, const int32_t* h_file, const int64_t* h_byte_offset, int32_t cols,
                                                   int32_t bytes_per_value, char* h_out, int64_t out_capacity, int64_t* h_out_bytes);
 
+/* ---- the offline driver's extraction step, one asynchronous call per batch of HOST waveforms -------------------- */
+/*
+ * Behind compute_and_store_features_batch the extractor is handed a list of host tensors per batch and its result goes to a save
+ * thread (lhotse/cut/set.py:2365-2404).  A host pipeline does that step inside the library: hipfeat_host_pipeline_submit packs the
+ * cuts (h_items[b] = pointer to h_num_samples[b] float32 samples, or int16 PCM when pcm16 != 0; pageable or page-locked) into
+ * page-locked staging with `copy_threads` persistent host threads, and ENQUEUES, chunk by chunk on two private streams, the upload,
+ * [hipfeat_pcm16_to_float,] the plan's feature launch (per-item reflect edges; zero_pad_batch != 0: edge_rule "batch_zero_pad"),
+ * [hipfeat_float_to_half when half_out != 0] and the download into a page-locked result buffer owned by the pipeline.  It returns
+ * without waiting for the device: *h_out is where the packed (*h_out_rows, feature_dim) matrix WILL be (float32, or binary16 with
+ * half_out), h_num_frames[b] the frame counts (known at once), *ticket the handle.  hipfeat_host_pipeline_wait blocks until that
+ * batch's features are in *h_out; hipfeat_host_pipeline_release gives the buffer back (after which *h_out may be overwritten by a later
+ * batch).  Up to 64 results may be outstanding; submitting batch n + 1 before waiting for batch n is the point: its packing and
+ * upload overlap batch n's download.  One pipeline per plan and calling thread; wait / release may come from another thread.
+ */
+typedef struct hipfeat_host_pipeline hipfeat_host_pipeline;
+HIPFEAT_API hipfeat_status hipfeat_host_pipeline_create(const hipfeat_plan* plan, int32_t copy_threads, hipfeat_host_pipeline** pipeline);
+HIPFEAT_API hipfeat_status hipfeat_host_pipeline_destroy(hipfeat_host_pipeline* pipeline);
+HIPFEAT_API hipfeat_status hipfeat_host_pipeline_submit(hipfeat_host_pipeline* pipeline, const void* const* h_items, const int64_t* h_num_samples,
+                                                        int64_t batch, int32_t pcm16, int32_t zero_pad_batch, int32_t half_out,
+                                                        int64_t* h_num_frames, void** h_out, int64_t* h_out_rows, int64_t* ticket);
+HIPFEAT_API hipfeat_status hipfeat_host_pipeline_wait(hipfeat_host_pipeline* pipeline, int64_t ticket);
+HIPFEAT_API hipfeat_status hipfeat_host_pipeline_release(hipfeat_host_pipeline* pipeline, int64_t ticket);
+
 #ifdef __cplusplus
 }
 #endif

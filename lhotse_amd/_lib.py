@@ -84,6 +84,14 @@ _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
         ["const char*", "const int64_t*", "const char*", "const int64_t*", "int64_t", "const int64_t*", "const int64_t*", "const char*", "const int64_t*",
          "int32_t", "const int32_t*", "const int64_t*", "int32_t", "int32_t", "char*", "int64_t", "int64_t*"],
     ),
+    "hipfeat_host_pipeline_create": ("int", ["const hipfeat_plan*", "int32_t", "hipfeat_host_pipeline**"]),
+    "hipfeat_host_pipeline_destroy": ("int", ["hipfeat_host_pipeline*"]),
+    "hipfeat_host_pipeline_submit": (
+        "int",
+        ["hipfeat_host_pipeline*", "const void* const*", "const int64_t*", "int64_t", "int32_t", "int32_t", "int32_t", "int64_t*", "void**", "int64_t*", "int64_t*"],
+    ),
+    "hipfeat_host_pipeline_wait": ("int", ["hipfeat_host_pipeline*", "int64_t"]),
+    "hipfeat_host_pipeline_release": ("int", ["hipfeat_host_pipeline*", "int64_t"]),
     "hipfeat_extract_host": (
         "int",
         ["const hipfeat_plan*", "const float*", "int64_t", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "int64_t", "const int64_t*", "int64_t", "void*"],

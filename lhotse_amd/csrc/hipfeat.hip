@@ -2921,6 +2921,8 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_manifest_lines(const char* h_heads
   return HIPFEAT_OK;
 }
 
+#include "host_pipeline.hpp"
+
 #ifdef HIPFEAT_PHASE_TIMERS
 // experiment builds only: install the per-wave phase-clock buffer ([waves][8] uint64, device memory)
 extern "C" HIPFEAT_API int hipfeat_debug_set_phase_buffer(unsigned long long* d_buf) {

@@ -515,6 +515,101 @@ class _HostPipeline:
         return host
 
 
+class PendingFeatures:
+    """The packed (rows, F) feature matrix of one batch on its way to (or already in) host memory.  ``wait()`` -> the numpy matrix
+    (a view of page-locked memory owned by the pipeline when ``ticket`` is set: valid until ``release()``)."""
+
+    __slots__ = ("_pipe", "ticket", "_array", "frames")
+
+    def __init__(self, pipe, ticket, array: np.ndarray, frames: np.ndarray):
+        self._pipe, self.ticket, self._array, self.frames = pipe, ticket, array, frames
+
+    @property
+    def shape(self):
+        return self._array.shape
+
+    def wait(self) -> np.ndarray:
+        if self._pipe is not None and self.ticket is not None:
+            self._pipe._wait(self.ticket)
+        return self._array
+
+    def release(self) -> None:
+        if self._pipe is not None and self.ticket is not None:
+            t, self.ticket = self.ticket, None
+            self._array = None
+            self._pipe._release(t)
+
+
+class NativeHostPipeline:
+    """``hipfeat_host_pipeline_*`` (include/hipfeat.h): the batch driver's extraction step as one asynchronous library call per batch --
+    a persistent pool of host threads packs the cuts into page-locked staging and the chunked H2D / launch / D2H sequence is ENQUEUED,
+    not waited for.  Against the Python ``_HostPipeline`` it removes ~50 interpreter-level calls (and their GIL hand-overs) per batch
+    and lets batch n + 1's packing overlap batch n's download."""
+
+    def __init__(self, plan, copy_threads: Optional[int] = None):
+        self.plan, self.lib = plan, plan.lib
+        threads = copy_threads or max(2, min(12, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)) // 4))
+        h = np.zeros(1, dtype=np.uint64)
+        self.handle = 0
+        self.lib.check("hipfeat_host_pipeline_create", plan.handle, int(threads), _lib.addr(h))
+        self.handle = int(h[0])
+        self.threads = int(threads)
+        self._submit = self.lib.fn("hipfeat_host_pipeline_submit")
+        self._waitf, self._releasef = self.lib.fn("hipfeat_host_pipeline_wait"), self.lib.fn("hipfeat_host_pipeline_release")
+
+    def submit(self, items: Sequence[ArrayLike], zero_pad_batch: bool = False, half: bool = False) -> PendingFeatures:
+        """1-D HOST waveforms (all float32 or all int16 PCM; numpy arrays or CPU tensors) -> PendingFeatures."""
+        import ctypes
+
+        B = len(items)
+        pcm = _is_pcm16(items[0])
+        keep, ptrs, lens = [], np.empty(B, dtype=np.uint64), np.empty(B, dtype=np.int64)
+        for i, x in enumerate(items):
+            if _is_pcm16(x) != pcm:
+                raise TypeError("a batch must be all float32 or all int16 PCM")
+            if isinstance(x, torch.Tensor):
+                x = x.detach().contiguous()
+                ptrs[i] = x.data_ptr()
+            else:
+                x = np.ascontiguousarray(x)
+                ptrs[i] = x.ctypes.data
+            keep.append(x)  # (alive until submit() has packed them)
+            lens[i] = int(x.shape[0])
+        frames = np.empty(B, dtype=np.int64)
+        res = np.zeros(3, dtype=np.int64)  # h_out pointer, rows, ticket
+        a = res.ctypes.data
+        st = self._submit(self.handle, ptrs.ctypes.data, lens.ctypes.data, B, 1 if pcm else 0, 1 if zero_pad_batch else 0, 1 if half else 0,
+                          frames.ctypes.data, a, a + 8, a + 16)
+        if st != 0:
+            msg = self.lib.last_error()
+            raise (ValueError(msg) if int(st) == _lib.ERR_TOO_SHORT else _lib.HipFeatError(int(st), msg))
+        rows, F = int(res[1]), int(self.plan.feature_dim)
+        item = 2 if half else 4
+        buf = (ctypes.c_char * (rows * F * item)).from_address(int(res[0]))
+        arr = np.frombuffer(buf, dtype=np.float16 if half else np.float32).reshape(rows, F)
+        return PendingFeatures(self, int(res[2]), arr, frames)
+
+    def _wait(self, ticket: int) -> None:
+        st = self._waitf(self.handle, int(ticket))
+        if st != 0:
+            raise _lib.HipFeatError(int(st), self.lib.last_error())
+
+    def _release(self, ticket: int) -> None:
+        if self.handle:
+            self._releasef(self.handle, int(ticket))
+
+    def close(self):
+        if self.handle:
+            h, self.handle = self.handle, 0
+            self.lib.raw("hipfeat_host_pipeline_destroy", h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _SHARED_STAGING: Dict[int, "_HostStaging"] = {}
 
 
@@ -612,12 +707,16 @@ class _HipExtractor(FeatureExtractor):
         st["_staging"] = None
         st.pop("_lock", None)
         st.pop("_pipeline", None)
+        st.pop("_native_pipeline", None)
         return st
 
     def _drop_plan(self):
         # the host pipeline (two side streams) and the pinned staging belong to the plan's device: they go with it, or a moved
         # extractor would record / wait on the OLD device's streams while the kernel runs on the new one
         self.__dict__.pop("_pipeline", None)
+        native = self.__dict__.pop("_native_pipeline", None)
+        if native is not None:
+            native.close()  # (before the plan it borrows)
         self._staging = None
         if self._plan is not None:
             self._plan.close()
@@ -675,6 +774,26 @@ class _HipExtractor(FeatureExtractor):
                 if pipe is None or pipe.device != self.plan.device:
                     pipe = self.__dict__["_pipeline"] = _HostPipeline(self.plan.device)
         return pipe
+
+    def _native_pipe(self) -> "NativeHostPipeline":
+        """The library-side host pipeline of this extractor's plan (created on first use; dropped with the plan)."""
+        pipe = self.__dict__.get("_native_pipeline")
+        if pipe is None or pipe.plan is not self.plan:
+            with self._lazy_lock():
+                pipe = self.__dict__.get("_native_pipeline")
+                if pipe is None or pipe.plan is not self.plan:
+                    pipe = self.__dict__["_native_pipeline"] = NativeHostPipeline(self.plan)
+        return pipe
+
+    def submit_host_items(self, items: Sequence[ArrayLike], sampling_rate: int, half: bool = False) -> "PendingFeatures":
+        """Host waveforms of one batch -> PendingFeatures (asynchronous: ``.wait()`` for the packed host matrix, ``.release()`` when done).
+        The batch driver's form of ``extract_batch`` (lhotse/cut/set.py:2393-2398 hands a list of host tensors over per batch)."""
+        self._check_sr(sampling_rate)
+        items = [_as_1d_float(x.squeeze() if x.ndim > 1 else x, "submit_host_items()") for x in items]
+        zero_pad = getattr(self.config, "edge_rule", "reflect") == "batch_zero_pad"
+        if getattr(self.config, "dither", 0.0):
+            raise _lib.HipFeatError(_lib.ERR_UNSUPPORTED, "dither is added by the Python host: use extract_batch")
+        return self._native_pipe().submit(items, zero_pad_batch=zero_pad, half=half)
 
     def _host_items_to_host(self, items: Sequence[ArrayLike], padded_len: Optional[int], half: bool = False) -> Tuple[torch.Tensor, np.ndarray]:
         """Host waveforms in, packed host feature matrix out (float32, or float16 converted on the device with `half`), through the

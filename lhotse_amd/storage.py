@@ -493,6 +493,39 @@ def _batch_features_on_host(extractor, waves, sampling_rate: int, lengths, half:
     return (np.concatenate(mats, axis=0) if len(mats) != 1 else mats[0]), [int(m.shape[0]) for m in mats]
 
 
+class _HostFeatures:
+    """A feature matrix that is on the host already, with the interface of extractors.PendingFeatures."""
+
+    __slots__ = ("_array", "frames")
+
+    def __init__(self, array: np.ndarray, frames):
+        self._array, self.frames = array, frames
+
+    @property
+    def shape(self):
+        return self._array.shape
+
+    def wait(self) -> np.ndarray:
+        return self._array
+
+    def release(self) -> None:
+        self._array = None
+
+
+def _batch_features_pending(extractor, waves, sampling_rate: int, lengths, half: bool = False):
+    """-> (pending packed ``(sum T_b, F)`` host matrix, per-cut frame counts).  Host waveforms in front of a Hip* extractor on a GPU go
+    through the library's asynchronous host pipeline (``submit_host_items``): the call returns once the batch is packed and enqueued,
+    ``pending.wait()`` (on the save thread) gives the matrix, ``pending.release()`` its buffer back.  Everything else is computed here
+    and wrapped."""
+    if lengths is None and hasattr(extractor, "submit_host_items") and getattr(extractor.plan, "handle", None) and extractor.plan.device.type == "cuda" \
+            and not getattr(extractor.config, "dither", 0.0) \
+            and all(not isinstance(w, torch.Tensor) or w.device.type == "cpu" for w in waves) and len(waves) > 0:
+        pending = extractor.submit_host_items(waves, sampling_rate, half=half)
+        return pending, [int(t) for t in pending.frames]
+    host, frames = _batch_features_on_host(extractor, waves, sampling_rate, lengths, half=half)
+    return _HostFeatures(host, frames), frames
+
+
 def pump_batches(batches, extract, save, backlog: int = None, stats: Optional[Dict] = None, finish=None) -> None:
     """The loop of the batch driver (lhotse/cut/set.py:2365-2404): the calling thread runs ``extract(batch)`` -> arguments of ``save`` (or
     None to skip the batch), ONE background thread runs ``save(*args)`` behind it -- and, with ``finish``, a second one runs
@@ -643,8 +676,8 @@ def compute_and_store_features_batch(
             assert all(c.sampling_rate == sr for c in batch_cuts)
             if augment_fn is not None:
                 waves = [augment_fn(w, c.sampling_rate) for c, w in zip(batch_cuts, waves)]
-            host, frames = _batch_features_on_host(extractor, waves, sr, lens, half=half)
-            return writer, list(batch_cuts), host, frames, template_of(host, sr), batch.get("hipfeat_fragments")
+            pending, frames = _batch_features_pending(extractor, waves, sr, lens, half=half)
+            return writer, list(batch_cuts), pending, frames, template_of(pending, sr), batch.get("hipfeat_fragments")
 
         pump_batches(loader, extract, save, finish=finish)
 
@@ -670,8 +703,9 @@ def compute_and_store_features_batch(
 
             loader = DataLoader(_FragmentingDataset(collate=collate), batch_size=None, sampler=sampler, num_workers=num_workers)
 
-            def save(archive, batch_cuts, host: np.ndarray, frames: List[int], template: Dict, frags):
+            def save(archive, batch_cuts, pending, frames: List[int], template: Dict, frags):
                 frames = np.ascontiguousarray(frames, dtype=np.int64)
+                host = pending.wait()  # (the batch's download may still be in flight: the extractor only enqueued it)
                 with np.errstate(over="ignore"):
                     host = np.ascontiguousarray(host, dtype=np_dtype)
                 stored = [i for i, c in enumerate(batch_cuts) if not isinstance(c, PaddingCut)]
@@ -681,8 +715,11 @@ def compute_and_store_features_batch(
                 file_of = np.zeros(len(batch_cuts), dtype=np.int32)
                 byte_off = np.zeros(len(batch_cuts), dtype=np.int64)
                 f2, b2 = archive.append(host, frames[stored])
+                num_features = int(host.shape[1])
+                del host
+                pending.release()  # the page-locked result goes back to the pipeline
                 file_of[stored], byte_off[stored] = f2, b2
-                return archive, batch_cuts, frames, file_of, byte_off, int(host.shape[1]), template, frags
+                return archive, batch_cuts, frames, file_of, byte_off, num_features, template, frags
 
             def finish(archive, batch_cuts, frames, file_of, byte_off, num_features: int, template: Dict, frags) -> None:
                 spliced = frags is not None and all(f is not None for f in frags) and base is not None and num_features == base["num_features"]
@@ -712,8 +749,9 @@ def compute_and_store_features_batch(
     # ---- any other registered FeaturesWriter: per-cut write() calls, manifests through Python objects ------------------------------
     loader = DataLoader(UnsupervisedWaveformDataset(collate=collate), batch_size=None, sampler=sampler, num_workers=num_workers)
 
-    def save(writer, batch_cuts, host: np.ndarray, frames: List[int], template: Dict, frags):
+    def save(writer, batch_cuts, pending, frames: List[int], template: Dict, frags):
         check_frames(batch_cuts, frames)
+        host = pending.wait()
         stored = [i for i, c in enumerate(batch_cuts) if not isinstance(c, PaddingCut)]
         bounds = np.concatenate([[0], np.cumsum(frames)])
         if hasattr(writer, "write_packed") and len(stored) == len(batch_cuts):
@@ -724,7 +762,10 @@ def compute_and_store_features_batch(
                 keys[i] = writer.write(batch_cuts[i].id, host[int(bounds[i]) : int(bounds[i + 1])])
         if hasattr(writer, "flush"):
             writer.flush()
-        return batch_cuts, frames, keys, int(host.shape[1]), template  # -> write_manifests, on the second background thread
+        num_features = int(host.shape[1])
+        del host
+        pending.release()
+        return batch_cuts, frames, keys, num_features, template  # -> write_manifests, on the second background thread
 
     def write_manifests(batch_cuts, frames: List[int], keys: List[str], num_features: int, template: Dict) -> None:
         dicts = [None if isinstance(c, PaddingCut) else _features_dict(template, c, frames[i], keys[i]) for i, c in enumerate(batch_cuts)]

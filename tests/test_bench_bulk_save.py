@@ -28,6 +28,8 @@ def test_bulk_save_workload_writes_what_the_extractor_computes(monkeypatch, stri
     first = w.last_root
     w.clear()
     w.step()
+    w._dropper.shutdown(wait=True)  # (finished runs are deleted on a helper thread, off the timed path)
+    w._dropper = None
     assert not os.path.exists(first) and os.path.isdir(w.last_root)  # one run on disk at a time
     st = w.stats
     assert st["manifest_lines"] == 120 and st["archive_bytes"] == 120 * 100 * 80 * 4 and st["extract_s"] > 0 and st["save_s"] > 0 and st["manifest_s"] > 0

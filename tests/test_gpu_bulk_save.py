@@ -77,3 +77,64 @@ def test_appending_resumes_behind_the_existing_rows(tmp_path):
     for key, x in zip(ka + kb, a + b):
         assert np.array_equal(r.read(key), ex.extract(x, 16000))
     assert int(kb[0].split(":")[0]) == sum(int(k.split(":")[1]) for k in ka) * 80 * 4
+
+
+@pytest.mark.parametrize("kind,pcm,half,zero_pad", [("fbank", False, False, False), ("fbank", True, True, False), ("mfcc", False, True, False),
+                                                    ("fbank", False, False, True), ("fbank", True, False, True)])
+def test_native_host_pipeline_equals_the_python_pipeline_bit_for_bit(kind, pcm, half, zero_pad):
+    """Round 5: hipfeat_host_pipeline_* (packing threads + chunked H2D / launch / D2H inside the library, asynchronous) hands back,
+    for every batch, exactly the matrix `_batch_features_on_host` (the Python pipeline) does -- float32 and int16 PCM inputs, float32
+    and binary16 results, both edge rules -- also with several batches in flight and results released out of order."""
+    cfg = {"edge_rule": "batch_zero_pad"} if zero_pad else {}
+    ex = (LA.HipFbank(LA.HipFbankConfig(**cfg)) if kind == "fbank" else LA.HipMfcc(LA.HipMfccConfig(**cfg)))
+    batches = _batches(11, 9) + [[(np.random.RandomState(1).rand(160000).astype(np.float32) - 0.5) for _ in range(60)]]  # + one 600 s batch
+    if pcm:
+        batches = [[(w * 32767).astype(np.int16) for w in waves] for waves in batches]
+    pend = []
+    for waves in batches:  # everything is submitted before anything is waited for (at most 10 results outstanding)
+        items = [torch.from_numpy(w) for w in waves[::2]] + list(waves[1::2])  # tensors and numpy arrays mixed
+        order = list(range(0, len(waves), 2)) + list(range(1, len(waves), 2))
+        p, frames = S._batch_features_pending(ex, items, 16000, None, half=half)
+        assert p.ticket is not None, "the native pipeline must be the path taken on a GPU"
+        pend.append((p, frames, [waves[i] for i in order]))
+    for p, frames, waves in reversed(pend):  # waited for and released in reverse order
+        got = p.wait().copy()
+        p.release()
+        want, wframes = S._batch_features_on_host(ex, [torch.from_numpy(w) for w in waves], 16000, None, half=half)
+        assert list(frames) == list(wframes) and got.dtype == want.dtype and got.shape == want.shape
+        assert np.array_equal(got, want)
+    # a released buffer is reused: steady state allocates nothing new
+    pipe = ex._native_pipe()
+    for _ in range(3):
+        p, _ = S._batch_features_pending(ex, [torch.from_numpy(w) for w in batches[-1]], 16000, None, half=half)
+        p.wait()
+        p.release()
+    with pytest.raises(ValueError):  # too short: worded by the library, raised at submit
+        S._batch_features_pending(ex, [torch.zeros(100)], 16000, None)
+    ex2 = ex.to("cuda:0")  # moving the extractor drops the pipeline with the plan
+    assert ex2._native_pipe() is not pipe
+
+
+def test_native_archive_and_lines_behind_the_native_pipeline(tmp_path):
+    """The whole native save path on the GPU box: submit -> wait -> hipfeat_archive_append (3 stripes) -> hipfeat_manifest_lines; what the
+    lines point at is, per cut, exactly what `extract` computes."""
+    import json
+
+    ex = LA.HipFbank()
+    batches = _batches(21, 6)
+    lines = []
+    with S.NativeArchive(tmp_path / "feats", mode="w", stripes=3) as ar:
+        for bi, waves in enumerate(batches):
+            p, frames = S._batch_features_pending(ex, [torch.from_numpy(w) for w in waves], 16000, None)
+            file_of, byte_off = ar.append(p.wait(), np.asarray(frames))
+            p.release()
+            heads = [f'{{"id": "b{bi}c{i}", "storage_path": "'.encode() for i in range(len(waves))]
+            tails = [b'"}'] * len(waves)
+            blob = ar.lines(heads, tails, np.asarray(frames), np.asarray(frames), file_of, byte_off, 80)
+            lines += [json.loads(ln) for ln in blob.decode().splitlines()]
+        paths = [str(q) for q in ar.paths]
+    flat = [w for waves in batches for w in waves]
+    assert len(lines) == len(flat) and {d["storage_path"] for d in lines} == set(paths)
+    readers = {q: S.HipArchiveReader(q) for q in paths}
+    for d, w in zip(lines, flat):
+        assert np.array_equal(readers[d["storage_path"]].read(d["storage_key"]), ex.extract(w, 16000))
