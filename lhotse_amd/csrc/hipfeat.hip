@@ -2869,6 +2869,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_archive_open(const char* const* h_
     a->files.fds.push_back(fd);
     a->files.size.push_back((int64_t)end);
   }
+  if (num_files > 1) a->files.pool = new hipfeat::WorkPool(num_files - 1);
   *out = a;
   return HIPFEAT_OK;
 }
@@ -2881,7 +2882,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_archive_append(hipfeat_archive* a,
     if (h_num_frames[i] < 0) return fail(HIPFEAT_ERR_INVALID, "cut %lld: %lld frames", (long long)i, (long long)h_num_frames[i]);
   std::lock_guard<std::mutex> lk(a->mu);
   int errfile = 0;
-  const int e = a->files.append(static_cast<const char*>(h_matrix), batch, h_num_frames, (int64_t)cols * bytes_per_value, h_file, h_byte_offset, &errfile);
+  const int e = a->files.append(static_cast<const char*>(h_matrix), batch, h_num_frames, (int64_t)cols * bytes_per_value, bytes_per_value == 2, h_file,
+                                h_byte_offset, &errfile);
+  if (e == hipfeat::kErrNotFinite16)
+    return fail(HIPFEAT_ERR_INVALID, "the batch holds values that are not finite in binary16 (|x| > 65504, inf or nan): nothing was written");
   if (e) return fail(HIPFEAT_ERR_INVALID, "write to archive file %d failed: %s", errfile, strerror(e));
   return HIPFEAT_OK;
 }
@@ -2895,6 +2899,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_archive_close(hipfeat_archive* a) 
   int bad = 0;
   for (int fd : a->files.fds)
     if (::close(fd) != 0) bad = errno;
+  delete a->files.pool;
   delete a;
   return bad ? fail(HIPFEAT_ERR_INVALID, "closing an archive file failed: %s", strerror(bad)) : HIPFEAT_OK;
 }

@@ -9,10 +9,14 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -20,6 +24,86 @@
 #include <unistd.h>
 
 namespace hipfeat {
+
+// A few persistent host threads that run `n` indexed jobs per call; the calling thread takes its share.  (Starting a std::thread per
+// batch costs 50-100 us each -- as much as the work itself for a 600 s batch cut eight ways.)
+class WorkPool {
+ public:
+  explicit WorkPool(int workers) {
+    for (int i = 0; i < workers; ++i) th_.emplace_back([this] { loop(); });
+  }
+  ~WorkPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  WorkPool(const WorkPool&) = delete;
+  WorkPool& operator=(const WorkPool&) = delete;
+  int workers() const { return (int)th_.size(); }
+  // fn(i) for every i in [0, n), spread over the workers and the caller; returns when all have finished.  One run at a time.
+  void run(size_t n, const std::function<void(size_t)>& fn) {
+    if (n == 0) return;
+    if (n == 1 || th_.empty()) {
+      for (size_t i = 0; i < n; ++i) fn(i);
+      return;
+    }
+    std::lock_guard<std::mutex> one(run_mu_);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn;
+      n_ = n;
+      next_.store(0, std::memory_order_relaxed);
+      active_ = (int)th_.size();
+      ++gen_;
+    }
+    cv_.notify_all();
+    drain(fn, n);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] { return active_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void drain(const std::function<void(size_t)>& fn, size_t n) {
+    for (;;) {
+      const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n) return;
+      fn(i);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(size_t)>* fn;
+      size_t n;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        fn = fn_;
+        n = n_;
+      }
+      drain(*fn, n);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--active_ == 0) done_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(size_t)>* fn_ = nullptr;
+  size_t n_ = 0;
+  std::atomic<size_t> next_{0};
+  int active_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
 
 // decimal digits of a non-negative int64 into `dst`; returns the number of characters written
 static inline int put_i64(char* dst, int64_t v) {
@@ -109,45 +193,57 @@ static int pwrite_all(int fd, const char* data, int64_t bytes, int64_t offset) {
 // of about equal bytes and run k is appended to file k by its own thread.  One file = one inode = one set of page-cache locks: writers
 // to DIFFERENT files do not serialise on them, which is what bounds a single tmpfs / page-cache file to one writer's copy rate
 // (tools/tmpfs_write_probe.py).  With one file it is one pwrite on the calling thread.
+constexpr int kErrNotFinite16 = -16;  // append(): a binary16 value of the batch is inf / nan
+
 struct ArchiveFiles {
   std::vector<int> fds;
   std::vector<int64_t> size;  // bytes in file k
+  WorkPool* pool = nullptr;   // nfiles - 1 persistent writer threads (the caller writes run 0)
 
-  // -> 0, or the errno of the first failing write (errfile = its index).  file_of / byte_off: where every cut's rows went.
-  int append(const char* data, int64_t batch, const int64_t* frames, int64_t row_bytes, int32_t* file_of, int64_t* byte_off, int* errfile) {
+  // -> 0, the errno of the first failing write (errfile = its index), or kErrNotFinite16.  file_of / byte_off: where every cut's rows
+  // went.  check_f16: the rows are binary16 and must be finite (|x| <= 65504): every writer scans its own run before writing it.
+  int append(const char* data, int64_t batch, const int64_t* frames, int64_t row_bytes, bool check_f16, int32_t* file_of, int64_t* byte_off, int* errfile) {
     const int nf = (int)fds.size();
     int64_t total = 0;
     for (int64_t i = 0; i < batch; ++i) total += frames[i] * row_bytes;
     // runs of whole cuts: cut i goes to file k while the bytes in front of it are below (k + 1) / nf of the batch
-    std::vector<int64_t> first(nf + 1, batch), start_byte(nf + 1, total);
+    std::vector<int64_t> start_byte(nf + 1, total);
     int64_t acc = 0;
     int k = 0;
-    first[0] = 0;
     start_byte[0] = 0;
     for (int64_t i = 0; i < batch; ++i) {
       while (k + 1 < nf && acc * nf >= total * (int64_t)(k + 1)) {
         ++k;
-        first[k] = i;
         start_byte[k] = acc;
       }
       if (file_of) file_of[i] = k;
       if (byte_off) byte_off[i] = size[k] + (acc - start_byte[k]);
       acc += frames[i] * row_bytes;
     }
-    for (int j = k + 1; j < nf; ++j) {  // (fewer cuts than files: the remaining runs are empty)
-      first[j] = batch;
-      start_byte[j] = total;
-    }
+    for (int j = k + 1; j < nf; ++j) start_byte[j] = total;  // (fewer cuts than files: the remaining runs are empty)
     std::vector<int> rc(nf, 0);
-    std::vector<std::thread> th;
-    auto run = [&](int f) {
+    if (check_f16) {  // nothing is written unless the whole batch is finite
+      auto scan = [&](size_t f) {
+        const uint16_t* v = reinterpret_cast<const uint16_t*>(data + start_byte[f]);
+        const int64_t n = (start_byte[f + 1] - start_byte[f]) / 2;
+        unsigned worst = 0;
+        for (int64_t i = 0; i < n; ++i) worst = std::max<unsigned>(worst, v[i] & 0x7FFFu);
+        if (worst >= 0x7C00u) rc[f] = kErrNotFinite16;
+      };
+      if (pool) pool->run((size_t)nf, scan);
+      else for (int f = 0; f < nf; ++f) scan((size_t)f);
+      for (int f = 0; f < nf; ++f)
+        if (rc[f]) {
+          *errfile = f;
+          return rc[f];
+        }
+    }
+    auto write = [&](size_t f) {
       const int64_t n = start_byte[f + 1] - start_byte[f];
       if (n > 0) rc[f] = pwrite_all(fds[f], data + start_byte[f], n, size[f]);
     };
-    for (int f = 1; f < nf; ++f)
-      if (start_byte[f + 1] > start_byte[f]) th.emplace_back(run, f);
-    run(0);
-    for (auto& t : th) t.join();
+    if (pool) pool->run((size_t)nf, write);
+    else for (int f = 0; f < nf; ++f) write((size_t)f);
     for (int f = 0; f < nf; ++f) {
       if (rc[f]) {
         *errfile = f;

@@ -517,12 +517,13 @@ class _HostPipeline:
 
 class PendingFeatures:
     """The packed (rows, F) feature matrix of one batch on its way to (or already in) host memory.  ``wait()`` -> the numpy matrix
-    (a view of page-locked memory owned by the pipeline when ``ticket`` is set: valid until ``release()``)."""
+    (a view of page-locked memory owned by the pipeline when ``ticket`` is set: valid until ``release()``).  The object keeps the
+    batch's waveforms alive until the pipeline thread has packed them."""
 
-    __slots__ = ("_pipe", "ticket", "_array", "frames")
+    __slots__ = ("_pipe", "ticket", "_array", "frames", "_keep")
 
-    def __init__(self, pipe, ticket, array: np.ndarray, frames: np.ndarray):
-        self._pipe, self.ticket, self._array, self.frames = pipe, ticket, array, frames
+    def __init__(self, pipe, ticket, array: np.ndarray, frames: np.ndarray, keep=None):
+        self._pipe, self.ticket, self._array, self.frames, self._keep = pipe, ticket, array, frames, keep
 
     @property
     def shape(self):
@@ -530,14 +531,24 @@ class PendingFeatures:
 
     def wait(self) -> np.ndarray:
         if self._pipe is not None and self.ticket is not None:
-            self._pipe._wait(self.ticket)
+            try:
+                self._pipe._wait(self.ticket)
+            finally:
+                self._keep = None  # (the library reports a batch only after it is done with the caller's buffers, also on failure)
         return self._array
 
     def release(self) -> None:
         if self._pipe is not None and self.ticket is not None:
             t, self.ticket = self.ticket, None
             self._array = None
-            self._pipe._release(t)
+            self._pipe._release(t)  # (waits for the pipeline thread to be done with the waveforms first)
+            self._keep = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class NativeHostPipeline:
@@ -568,13 +579,14 @@ class NativeHostPipeline:
             if _is_pcm16(x) != pcm:
                 raise TypeError("a batch must be all float32 or all int16 PCM")
             if isinstance(x, torch.Tensor):
-                x = x.detach().contiguous()
+                if not x.is_contiguous():
+                    x = x.contiguous()
                 ptrs[i] = x.data_ptr()
             else:
                 x = np.ascontiguousarray(x)
                 ptrs[i] = x.ctypes.data
-            keep.append(x)  # (alive until submit() has packed them)
-            lens[i] = int(x.shape[0])
+            keep.append(x)  # (alive until the pipeline thread has packed them: PendingFeatures holds the list)
+            lens[i] = x.shape[0]
         frames = np.empty(B, dtype=np.int64)
         res = np.zeros(3, dtype=np.int64)  # h_out pointer, rows, ticket
         a = res.ctypes.data
@@ -587,7 +599,7 @@ class NativeHostPipeline:
         item = 2 if half else 4
         buf = (ctypes.c_char * (rows * F * item)).from_address(int(res[0]))
         arr = np.frombuffer(buf, dtype=np.float16 if half else np.float32).reshape(rows, F)
-        return PendingFeatures(self, int(res[2]), arr, frames)
+        return PendingFeatures(self, int(res[2]), arr, frames, keep)
 
     def _wait(self, ticket: int) -> None:
         st = self._waitf(self.handle, int(ticket))

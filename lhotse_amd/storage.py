@@ -358,15 +358,15 @@ class NativeArchive:
         with np.errstate(over="ignore"):
             matrix = np.ascontiguousarray(matrix, dtype=self.np_dtype)  # (no copy for what the driver hands over: the device converted already)
         assert matrix.ndim == 2, matrix.shape
-        if self.item == 2 and matrix.size and int((matrix.view(np.uint16) & 0x7FFF).max()) >= 0x7C00:  # as write_packed
-            raise ValueError(f"{self.name}: the batch holds values that are not finite in binary16 (|x| > 65504, inf or nan); this storage is "
-                             "meant for log-domain features -- use 'hip_archive' (float32) for linear-domain ones")
         frames = np.ascontiguousarray(frames, dtype=np.int64)
         assert int(frames.sum()) == matrix.shape[0], (int(frames.sum()), matrix.shape)
         file_of, byte_off = np.zeros(len(frames), dtype=np.int32), np.zeros(len(frames), dtype=np.int64)
         st = self._append(self.handle, matrix.ctypes.data, len(frames), _lib.addr(frames), int(matrix.shape[1]), self.item, _lib.addr(file_of), _lib.addr(byte_off))
         if st != 0:
-            raise _lib.HipFeatError(int(st), self.lib.last_error())
+            msg = self.lib.last_error()
+            if "not finite in binary16" in msg:  # (checked by the writer threads on their own runs, before anything is written: as write_packed)
+                raise ValueError(f"{self.name}: {msg}; this storage is meant for log-domain features -- use 'hip_archive' (float32) for linear-domain ones")
+            raise _lib.HipFeatError(int(st), msg)
         return file_of, byte_off
 
     def lines(self, heads: Sequence[bytes], tails: Sequence[bytes], frames: np.ndarray, expected: Optional[np.ndarray], file_of: np.ndarray,
