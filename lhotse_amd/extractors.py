@@ -789,12 +789,15 @@ class _HipExtractor(FeatureExtractor):
 
     def _native_pipe(self) -> "NativeHostPipeline":
         """The library-side host pipeline of this extractor's plan (created on first use; dropped with the plan)."""
+        plan = self.plan  # (before the lock: creating the plan takes the same, non-reentrant, lock)
         pipe = self.__dict__.get("_native_pipeline")
-        if pipe is None or pipe.plan is not self.plan:
+        if pipe is None or pipe.plan is not plan:
             with self._lazy_lock():
                 pipe = self.__dict__.get("_native_pipeline")
-                if pipe is None or pipe.plan is not self.plan:
-                    pipe = self.__dict__["_native_pipeline"] = NativeHostPipeline(self.plan)
+                if pipe is None or pipe.plan is not plan:
+                    if pipe is not None:
+                        pipe.close()
+                    pipe = self.__dict__["_native_pipeline"] = NativeHostPipeline(plan)
         return pipe
 
     def submit_host_items(self, items: Sequence[ArrayLike], sampling_rate: int, half: bool = False) -> "PendingFeatures":
