@@ -681,7 +681,7 @@ class BulkSave:
 
         self.torch, self.np, self.S, self.dev, self.rank = torch, np, S, dev, rank
         NB = self.NB = args.cuts or self.default_cuts
-        self.stripes = max(1, int(getattr(args, "stripes", 1) or 1))
+        self.stripes = max(1, int(getattr(args, "stripes", 8) or 8))
         self.ex = lhotse_amd.HipFbank(lhotse_amd.HipFbankConfig(device=f"cuda:{dev.index}"))
         self.plan = self.ex.plan
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
@@ -893,8 +893,14 @@ class BulkSave:
     def extra(self, args):
         """The other entry forms / storages and round 4's per-cut route, a few passes each, with the stage split of every variant."""
         out = {}
-        for dtype, storage, route in (("float32", "hip_archive", "native"), ("int16", "hip_archive", "native"), ("float32", "hip_archive_f16", "native"),
-                                      ("int16", "hip_archive_f16", "native"), ("float32", "hip_archive", "per_cut"), ("int16", "hip_archive_f16", "per_cut")):
+        keep_stripes = self.stripes
+        for dtype, storage, route, stripes in (("float32", "hip_archive", "native", keep_stripes), ("int16", "hip_archive", "native", keep_stripes),
+                                               ("float32", "hip_archive_f16", "native", keep_stripes), ("int16", "hip_archive_f16", "native", keep_stripes),
+                                               ("float32", "hip_archive", "native", 1), ("int16", "hip_archive_f16", "native", 1),
+                                               ("float32", "hip_archive", "per_cut", 1), ("int16", "hip_archive_f16", "per_cut", 1)):
+            if route == "native" and stripes == 1 and keep_stripes == 1:
+                continue
+            self.stripes = stripes
             self._drop(self._one_pass(dtype, storage, {}, route))  # warm
             st = {}
             t0 = time.perf_counter()
@@ -902,7 +908,7 @@ class BulkSave:
                 self._drop(self._one_pass(dtype, storage, st, route))
             dt = time.perf_counter() - t0
             cuts = 3 * self.units
-            out[f"{dtype}->{storage}" + ("" if route == "native" else " (round 4's per-cut Python route)")] = {
+            out[f"{dtype}->{storage}" + (f" ({stripes} file{'s' if stripes > 1 else ''})" if route == "native" else " (round 4's per-cut Python route, 1 file)")] = {
                 "cuts_per_s": round(cuts / dt, 1), "archive_MB_per_s": round(st["archive_bytes"] / dt / 1e6, 1),
                 "h2d_MB_per_s": round(cuts * SAMPLES_PER_CUT * (2 if dtype == "int16" else 4) / dt / 1e6, 1),
                 "manifest_bytes_per_cut": round(st["manifest_bytes"] / cuts, 1),
@@ -912,6 +918,7 @@ class BulkSave:
                 "binds": max((st["extract_s"], "the calling thread (packing into page-locked staging + enqueueing)"), (st["save_s"], "archive thread"),
                              (st.get("device_wait_s", 0.0), "PCIe / device (the archive thread waits for the batch's download)"), (st["manifest_s"], "manifest thread"))[1],
             }
+        self.stripes = keep_stripes
         out["fragments_per_s_per_process"] = round(self.fragments_per_s, 1)
         out["stripes"] = self.stripes
         out["what"] = ("3 passes per variant after one warm-up; shares are of wall time: the calling thread extracts (pack to pinned + H2D + kernel + D2H), "
@@ -1315,7 +1322,8 @@ def main():
     ap.add_argument("--prefetch", type=int, default=1, help="onthefly: mini-batches per call (a loader that prefetches K packs them into one arena and gets K dense tensors "
                     "from ONE pair of launches); default 1")
     ap.add_argument("--streams", type=int, default=3, help="onthefly: streams the calls alternate over (default 3)")
-    ap.add_argument("--stripes", type=int, default=1, help="bulk_save: files the archive is striped over (one writer thread each)")
+    ap.add_argument("--stripes", type=int, default=8, help="bulk_save: files the archive is striped over (one writer thread each; default 8 -- "
+                    "one page-cache file takes ONE writer's copy rate, ~4 GB/s on the box of profiles/r05_tmpfs_write_probe.json; the single-file rate is in `extra`)")
     ap.add_argument("--route", default="pair", choices=["pair", "per_factor"], help="onthefly: `pair` = the two-launch mini-batch (default), `per_factor` = round 3's route")
     ap.add_argument("--total-cuts", type=int, default=0, help="fbank16k only: STRONG scaling (BASELINE configs[2]: 100000): this many cuts in total per step, "
                     "sharded round-robin over the ranks (same global corpus for every N); default 0 = weak scaling, --cuts per GPU")

@@ -456,6 +456,7 @@ def compute_and_store_features_sharded(
     world: int = None,
     barrier_timeout: float = 3600.0,
     numa_bind: bool = True,
+    archive_stripes: int = 1,
 ):
     """Feature extraction of one CutSet over the GPUs of a node: the multi-GPU form of ``compute_and_store_features_batch``.
 
@@ -466,6 +467,8 @@ def compute_and_store_features_sharded(
     batch driver on GPU ``LOCAL_RANK`` into its own storage ``<storage_path>/feats-r`` and manifest ``cuts-r.jsonl.gz`` (per-shard
     resume included: an interrupted run continues where each rank stopped), and after a barrier rank 0 merges the shard manifests into
     ``manifest_path`` in input order.  NO collective touches the data path; the barrier is the only communication.
+
+    ``archive_stripes``: files per rank's ``hip_archive`` (``feats-r.hfa``, ``feats-r.1.hfa``, ...; see ``compute_and_store_features_batch``).
 
     ``numa_bind`` (default on, for world > 1): before the extractor touches its GPU -- i.e. before any pinned staging buffer exists and
     before the packing / save threads start -- the rank is pinned to the CPUs of its GPU's NUMA node (``bind_to_gpu_numa_node``;
@@ -535,7 +538,7 @@ def compute_and_store_features_sharded(
     try:
         out = compute_and_store_features_batch(mine, extractor, sub_storage, manifest_path=sub_manifest, batch_duration=batch_duration,
                                                num_workers=num_workers, collate=collate, augment_fn=augment_fn, storage_type=storage_type,
-                                               overwrite=overwrite)
+                                               overwrite=overwrite, archive_stripes=archive_stripes)
         meet.barrier("extracted")
         if rank == 0:
             out = combine_shard_manifests(cuts, manifest_path, [shard_paths(storage_path, manifest_path, r)[1] for r in range(world)], owner)
