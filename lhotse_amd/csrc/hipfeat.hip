@@ -691,6 +691,10 @@ static hipfeat_status setup_fft1024c(hipfeat_plan* p, const float* h_window, con
   // fixed-schedule instances: 12 waves per workgroup, the span buffer aliases the exchange / power region (kernel_fft1024c.hpp)
   int fixed = fft1024c_fixed_id(nrows, sch.nsets, sch.steps, !c.remove_dc_offset && c.preemph_coeff == 0.0f);
   if (fixed && p->c_xs_floats > kWRegion) fixed = 0;
+  if (fixed >= 1 && fixed <= 3 && (librosa || c.use_fft_mag)) fixed = 0;  // the Kaldi instances have |X|^2, ln and Kaldi's edges compiled in
+  // ... and the default frame geometry at 24 / 32 / 22.05 kHz with 80 filters (kernel_fft1024c.hpp)
+  if (fixed >= 1 && fixed <= 3 && !(M == 80 && !c.snip_edges && ((fixed == 1 && N == 600 && shift == 240) || (fixed == 2 && N == 800 && shift == 320) || (fixed == 3 && N == 551 && shift == 220))))
+    fixed = 0;
   const int waves = fixed ? kWWavesFixed : kWWaves;
   const size_t lds = ((size_t)p->c_shared_floats + (size_t)waves * (fixed ? kWRegion : p->c_xs_floats + kWRegion)) * sizeof(float);
   if (lds > 160 * 1024 || (p->c_xs_floats >> 8) > 10) return HIPFEAT_OK;
@@ -1134,14 +1138,21 @@ static hipfeat_status setup_fft2048c(hipfeat_plan* p, const float* h_window, con
   // runs 12 waves per workgroup (3 waves/SIMD) without a span prefetch, the span buffer aliasing the exchange / power region (at 48 kHz that
   // layout measured 3 % slower than 8 waves with the prefetch)
   const bool fixed = sch.nsets == 3 && sch.steps[0] == 52 && sch.steps[1] == 28 && sch.steps[2] == 16 && sch.step0[1] == 52 && sch.step0[2] == 80 &&
-                     (odd ? nrows == 18 : nrows == 19) && !route_env("HIPFEAT_NO_FIXED_SCHEDULE");
-  const bool w12 = fixed && odd && p->c_xs_floats <= kXRegion && ((size_t)p->c_shared_floats + (size_t)kXWavesFixed * kXRegion) * sizeof(float) <= 160 * 1024;
+                     (odd ? nrows == 18 : nrows == 19) && !librosa && !c.use_fft_mag && M == 80 &&
+                     (odd ? (N == 1102 && shift == 441) : (N == 1200 && shift == 480)) && !c.snip_edges &&  // the geometry the instances have compiled in (kernel_fft2048c.hpp)
+                     !route_env("HIPFEAT_NO_FIXED_SCHEDULE");
+  // (HIPFEAT_FFT2048_W12 = 1 / 0: routing switch, forces / forbids the 12-wave layout for either default -- same-call A/Bs)
+  const char* w12_env = route_env("HIPFEAT_FFT2048_W12");
+  const bool w12_want = w12_env ? w12_env[0] == '1' : odd;
+  const bool w12 = fixed && w12_want && p->c_xs_floats <= kXRegion && ((size_t)p->c_shared_floats + (size_t)kXWavesFixed * kXRegion) * sizeof(float) <= 160 * 1024;
   int waves = w12 ? kXWavesFixed : kXMaxWaves;
   auto lds_of = [&](int wv) { return ((size_t)p->c_shared_floats + (size_t)wv * (w12 ? kXRegion : p->c_xs_floats + kXRegion)) * sizeof(float); };
   while (waves > 0 && lds_of(waves) > 160 * 1024) --waves;
   if (waves < 4) return HIPFEAT_OK;
+  if (fixed && waves != (w12 ? kXWavesFixed : kXMaxWaves)) return HIPFEAT_OK;  // (cannot happen for the default geometry: its LDS image fits)
   const size_t lds = lds_of(waves);
-  const void* fn = fixed ? (odd ? (w12 ? fft2048c_entry<18, true, 52, 28, 16, true>() : fft2048c_entry<18, true, 52, 28, 16>()) : fft2048c_entry<19, false, 52, 28, 16>())
+  const void* fn = fixed ? (odd ? (w12 ? fft2048c_entry<18, true, 52, 28, 16, true>() : fft2048c_entry<18, true, 52, 28, 16>())
+                                : (w12 ? fft2048c_entry<19, false, 52, 28, 16, true>() : fft2048c_entry<19, false, 52, 28, 16>()))
                    : odd ? (nrows == 18 ? fft2048c_entry<18, true>() : fft2048c_entry<32, true>())
                          : (nrows == 19 ? fft2048c_entry<19, false>() : fft2048c_entry<32, false>());
   p->w_fixed = fixed ? 1 : 0;
@@ -1793,7 +1804,8 @@ static hipfeat_status launch(const hipfeat_plan* plan, const hipfeat_layout* lay
       else if (plan->nrows == 18) hipLaunchKernelGGL((fft2048c_kernel<18, true>), grid, block, plan->fast_lds_bytes, stream, fp);
       else hipLaunchKernelGGL((fft2048c_kernel<32, true>), grid, block, plan->fast_lds_bytes, stream, fp);
     } else {
-      if (plan->w_fixed) hipLaunchKernelGGL((fft2048c_kernel<19, false, 52, 28, 16>), grid, block, plan->fast_lds_bytes, stream, fp);
+      if (plan->w_fixed && plan->x_waves == kXWavesFixed) hipLaunchKernelGGL((fft2048c_kernel<19, false, 52, 28, 16, true>), grid, block, plan->fast_lds_bytes, stream, fp);
+      else if (plan->w_fixed) hipLaunchKernelGGL((fft2048c_kernel<19, false, 52, 28, 16>), grid, block, plan->fast_lds_bytes, stream, fp);
       else if (plan->nrows == 19) hipLaunchKernelGGL((fft2048c_kernel<19, false>), grid, block, plan->fast_lds_bytes, stream, fp);
       else hipLaunchKernelGGL((fft2048c_kernel<32, false>), grid, block, plan->fast_lds_bytes, stream, fp);
     }

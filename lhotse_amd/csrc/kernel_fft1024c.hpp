@@ -98,36 +98,55 @@ __global__ __launch_bounds__(64 * (S0 != 0 ? kWWavesFixed : kWWaves), (S0 != 0 ?
   }
   const CutDesc cd = p.cuts[cut];
   const float* __restrict__ w = p.wave + cd.wave_off;
-  const int N = p.N, shift = p.shift;
+  // round 5, experiment 2 (see kernel_fft2048c.hpp): the fixed-schedule Kaldi instances are the 80-filter defaults at 24 kHz
+  // <20, 24,16,8> (600-sample frames, hop 240), 32 kHz <26, 24,16,8> (800 / 320) and 22.05 kHz <20, 24,24,8> (551 / 220) and nothing
+  // else (hipfeat.hip selects them on exactly these numbers): frame geometry, span length and filter count are compile-time constants
+#ifdef HIPFEAT_ABL_RUNTIME_GEOMETRY
+  constexpr bool kGeo = false;
+#else
+  constexpr bool kGeo = kFixed && !PLAIN;
+#endif
+  constexpr int kGeoN = NROWS == 26 ? 800 : (S1 == 24 ? 551 : 600), kGeoShift = NROWS == 26 ? 320 : (S1 == 24 ? 220 : 240);
+  const int N = kGeo ? kGeoN : p.N, shift = kGeo ? kGeoShift : p.shift;
+  const int npad_left = kGeo ? (kGeoN - kGeoShift) / 2 : p.npad_left;
+  const int xs_floats = kGeo ? ((3 * kGeoShift + 32 * NROWS + 3) & ~3) : p.xs_floats;
+  const int M = kGeo ? 80 : p.M;
 
   for (int i = tid; i < p.shared_floats; i += 64 * kWv) smem[i] = p.shared_consts[i];
-  float* xs = smem + p.shared_floats + wv * (kPrefetch ? p.xs_floats + kWRegion : kWRegion);
-  float* myreg = kPrefetch ? xs + p.xs_floats : xs;  // (no prefetch: the span is dead once the samples are in registers, before the exchange)
+  float* xs = smem + p.shared_floats + wv * (kPrefetch ? xs_floats + kWRegion : kWRegion);
+  float* myreg = kPrefetch ? xs + xs_floats : xs;  // (no prefetch: the span is dead once the samples are in registers, before the exchange)
   const bool dc = (p.flags & F_REMOVE_DC) != 0;
+  // the fixed-schedule Kaldi instances (not PLAIN = the librosa default) serve Kaldi plans only: |X|^2 and the natural log are
+  // compile-time facts there (round 5, experiment 1; see kernel_fft2048c.hpp)
+  constexpr bool kKaldiOnly = kFixed && !PLAIN;
+#ifdef HIPFEAT_ABL_RUNTIME_MAG
   const bool mag = (p.flags & F_FFT_MAG) != 0;
-  const float log_scale = (p.flags & F_LOG10) ? 0.30102999566398120f : 0.69314718055994531f;  // log2 -> log10 / ln
+#else
+  const bool mag = kKaldiOnly ? false : (p.flags & F_FFT_MAG) != 0;
+#endif
+  const float log_scale = (!kKaldiOnly && (p.flags & F_LOG10)) ? 0.30102999566398120f : 0.69314718055994531f;  // log2 -> log10 / ln
   const float inv_n = 1.0f / (float)N;
   const float c = p.preemph;
 
   auto stage_span = [&](int f0, unsigned lane4) {
-    const int64_t j0 = (int64_t)f0 * shift - p.npad_left;
-    if (j0 >= 0 && j0 + p.xs_floats <= cd.num_samples) {
+    const int64_t j0 = (int64_t)f0 * shift - npad_left;
+    if (j0 >= 0 && j0 + xs_floats <= cd.num_samples) {
       const char* src = reinterpret_cast<const char*>(w + j0);  // uniform
-      const int nfull = p.xs_floats >> 8;
+      const int nfull = xs_floats >> 8;
 #pragma unroll
       for (int ch = 0; ch < 10; ++ch) {
         if (ch < nfull)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)ch * 1024u + 4u * lane4)),
                                            (__attribute__((address_space(3))) void*)(xs + ch * 256), 16, 0, 0);
       }
-      if ((unsigned)nfull * 256u + lane4 < (unsigned)p.xs_floats)
+      if ((unsigned)nfull * 256u + lane4 < (unsigned)xs_floats)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)nfull * 1024u + 4u * lane4)),
                                          (__attribute__((address_space(3))) void*)(xs + nfull * 256), 16, 0, 0);
     } else {
-      if (p.flags & F_CENTER)  // torch.stft / librosa "reflect" padding (the edge sample is not repeated)
-        for (int i = (int)(lane4 >> 2); i < p.xs_floats; i += 64) xs[i] = load_sample_center(w, j0 + i, cd.num_samples);
+      if (!kKaldiOnly && (p.flags & F_CENTER))  // torch.stft / librosa "reflect" padding (the edge sample is not repeated)
+        for (int i = (int)(lane4 >> 2); i < xs_floats; i += 64) xs[i] = load_sample_center(w, j0 + i, cd.num_samples);
       else
-        for (int i = (int)(lane4 >> 2); i < p.xs_floats; i += 64) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
+        for (int i = (int)(lane4 >> 2); i < xs_floats; i += 64) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
     }
   };
 
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(64 * (S0 != 0 ? kWWavesFixed : kWWaves), (S0 != 0 ?
         mel4_reduce_floor(acc, m4, m8, p.mel_floor, val);  // fft_common.hpp: row_shr:4 / row_shr:8 multiply-adds, floor
 #pragma unroll
         for (int i = 0; i < 4; ++i) val[i] = __builtin_amdgcn_logf(val[i]) * log_scale;
-        if (col < p.M) mel4_store_saddr<4>(orow, (unsigned)col, p.out_stride, nf, val);
+        if (col < M) mel4_store_saddr<4>(orow, (unsigned)col, p.out_stride, nf, val);
       }
     }
     HFC_T(6);  // mel phase: operand reads, MFMAs, reduction, log, stores

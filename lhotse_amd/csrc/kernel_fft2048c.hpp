@@ -91,7 +91,6 @@ __global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nthreads = 64 * p.waves;
 
   const int blk = blockIdx.x;
   int cut, fb;
@@ -104,36 +103,55 @@ __global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 
   }
   const CutDesc cd = p.cuts[cut];
   const float* __restrict__ w = p.wave + cd.wave_off;
-  const int N = p.N, shift = p.shift;
+  // round 5, experiment 2: the fixed-schedule instances are the 80-filter Kaldi defaults at 44.1 kHz (ODD: 1102-sample frames, hop 441)
+  // and 48 kHz (1200 / 480) and nothing else (hipfeat.hip selects them on exactly these numbers): frame geometry, span length, waves
+  // per workgroup and filter count as compile-time constants free ~20 scalar registers (the kernel spills 44) and the scalar
+  // arithmetic that derives addresses from them every round
+#ifdef HIPFEAT_ABL_RUNTIME_GEOMETRY
+  constexpr bool kGeo = false;
+#else
+  constexpr bool kGeo = kFixed;
+#endif
+  const int N = kGeo ? (ODD ? 1102 : 1200) : p.N, shift = kGeo ? (ODD ? 441 : 480) : p.shift;
+  const int npad_left = kGeo ? (ODD ? 330 : 360) : p.npad_left;
+  const int xs_floats = kGeo ? (((ODD ? 441 : 480) + 64 * NROWS + 3) & ~3) : p.xs_floats;
+  const int nwaves = kGeo ? (W12 ? kXWavesFixed : kXMaxWaves) : p.waves;
+  const int M = kGeo ? 80 : p.M;
 
-  for (int i = tid; i < p.shared_floats; i += nthreads) smem[i] = p.shared_consts[i];
-  float* xs = smem + p.shared_floats + wv * (kPrefetch ? p.xs_floats + kXRegion : kXRegion);
-  float* myreg = kPrefetch ? xs + p.xs_floats : xs;  // (no prefetch: the span is dead once the samples are in registers, before the exchange)
+  for (int i = tid; i < p.shared_floats; i += 64 * nwaves) smem[i] = p.shared_consts[i];
+  float* xs = smem + p.shared_floats + wv * (kPrefetch ? xs_floats + kXRegion : kXRegion);
+  float* myreg = kPrefetch ? xs + xs_floats : xs;  // (no prefetch: the span is dead once the samples are in registers, before the exchange)
   const bool dc = (p.flags & F_REMOVE_DC) != 0;
+  // the fixed-schedule instances serve Kaldi plans only (hipfeat.hip: never librosa): |X|^2, natural log and Kaldi's edge rule are
+  // compile-time facts there -- 17 uniform branches around v_sqrt per round less (round 5, experiment 1)
+#ifdef HIPFEAT_ABL_RUNTIME_MAG
   const bool mag = (p.flags & F_FFT_MAG) != 0;
-  const float log_scale = (p.flags & F_LOG10) ? 0.30102999566398120f : 0.69314718055994531f;  // log2 -> log10 / ln
+#else
+  const bool mag = kFixed ? false : (p.flags & F_FFT_MAG) != 0;
+#endif
+  const float log_scale = (!kFixed && (p.flags & F_LOG10)) ? 0.30102999566398120f : 0.69314718055994531f;  // log2 -> log10 / ln
   const float inv_n = 1.0f / (float)N;
   const float c = p.preemph;
 
   auto stage_span = [&](int f0, unsigned lane4) {
-    const int64_t j0 = (int64_t)f0 * shift - p.npad_left;
-    if (j0 >= 0 && j0 + p.xs_floats <= cd.num_samples) {
+    const int64_t j0 = (int64_t)f0 * shift - npad_left;
+    if (j0 >= 0 && j0 + xs_floats <= cd.num_samples) {
       const char* src = reinterpret_cast<const char*>(w + j0);  // uniform
-      const int nfull = p.xs_floats >> 8;
+      const int nfull = xs_floats >> 8;
 #pragma unroll
       for (int ch = 0; ch < 10; ++ch) {
         if (ch < nfull)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)ch * 1024u + 4u * lane4)),
                                            (__attribute__((address_space(3))) void*)(xs + ch * 256), 16, 0, 0);
       }
-      if ((unsigned)nfull * 256u + lane4 < (unsigned)p.xs_floats)
+      if ((unsigned)nfull * 256u + lane4 < (unsigned)xs_floats)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((unsigned)nfull * 1024u + 4u * lane4)),
                                          (__attribute__((address_space(3))) void*)(xs + nfull * 256), 16, 0, 0);
     } else {
-      if (p.flags & F_CENTER)  // torch.stft / librosa "reflect" padding (the edge sample is not repeated)
-        for (int i = (int)(lane4 >> 2); i < p.xs_floats; i += 64) xs[i] = load_sample_center(w, j0 + i, cd.num_samples);
+      if (!kFixed && (p.flags & F_CENTER))  // torch.stft / librosa "reflect" padding (the edge sample is not repeated)
+        for (int i = (int)(lane4 >> 2); i < xs_floats; i += 64) xs[i] = load_sample_center(w, j0 + i, cd.num_samples);
       else
-        for (int i = (int)(lane4 >> 2); i < p.xs_floats; i += 64) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
+        for (int i = (int)(lane4 >> 2); i < xs_floats; i += 64) xs[i] = load_sample(w, j0 + i, cd.num_samples, cd.padded_len);
     }
   };
 
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 
   unsigned long long hfc_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hfc_last = __builtin_readcyclecounter();
 #endif
   for (int r = 0; r < p.rounds; ++r) {
-    const int f0 = first_frame + 2 * p.waves * r;
+    const int f0 = first_frame + 2 * nwaves * r;
     if (f0 >= cd.num_frames) break;
     const int nf = min(2, cd.num_frames - f0);
 
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 
         // the samples are in flight to registers; once they have arrived the buffer is free for the next round's span
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         HFC_T(0);  // sample, neighbour and window reads
-        if (kPrefetch && NROWS < 32 && r + 1 < p.rounds && f0 + 2 * p.waves < cd.num_frames) stage_span(f0 + 2 * p.waves, (unsigned)lane_o * 4u);
+        if (kPrefetch && NROWS < 32 && r + 1 < p.rounds && f0 + 2 * nwaves < cd.num_frames) stage_span(f0 + 2 * nwaves, (unsigned)lane_o * 4u);
         HFC_T(1);  // span request (LDS-DMA issue)
 
 #pragma unroll
@@ -234,7 +252,7 @@ __global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 
           asm volatile("" : "+v"(a[0].x), "+v"(a[31].y) : : "memory");  // not before the FFT's results exist (hipcc would hoist the loads)
 #pragma unroll
           for (int k1 = 1; k1 < 32; ++k1) twp[k1] = gt[k1 * 32];
-          if (r + 1 < p.rounds && f0 + 2 * p.waves < cd.num_frames) stage_span(f0 + 2 * p.waves, (unsigned)lane_o * 4u);
+          if (r + 1 < p.rounds && f0 + 2 * nwaves < cd.num_frames) stage_span(f0 + 2 * nwaves, (unsigned)lane_o * 4u);
         }
         if (kTwLate && !kPrefetch) {  // two bursts of 16: request, multiply, request, multiply
 #pragma unroll
@@ -413,7 +431,7 @@ __global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 
         mel4_reduce_floor(acc, m4, m8, p.mel_floor, val);  // fft_common.hpp: row_shr:4 / row_shr:8 multiply-adds, floor
         val[0] = __builtin_amdgcn_logf(val[0]) * log_scale;
         val[1] = __builtin_amdgcn_logf(val[1]) * log_scale;
-        if (col < p.M) mel4_store_saddr<2>(orow, (unsigned)col, p.out_stride, nf, val);
+        if (col < M) mel4_store_saddr<2>(orow, (unsigned)col, p.out_stride, nf, val);
       }
     }
     HFC_T(6);  // mel phase: operand reads, MFMAs, reduction, log, stores
