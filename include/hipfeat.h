@@ -60,7 +60,14 @@ typedef enum hipfeat_kind {
    * Implies: centred frames (frame t covers samples [t*shift - N/2, t*shift + N/2), torch.stft(center=True)),
    * "reflect" edges without repeating the edge sample, fft_length == frame_length (any size, direct DFT),
    * S / shift computed frames, log10(max(mel, mel_floor)) clamped to (per-cut max - 8), then (x + 4) / 4,
-   * and (S + shift/2) / shift output rows, the extra one (if any) all zeros.  window / mel as for HIPFEAT_FBANK. */
+   * and (S + shift/2) / shift output rows, the extra one (if any) all zeros.  window / mel as for HIPFEAT_FBANK.
+   * MEMORY-MODEL NOTE (gfx950 only, by construction of this library): the per-cut clamp is finished by whichever workgroup of the
+   * launch completes the cut last; the hand-off between workgroups uses agent-scope write-through (sc1) stores + vmcnt(0) in front
+   * of a relaxed agent-scope counter increment, and sc1 loads behind it -- the ordering the gfx950 memory pipeline gives, NOT a
+   * release / acquire pair of the HIP memory model (that pair costs an L2 write-back + invalidate per workgroup: 1.9 -> 12.7 ms per
+   * 4000 cuts, measured in round 3).  The library is built for --offload-arch=gfx950 alone and refuses other devices at plan creation,
+   * so no caller can meet this path on hardware where the assumption does not hold; a launch that faults leaves the per-cut counters
+   * of its layout armed -- destroy the layout (or plan) after a HIPFEAT_ERR_HIP from a Whisper extraction instead of re-using it. */
   HIPFEAT_WHISPER = 4,
   /* librosa-style log-mel (lhotse/features/librosa_fbank.py:66-137): the arithmetic of HIPFEAT_FBANK (set use_fft_mag = 1
    * for librosa's |X|) on centred frames with "reflect" edges (librosa.stft center=True, pad_mode="reflect"), log10 instead of

@@ -1309,6 +1309,13 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_plan_create(const hipfeat_config* 
     delete p;
     return fail(HIPFEAT_ERR_HIP, "device %d not available (%d HIP devices visible)", device, ndev);
   }
+  {  // the kernels are gfx950 code objects and lean on gfx950's memory pipeline (hipfeat.h, HIPFEAT_WHISPER): any other device is refused here
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      delete p;
+      return fail(HIPFEAT_ERR_UNSUPPORTED, "device %d is not a gfx950 (MI355X-class) GPU: libhipfeat is built for that architecture alone", device);
+    }
+  }
   DeviceGuard g(device);
   hipfeat_status st = HIPFEAT_OK;
   auto bail = [&](hipfeat_status s) {

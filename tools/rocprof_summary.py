@@ -18,12 +18,16 @@ def main(path):
                   max(sgpr_count), max(lds_size), max(scratch_size), max(grid_x), max(workgroup_x)
            from kernels where name like '%hipfeat%' group by name"""
     print("\n# hipfeat kernels: per-dispatch resources")
+    print("# (registers: this rocprofv3 reports HALF of a wave64 kernel's allocation on gfx950 -- it applies the 4-register granule to the")
+    print("#  kernel descriptor's granulated count, the hardware allocates in granules of 8: 126 VGPRs in the build -> 128 allocated -> 64 here;")
+    print("#  143 -> 72, 161 -> 84, 181 -> 92, checked against -Rpass-analysis=kernel-resource-usage on six instances.  `registers` below is")
+    print("#  2 x (vgpr + agpr) of the trace = the allocation that decides occupancy: waves/SIMD = floor(512 / registers).)")
     for r in c.execute(q):
+        regs = 2 * (int(r[5] or 0) + int(r[6] or 0))
         print(
             f"{r[0][:80]}\n   dispatches={r[1]} avg={r[2]/1e3:.2f}us min={r[3]/1e3:.2f}us max={r[4]/1e3:.2f}us "
-            f"vgpr={r[5]} agpr={r[6]} sgpr={r[7]} lds={r[8]}B scratch={r[9]} grid={r[10]} wg={r[11]}"
+            f"registers={regs} ({512 // regs if regs else '?'} waves/SIMD by registers; trace fields vgpr={r[5]} agpr={r[6]}) sgpr={r[7]} lds={r[8]}B scratch={r[9]} grid={r[10]} wg={r[11]}"
         )
-
 
 if __name__ == "__main__":
     main(sys.argv[1])
