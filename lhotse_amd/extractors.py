@@ -559,7 +559,9 @@ class NativeHostPipeline:
 
     def __init__(self, plan, copy_threads: Optional[int] = None):
         self.plan, self.lib = plan, plan.lib
-        threads = copy_threads or max(2, min(12, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)) // 4))
+        # copy threads: HIPFEAT_COPY_THREADS, else a quarter of the CPUs this process may run on, 2 ... 12 (profiles/r05_copy_threads.txt)
+        env = os.environ.get("HIPFEAT_COPY_THREADS")
+        threads = copy_threads or (int(env) if env else max(2, min(12, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)) // 4)))
         h = np.zeros(1, dtype=np.uint64)
         self.handle = 0
         self.lib.check("hipfeat_host_pipeline_create", plan.handle, int(threads), _lib.addr(h))

@@ -117,7 +117,7 @@ def test_full_size_properties():
     # (oracle parity of these and four other sets of full-size cuts: test_headline_parity_multi_seed)
 
 
-HEADLINE_INPUTS = ["bench", "cpu0", 1, 2, 3]
+HEADLINE_INPUTS = ["bench", "cpu0", 1, 2, 3] + [f"bench_rank{r}" for r in range(1, 8)]  # bench_rank<r>: rank r's sample in the driver's 8-GPU run
 
 
 def _headline_cuts(which):
@@ -125,13 +125,14 @@ def _headline_cuts(which):
     seed 1234, 10 000 cuts filled 500 at a time, cut indices RandomState(4321)); "cpu0" = the CPU-generator input of
     test_full_size_properties (the input of rounds 1-3); an integer = that seed of the device generator."""
     B, S = 64, 160000
-    if which == "bench":
+    if isinstance(which, str) and which.startswith("bench"):  # ("bench_rank<r>": seed 1234 + r, indices of RandomState(4321 + r))
         import bench
 
-        idx = bench.fbank16k_parity_indices(10000, 0)
+        rank = 0 if which == "bench" else int(which[len("bench_rank"):])
+        idx = bench.fbank16k_parity_indices(10000, rank)
         last = int(idx.max()) // bench.FILL_CHUNK * bench.FILL_CHUNK + bench.FILL_CHUNK  # whole chunks up to the last sampled cut
         wave = torch.empty((last, S), dtype=torch.float32, device="cuda")
-        bench.fbank16k_fill(wave, 1234)
+        bench.fbank16k_fill(wave, 1234 + rank)
         return wave[torch.from_numpy(idx).cuda()].contiguous()
     if which == "cpu0":
         g = torch.Generator().manual_seed(0)
@@ -168,6 +169,9 @@ def test_headline_parity_multi_seed(which):
                        "hip_vs_float64_rms": f["hip_vs_f64_rms"], "floor_rms": f["oracle_f32_vs_f64_rms"], "K_measured": v["K_measured"],
                        "K_allowed": v["K_allowed"], "elementwise_bar": v["elementwise_bar"], "linear_domain_outside": f["lin_bad"],
                        "linear_domain_worst_share_of_tolerance": f["lin_margin_max"], "values_over_2e-3": f["n_over_2e-3"],
+                       "linear_vs_f64_hip_worst_share": f["lin_own_max"], "linear_vs_f64_reference32_worst_share": f["lin_floor_max"],
+                       "linear_vs_f64_bar": v["linear_bar_share_of_tolerance"], "linear_vs_f64_hip_over_1": f["lin_own_over1"],
+                       "linear_vs_f64_reference32_over_1": f["lin_floor_over1"],
                        "clause_needed_rel": False, "clause_needed_abs": bool(f["hip_vs_f64_max_abs"] > parity_bar.ABS_TOL),
                        "n_values": f["n_values"], "pass": v["pass"], "ref32": "oracle/kaldi_torch.reference_f32 (the reference's float32 torch calls)",
                        "numpy32_floor_max_abs": f["numpy32_vs_f64_max_abs"], "hip_vs_numpy32_max_abs": f["hip_vs_numpy32_max_abs"],
