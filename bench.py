@@ -774,6 +774,7 @@ class BulkSave:
         os.makedirs(root)
         busy = {"save": 0.0, "lines": 0.0, "n": 0}
         ex = self.ex
+        pipe0 = ex._native_pipe().stats() if route == "native" and hasattr(getattr(ex, "plan", None), "handle") else None
 
         def extract(batch):
             cuts, idx, frags = batch
@@ -836,6 +837,10 @@ class BulkSave:
 
                     S.pump_batches(self.batches, extract, save, stats=stats, finish=lines)
                     stats["archive_bytes"] = stats.get("archive_bytes", 0) + os.path.getsize(writer.storage_path)
+        if pipe0 is not None:  # the library's pipeline thread: its own clock over this pass
+            pipe1 = ex._native_pipe().stats()
+            for k in ("busy_s", "pack_s", "device_backpressure_s"):
+                stats["pipe_" + k] = stats.get("pipe_" + k, 0.0) + pipe1[k] - pipe0[k]
         stats["device_wait_s"] = stats.get("device_wait_s", 0.0) + busy.get("wait", 0.0)
         stats["manifest_s"] = stats.get("manifest_s", 0.0) + busy["lines"]
         stats["save_s"] = stats.get("save_s", 0.0) + busy["save"]
@@ -915,14 +920,18 @@ class BulkSave:
                 "main_thread_extract_share": round(st["extract_s"] / dt, 3), "main_thread_blocked_share": round(st["wait_s"] / dt, 3),
                 "archive_thread_busy_share": round(st["save_s"] / dt, 3), "archive_thread_waiting_for_the_device_share": round(st.get("device_wait_s", 0.0) / dt, 3),
                 "manifest_thread_busy_share": round(st["manifest_s"] / dt, 3),
+                "pipeline_thread_busy_share": round(st.get("pipe_busy_s", 0.0) / dt, 3), "pipeline_thread_packing_share": round(st.get("pipe_pack_s", 0.0) / dt, 3),
+                "pipeline_thread_waiting_for_pcie_or_device_share": round(st.get("pipe_device_backpressure_s", 0.0) / dt, 3),
                 "binds": max((st["extract_s"], "the calling thread (packing into page-locked staging + enqueueing)"), (st["save_s"], "archive thread"),
-                             (st.get("device_wait_s", 0.0), "PCIe / device (the archive thread waits for the batch's download)"), (st["manifest_s"], "manifest thread"))[1],
+                             (st.get("device_wait_s", 0.0), "PCIe / device (the archive thread waits for the batch's download)"), (st["manifest_s"], "manifest thread"),
+                             (st.get("pipe_busy_s", 0.0), "the library's pipeline thread (packing into page-locked staging + enqueueing; its PCIe / device back-pressure included)"))[1],
             }
         self.stripes = keep_stripes
         out["fragments_per_s_per_process"] = round(self.fragments_per_s, 1)
         out["stripes"] = self.stripes
         out["what"] = ("3 passes per variant after one warm-up; shares are of wall time: the calling thread extracts (pack to pinned + H2D + kernel + D2H), "
-                       "one background thread appends to the archive, a second one writes the manifest lines (storage.pump_batches); the largest share binds; "
+                       "one background thread appends to the archive, a second one writes the manifest lines (storage.pump_batches), the library's pipeline thread packs and enqueues "
+                       "(its own clock: hipfeat_host_pipeline_stats); the largest share binds; "
                        "fragments_per_s_per_process = manifest line halves one (loader) process serialises per second -- that work rides on the loader's workers, "
                        "next to audio decoding, not on this process")
         return {"bulk_save": out}

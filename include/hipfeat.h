@@ -354,6 +354,10 @@ HIPFEAT_API hipfeat_status hipfeat_host_pipeline_submit(hipfeat_host_pipeline* p
                                                         int64_t* h_num_frames, void** h_out, int64_t* h_out_rows, int64_t* ticket);
 HIPFEAT_API hipfeat_status hipfeat_host_pipeline_wait(hipfeat_host_pipeline* pipeline, int64_t ticket);
 HIPFEAT_API hipfeat_status hipfeat_host_pipeline_release(hipfeat_host_pipeline* pipeline, int64_t ticket);
+/* The pipeline thread's own clock since creation, h_stats[4] = {nanoseconds busy with batches, of those: packing into page-locked
+ * staging, of those: waiting for a staging set's previous uploads / downloads (back-pressure from PCIe and the device), batches}:
+ * lets a driver say which stage binds its run. */
+HIPFEAT_API hipfeat_status hipfeat_host_pipeline_stats(const hipfeat_host_pipeline* pipeline, int64_t* h_stats);
 
 #ifdef __cplusplus
 }

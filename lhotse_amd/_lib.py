@@ -92,6 +92,7 @@ _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
     ),
     "hipfeat_host_pipeline_wait": ("int", ["hipfeat_host_pipeline*", "int64_t"]),
     "hipfeat_host_pipeline_release": ("int", ["hipfeat_host_pipeline*", "int64_t"]),
+    "hipfeat_host_pipeline_stats": ("int", ["const hipfeat_host_pipeline*", "int64_t*"]),
     "hipfeat_extract_host": (
         "int",
         ["const hipfeat_plan*", "const float*", "int64_t", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "int64_t", "const int64_t*", "int64_t", "void*"],

@@ -12,6 +12,7 @@
 // Included at the end of hipfeat.hip (uses its fail / HIP_TRY / DeviceGuard and the extern "C" entry points).
 #pragma once
 
+#include <chrono>
 #include <deque>
 #include <map>
 #include <memory>
@@ -89,7 +90,14 @@ struct hipfeat_host_pipeline {
   std::map<int64_t, std::shared_ptr<PipeJob>> jobs;
   std::thread worker;
   bool stop = false;
+  // the pipeline thread's own clock (hipfeat_host_pipeline_stats): nanoseconds busy with batches / of those: packing / of those: waiting
+  // for a staging set's previous uploads and downloads (= back-pressure from PCIe and the device); batches processed
+  std::atomic<int64_t> ns_busy{0}, ns_pack{0}, ns_slot_wait{0}, n_batches{0};
 };
+
+static inline int64_t pipe_now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // The worker's side of one batch: everything that touches the staging sets and the streams.  Returns a status; on failure the
 // message is in this thread's g_err.
@@ -103,8 +111,10 @@ static hipfeat_status pipe_process(hipfeat_host_pipeline* p, PipeJob& j, PipeOut
   // the staging set's previous batch (three batches ago): its uploads must have left `h`, and its downloads must be over before the
   // chunk events they wait on are recorded again and before its device buffers are written
   if (s.used) {
+    const int64_t t0 = pipe_now_ns();
     HIP_TRY(hipEventSynchronize(s.uploaded));
     HIP_TRY(hipEventSynchronize(s.downloaded));
+    p->ns_slot_wait.fetch_add(pipe_now_ns() - t0, std::memory_order_relaxed);
   }
   const size_t in_bytes = (size_t)j.total * in_item;
   if (s.h_cap < in_bytes) {
@@ -143,7 +153,11 @@ static hipfeat_status pipe_process(hipfeat_host_pipeline* p, PipeJob& j, PipeOut
       const size_t nbytes = (size_t)j.lens[(size_t)i] * in_item;
       for (size_t q = 0; q < nbytes; q += kPipeCopyPiece) pieces.push_back(Piece{dst + q, src + q, std::min(kPipeCopyPiece, nbytes - q)});
     }
-    p->pool->run(pieces.size(), [&](size_t i) { std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); });
+    {
+      const int64_t t0 = pipe_now_ns();
+      p->pool->run(pieces.size(), [&](size_t i) { std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); });
+      p->ns_pack.fetch_add(pipe_now_ns() - t0, std::memory_order_relaxed);
+    }
     const int64_t e0 = j.off[(size_t)a], e1 = (b < batch ? j.off[(size_t)b] : j.total);
     HIP_TRY(hipMemcpyAsync(static_cast<char*>(s.d_raw) + (size_t)e0 * in_item, hin + (size_t)e0 * in_item, (size_t)(e1 - e0) * in_item, hipMemcpyHostToDevice, p->s_in));
     hipfeat_status st;
@@ -186,7 +200,10 @@ static void pipe_worker(hipfeat_host_pipeline* p) {
       p->queue.pop_front();
       o = p->outs[(size_t)j->out];  // a copy: `outs` may grow while this batch is processed; its buffer and event do not move
     }
+    const int64_t t0 = pipe_now_ns();
     const hipfeat_status st = pipe_process(p, *j, o);
+    p->ns_busy.fetch_add(pipe_now_ns() - t0, std::memory_order_relaxed);
+    p->n_batches.fetch_add(1, std::memory_order_relaxed);
     {
       std::lock_guard<std::mutex> lk(p->mu);
       j->status = st;
@@ -399,5 +416,14 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_release(hipfeat_host
   if (it == p->jobs.end()) return fail(HIPFEAT_ERR_INVALID, "host pipeline: ticket %lld is not outstanding", (long long)ticket);
   p->outs[(size_t)it->second->out].ticket = -1;
   p->jobs.erase(it);
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_stats(const hipfeat_host_pipeline* p, int64_t* h_stats) {
+  if (!p || !h_stats) return fail(HIPFEAT_ERR_INVALID, "NULL argument");
+  h_stats[0] = p->ns_busy.load(std::memory_order_relaxed);
+  h_stats[1] = p->ns_pack.load(std::memory_order_relaxed);
+  h_stats[2] = p->ns_slot_wait.load(std::memory_order_relaxed);
+  h_stats[3] = p->n_batches.load(std::memory_order_relaxed);
   return HIPFEAT_OK;
 }

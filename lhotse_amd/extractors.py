@@ -603,6 +603,12 @@ class NativeHostPipeline:
         arr = np.frombuffer(buf, dtype=np.float16 if half else np.float32).reshape(rows, F)
         return PendingFeatures(self, int(res[2]), arr, frames, keep)
 
+    def stats(self) -> Dict[str, float]:
+        """The pipeline thread's own clock since creation: seconds busy / packing / waiting for PCIe + device, batches."""
+        a = np.zeros(4, dtype=np.int64)
+        self.lib.check("hipfeat_host_pipeline_stats", self.handle, _lib.addr(a))
+        return {"busy_s": a[0] * 1e-9, "pack_s": a[1] * 1e-9, "device_backpressure_s": a[2] * 1e-9, "batches": int(a[3])}
+
     def _wait(self, ticket: int) -> None:
         st = self._waitf(self.handle, int(ticket))
         if st != 0:
