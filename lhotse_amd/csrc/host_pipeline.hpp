@@ -21,7 +21,10 @@ namespace {
 
 constexpr size_t kPipeCopyPiece = (size_t)1 << 20;        // bytes per memcpy task
 constexpr int64_t kPipeMinChunkBytes = (int64_t)4 << 20;  // a chunk = consecutive cuts of at least this many input bytes ...
-constexpr int kPipeTargetChunks = 4;                      // ... about this many per batch
+// ... about this many per batch (HIPFEAT_PIPE_CHUNKS: routing switch, 1 ... 16).  ONE: with submit() asynchronous the overlap that matters is
+// between batches (batch n + 1 is packed and uploaded while batch n downloads), and every chunk costs the pipeline thread ~0.1 ms of
+// enqueue calls: same-call A/B on the offline path, 1 vs 4 chunks: + 3 ... 30 % in 8 of 8 comparisons (profiles/r05_pipeline_chunks_ab.txt)
+constexpr int kPipeTargetChunks = 1;
 constexpr int kPipeInSlots = 3;                           // input staging sets in rotation
 constexpr size_t kPipeMaxOutstanding = 64;
 
@@ -90,6 +93,7 @@ struct hipfeat_host_pipeline {
   std::map<int64_t, std::shared_ptr<PipeJob>> jobs;
   std::thread worker;
   bool stop = false;
+  int target_chunks = kPipeTargetChunks;
   // the pipeline thread's own clock (hipfeat_host_pipeline_stats): nanoseconds busy with batches / of those: packing / of those: waiting
   // for a staging set's previous uploads and downloads (= back-pressure from PCIe and the device); batches processed
   std::atomic<int64_t> ns_busy{0}, ns_pack{0}, ns_slot_wait{0}, n_batches{0};
@@ -241,6 +245,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_create(const hipfeat
     delete p;
     return fail(HIPFEAT_ERR_HIP, "host pipeline: stream / event creation failed: %s", hipGetErrorName(e));
   }
+  if (const char* tc = route_env("HIPFEAT_PIPE_CHUNKS")) p->target_chunks = std::min(16, std::max(1, atoi(tc)));
   p->pool = new hipfeat::WorkPool(copy_threads - 1);  // the pipeline thread copies too
   p->worker = std::thread(pipe_worker, p);
   *out = p;
@@ -324,7 +329,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_submit(hipfeat_host_
   j->rows = j->row0[(size_t)batch];
   const size_t out_bytes = (size_t)j->rows * F * (half_out ? 2 : 4);
   {
-    const int64_t target = std::max<int64_t>(kPipeMinChunkBytes, (int64_t)(total * in_item) / kPipeTargetChunks);
+    const int64_t target = std::max<int64_t>(kPipeMinChunkBytes, (int64_t)(total * in_item) / p->target_chunks);
     int64_t a = 0, acc = 0;
     for (int64_t b = 0; b < batch; ++b) {
       acc += ((h_num_samples[b] + align - 1) & ~(align - 1)) * (int64_t)in_item;

@@ -418,6 +418,44 @@ class NativeArchive:
             pass
 
 
+_FRAGMENTING_CLS = None
+
+
+def _fragmenting_dataset_class():
+    """`FragmentingWaveformDataset`, created on first use (importing lhotse.dataset is not free) and reachable as a module attribute
+    (`__getattr__` below), which is what pickle needs to ship an instance to spawned DataLoader workers."""
+    global _FRAGMENTING_CLS
+    if _FRAGMENTING_CLS is None:
+        from lhotse import MonoCut
+        from lhotse.dataset import UnsupervisedWaveformDataset
+
+        class FragmentingWaveformDataset(UnsupervisedWaveformDataset):
+            """lhotse.dataset.UnsupervisedWaveformDataset (lhotse/dataset/unsupervised.py:44-98) whose batches also carry
+            `hipfeat_fragments`: per cut the two halves of its manifest line + the frame count they state (`manifest_fragments`), or None
+            for cuts that have to go through lhotse's own objects."""
+
+            def __init__(self, collate: bool, template: Optional[Dict], frame_shift: float):
+                super().__init__(collate=collate)
+                self.hipfeat_template, self.hipfeat_frame_shift = template, frame_shift
+
+            def __getitem__(self, batch_cuts):
+                batch = super().__getitem__(batch_cuts)
+                cache = self.__dict__.setdefault("_hipfeat_rec_cache", {})
+                t = self.hipfeat_template
+                batch["hipfeat_fragments"] = None if t is None else [manifest_fragments(c, t, self.hipfeat_frame_shift, cache, MonoCut) for c in batch["cuts"]]
+                return batch
+
+        FragmentingWaveformDataset.__module__, FragmentingWaveformDataset.__qualname__ = __name__, "FragmentingWaveformDataset"
+        _FRAGMENTING_CLS = FragmentingWaveformDataset
+    return _FRAGMENTING_CLS
+
+
+def __getattr__(name):  # PEP 562: `lhotse_amd.storage.FragmentingWaveformDataset` exists once asked for
+    if name == "FragmentingWaveformDataset" and HAVE_LHOTSE:
+        return _fragmenting_dataset_class()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
 def write_lines(manifest, blob: bytes) -> None:
     """Put pre-serialised JSONL lines behind what a SequentialJsonlWriter has written so far (its `file` is a text-mode handle over a
     GzipFile or a plain file: the bytes go to the layer underneath; zlib and the file write release the GIL)."""
@@ -691,17 +729,9 @@ def compute_and_store_features_batch(
                 base = {"type": extractor.name, "num_features": int(extractor.feature_dim(first.sampling_rate)), "frame_shift": frame_shift,
                         "sampling_rate": first.sampling_rate, "storage_type": archive.name, "storage_path": archive.storage_path}
 
-            class _FragmentingDataset(UnsupervisedWaveformDataset):
-                """lhotse's waveform dataset + the halves of every cut's manifest line, made where the cut is loaded (the DataLoader's
-                worker processes when num_workers > 0)."""
-
-                def __getitem__(self, batch_cuts):
-                    batch = super().__getitem__(batch_cuts)
-                    cache = self.__dict__.setdefault("_hipfeat_rec_cache", {})
-                    batch["hipfeat_fragments"] = None if base is None else [manifest_fragments(c, base, frame_shift, cache, MonoCut) for c in batch["cuts"]]
-                    return batch
-
-            loader = DataLoader(_FragmentingDataset(collate=collate), batch_size=None, sampler=sampler, num_workers=num_workers)
+            # lhotse's waveform dataset + the halves of every cut's manifest line, made where the cut is loaded (the DataLoader's worker
+            # processes when num_workers > 0); a module-level class: picklable, so the `spawn` start method works too
+            loader = DataLoader(_fragmenting_dataset_class()(collate, base, frame_shift), batch_size=None, sampler=sampler, num_workers=num_workers)
 
             def save(archive, batch_cuts, pending, frames: List[int], template: Dict, frags):
                 frames = np.ascontiguousarray(frames, dtype=np.int64)

@@ -81,11 +81,13 @@ def test_appending_resumes_behind_the_existing_rows(tmp_path):
 
 @pytest.mark.parametrize("kind,pcm,half,zero_pad", [("fbank", False, False, False), ("fbank", True, True, False), ("mfcc", False, True, False),
                                                     ("fbank", False, False, True), ("fbank", True, False, True)])
-def test_native_host_pipeline_equals_the_python_pipeline_bit_for_bit(kind, pcm, half, zero_pad):
+def test_native_host_pipeline_equals_the_python_pipeline_bit_for_bit(kind, pcm, half, zero_pad, monkeypatch):
     """Round 5: hipfeat_host_pipeline_* (packing threads + chunked H2D / launch / D2H inside the library, asynchronous) hands back,
     for every batch, exactly the matrix `_batch_features_on_host` (the Python pipeline) does -- float32 and int16 PCM inputs, float32
     and binary16 results, both edge rules -- also with several batches in flight and results released out of order."""
     cfg = {"edge_rule": "batch_zero_pad"} if zero_pad else {}
+    if pcm or kind == "mfcc":  # the chunked form of the pipeline (several upload / launch / download groups per batch): read at pipeline creation
+        monkeypatch.setenv("HIPFEAT_PIPE_CHUNKS", "4")
     ex = (LA.HipFbank(LA.HipFbankConfig(**cfg)) if kind == "fbank" else LA.HipMfcc(LA.HipMfccConfig(**cfg)))
     batches = _batches(11, 9) + [[(np.random.RandomState(1).rand(160000).astype(np.float32) - 0.5) for _ in range(60)]]  # + one 600 s batch
     if pcm:

@@ -613,6 +613,16 @@ def test_native_manifest_lines_equal_the_per_cut_path_byte_for_byte(tmp_path, cu
             assert sum(os.path.getsize(f) for f in files) == os.path.getsize(tmp_path / "plain.hfa")
         for a, b in zip(got_cuts, plain):
             assert a.id == b.id and a.supervisions[0].text == b.supervisions[0].text and np.array_equal(a.load_features(), b.load_features())
+    # the loader-side dataset is a module-level class: an instance survives pickling (spawned DataLoader workers)
+    import pickle
+
+    import lhotse_amd.storage as S
+
+    ds = S.FragmentingWaveformDataset(False, {"type": "hip-fbank", "num_features": 80, "frame_shift": 0.01, "sampling_rate": 16000, "storage_type": "hip_archive",
+                                              "storage_path": "x"}, 0.01)
+    back = pickle.loads(pickle.dumps(ds))
+    got = back[CutSet.from_cuts(cuts[:3])]
+    assert len(got["hipfeat_fragments"]) == 3 and all(f is not None and f[2] == S.expected_num_frames(c.duration, 0.01, 16000) for f, c in zip(got["hipfeat_fragments"], cuts[:3]))
     # resume into a striped archive: nothing is extracted twice, the files do not move
     sizes = {f: os.path.getsize(f) for f in (tmp_path / "s3.hfa", tmp_path / "s3.1.hfa", tmp_path / "s3.2.hfa")}
     again = list(LA.compute_and_store_features_batch(many, ex, tmp_path / "s3", manifest_path=tmp_path / "s3.jsonl.gz", batch_duration=4.0, num_workers=0,
