@@ -610,6 +610,8 @@ class NativeHostPipeline:
         return {"busy_s": a[0] * 1e-9, "pack_s": a[1] * 1e-9, "device_backpressure_s": a[2] * 1e-9, "batches": int(a[3])}
 
     def _wait(self, ticket: int) -> None:
+        if not self.handle:  # the extractor was moved / its plan dropped while a batch was outstanding: the result buffers went with the pipeline
+            raise _lib.HipFeatError(_lib.ERR_INVALID, "the host pipeline of this batch was closed (extractor moved or plan dropped) before the batch was collected")
         st = self._waitf(self.handle, int(ticket))
         if st != 0:
             raise _lib.HipFeatError(int(st), self.lib.last_error())

@@ -179,3 +179,16 @@ def test_cffi_branch_of_the_loader_with_a_minimal_cffi_module(monkeypatch):
     st = lib.raw("hipfeat_device_count", _lib.addr(cnt))  # a pointer argument through ffi.cast
     assert st in (0, _lib.ERR_HIP)
     assert lib.raw("hipfeat_device_count", None) == _lib.ERR_INVALID  # None -> ffi.NULL
+
+
+def test_experiment_switches_are_not_in_the_product_library():
+    """VERDICT r4 task 6: the switches that skip work or retune launch shapes (HIPFEAT_MB_SKIP produces deliberately wrong results) exist only
+    in -DHIPFEAT_EXPERIMENTS builds -- their names do not occur in the shipped .so, so no environment can reach them; the routing switches
+    (all routes meet the parity bar) do."""
+    from lhotse_amd import build as B
+
+    blob = open(B.build(), "rb").read()
+    for name in (b"HIPFEAT_MB_SKIP", b"HIPFEAT_MB_SLOTS", b"HIPFEAT_ROUNDS_R3", b"HIPFEAT_ROUNDS\0"):
+        assert name not in blob, name
+    for name in (b"HIPFEAT_FORCE_GENERIC", b"HIPFEAT_NO_FIXED_SCHEDULE", b"HIPFEAT_NO_FLAT", b"HIPFEAT_PIPE_CHUNKS"):
+        assert name in blob, name
