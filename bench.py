@@ -1296,12 +1296,36 @@ def after_idle(w, dev, idle_s: float = 2.0, launches: int = 25):
                                       "caller that launches after an idle gap sees; `value` of the line is the sustained rate"}}
 
 
-def gather_extras(local, dist, world: int):
+def gather_json(local, dist, world: int, cdev):
+    """Every rank's JSON-serialisable object on every rank, with the same primitives the rest of the run uses (all_reduce / all_gather of
+    plain tensors on `cdev`: no pickling, no object collectives -- nothing new for RCCL to trip over on the driver's 8-GPU run)."""
+    import torch
+
+    raw = json.dumps(local).encode("utf-8")
+    n = torch.tensor([len(raw)], dtype=torch.int64, device=cdev)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX)
+    size = int(n.item())
+    buf = torch.zeros(size + 8, dtype=torch.uint8, device=cdev)
+    buf[:8] = torch.tensor(list(len(raw).to_bytes(8, "little")), dtype=torch.uint8, device=cdev)
+    buf[8 : 8 + len(raw)] = torch.tensor(list(raw), dtype=torch.uint8, device=cdev)
+    parts = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out = []
+    for t in parts:
+        b = bytes(t.cpu().tolist())
+        out.append(json.loads(b[8 : 8 + int.from_bytes(b[:8], "little")].decode("utf-8")))
+    return out
+
+
+def gather_extras(local, dist, world: int, cdev=None):
     """Host-fed legs run on ALL ranks at once (barrier in, barrier out): rank 0 gets every rank's dict and the sums of the numeric leaves."""
     if dist is None or world == 1:
         return local
-    objs = [None] * world
-    dist.all_gather_object(objs, local)
+    if hasattr(dist, "all_gather_object") and cdev is None:  # (tests hand in a stand-in group)
+        objs = [None] * world
+        dist.all_gather_object(objs, local)
+    else:
+        objs = gather_json(local, dist, world, cdev)
 
     def total(path):
         vals = []
@@ -1407,7 +1431,7 @@ def main():
         local = w.extra(args)
         if dist is not None:
             dist.barrier()
-        extra = gather_extras(local, dist, world) if local else {}
+        extra = gather_extras(local, dist, world, cdev) if local else {}
         if args.config == "fbank16k" and hasattr(w, "settle_device"):
             extra.update(after_idle(w, dev))
     if other:

@@ -309,3 +309,42 @@ def test_numa_binding_reads_the_topology_and_never_widens(tmp_path, monkeypatch)
         go.set()
         t.join()
         os.sched_setaffinity(0, allowed)
+
+
+def _gather_json_rank(rank, world, port, q):
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    import bench
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = {"host_fed_cuts_per_s": {"batch_60": 100.0 * (rank + 1), "what": "zażółć " * (rank + 1)}, "rank": rank}
+    got = bench.gather_extras(local, dist, world, torch.device("cpu"))
+    q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_gathers_the_host_fed_legs_of_all_ranks_with_plain_tensor_collectives():
+    """bench.py's N > 1 host-fed report: dicts of different sizes (non-ASCII text included) from three gloo ranks, gathered with all_reduce /
+    all_gather of byte tensors only -- every rank sees every rank's dict, and the numeric leaves are summed."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gather_json_rank, args=(r, 3, port, q)) for r in range(3)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=120) for _ in range(3))
+    [p.join(timeout=60) for p in ps]
+    for r in range(3):
+        assert [o["rank"] for o in res[r]["per_rank"]] == [0, 1, 2]
+        assert res[r]["per_rank"][2]["host_fed_cuts_per_s"]["what"] == "zażółć " * 3
+        assert res[r]["aggregate_over_ranks"]["host_fed_cuts_per_s"]["batch_60"] == 600.0 and res[r]["aggregate_over_ranks"]["rank"] == 3.0
