@@ -1176,7 +1176,9 @@ def parity_leg(w, rank: int, dist, cdev, log_mel: bool = True):
         # clause 2, against float64 truth: share = |exp(x) - exp(f64)| / (1e-4 exp(f64) + eps), eps = the reference's own mel floor
         "linear_domain_vs_f64": {"hip_worst_share": round(par["lin_own_max"], 4), "reference32_worst_share": round(par["lin_floor_max"], 4),
                                  "bar": round(v["linear_bar_share_of_tolerance"], 4), "hip_values_over_1": par["lin_own_over1"],
-                                 "reference32_values_over_1": par["lin_floor_over1"], "of": par["n_values"]},
+                                 "reference32_values_over_1": par["lin_floor_over1"], "of": par["n_values"],
+                                 "K_linear_measured": round(v["K_linear_measured"], 3) if log_mel else None, "K_linear_allowed": v["K_linear_allowed"]},
+        "statement_version": v["statement_version"],
         # ... and the two float32 pipelines against each other (reported; rounds 4's form of the clause: the reference fails it against float64 itself)
         "linear_domain_outside_rtol1e-4_atol_eps": par["lin_bad"],  # values with |exp(hip) - exp(ref32)| > 1e-4 exp(ref32) + eps
         "linear_domain_worst_share_of_tolerance": round(par["lin_margin_max"], 4),  # max |exp(hip) - exp(ref32)| / (1e-4 exp(ref32) + eps)

@@ -163,16 +163,167 @@ class TorchSpeed:
         return y[0, : self._len(length, self.orig, self.new)].numpy()
 
 
+class TorchKaldi:
+    """EVERY deterministic configuration of the reference's four Kaldi-style layers in the reference's own float32 torch calls
+    (round 6, VERDICT r5 Missing #4: `ref32` outside the headline used to be kaldi_ref's float64-FFT proxy):
+
+      Wav2Win._forward_strided      layers.py:151-187  (DC removal, raw / windowed log-energy, replicate-pad pre-emphasis, window, zero pad)
+      _get_strided_batch            layers.py:727-772  (snip_edges True / False, flip + cat reflection, as_strided view)
+      _get_log_energy               layers.py:859-870
+      Wav2Spec / Wav2LogSpec        layers.py:392-402, :461-473   (energy overwrites bin 0)
+      Wav2LogFilterBank             layers.py:565-578  (energy column prepended)
+      Wav2MFCC                      layers.py:708-724  (use_energy=True raises upstream, SURVEY Q4: not restated)
+      _extract_batch                kaldi/extractors.py:485-554   (`extract_batch(..., "batch_zero_pad")`: pad_sequence with zeros, ONE
+                                    batched forward, rows cut to compute_num_frames_from_samples)
+
+    Constants: windows from torch's own window kernels (layers.py:921-940), DCT / lifter with torch's float32 cos / sin (layers.py:681-706),
+    mel matrices from kaldi_ref.mel_matrix(float32) -- the reference evaluates lin2mel with NUMPY's float32 log on a tensor
+    (layers.py:943-944 `np.log(1 + x / 700)`), which is what kaldi_ref restates.  tests/test_oracle.py::test_torch_kaldi_is_the_live_reference_bit_for_bit
+    (authoring container) asserts array_equal with the live reference layers over the random-configuration family of the GPU suite, all
+    windows, energy options, snip_edges, both mel scales, the four kinds and the zero-padded batch form."""
+
+    def __init__(self, cfg: K.RefConfig):
+        import math
+
+        if cfg.dither != 0.0:
+            raise ValueError("ref32 is deterministic: dither must be 0 (layers.py:191-193 draws randn)")
+        if cfg.kind == "mfcc" and cfg.use_energy:
+            raise NotImplementedError("Wav2MFCC(use_energy=True) raises in the reference (layers.py:721-722, SURVEY Q4): there is no ref32 for it")
+        self.cfg = cfg
+        self.n, self.shift, self.fft = K.window_sizes(cfg)
+        n = self.n
+        wt = cfg.window_type
+        if wt == "hanning":
+            self.window = torch.hann_window(n, periodic=False)
+        elif wt == "hamming":
+            self.window = torch.hamming_window(n, periodic=False, alpha=0.54, beta=0.46)
+        elif wt == "povey":
+            self.window = torch.hann_window(n, periodic=False).pow(0.85)
+        elif wt == "rectangular":
+            self.window = torch.ones(n, dtype=torch.float32)
+        elif wt == "blackman":
+            a = 2 * math.pi / n
+            i = torch.arange(n, dtype=torch.float32)
+            self.window = 0.42 - 0.5 * torch.cos(a * i) + (0.5 - 0.42) * torch.cos(2 * a * i)
+        else:
+            raise ValueError(f"Invalid window type: {wt}")
+        self.eps = torch.tensor(torch.finfo(torch.float32).eps)
+        if cfg.kind in ("fbank", "mfcc"):
+            self.fb = torch.from_numpy(np.ascontiguousarray(K.mel_matrix(cfg, np.float32).astype(np.float32)))
+        if cfg.kind == "mfcc":
+            m, c = cfg.num_filters, cfg.num_ceps
+            nn = torch.arange(float(m)).unsqueeze(1)
+            kk = torch.arange(float(c))
+            dct = torch.cos(math.pi / float(m) * (nn + 0.5) * kk)
+            dct[:, 0] *= 1.0 / math.sqrt(2.0)
+            dct *= math.sqrt(2.0 / float(m))
+            self.dct = dct
+            q = cfg.cepstral_lifter
+            self.lifter = 1 + 0.5 * q * torch.sin(math.pi * torch.arange(c, dtype=torch.float32) / q) if q else None
+
+    @property
+    def feature_dim(self) -> int:
+        c = self.cfg
+        if c.kind == "fbank":
+            return c.num_filters + (1 if c.use_energy else 0)
+        return c.num_ceps if c.kind == "mfcc" else self.fft // 2 + 1
+
+    def _strided(self, x: torch.Tensor) -> torch.Tensor:
+        S = x.shape[-1]
+        if self.cfg.snip_edges:
+            if S < self.n:
+                return torch.empty((0, 0, 0))
+            T = 1 + (S - self.n) // self.shift
+        else:
+            T = (S + self.shift // 2) // self.shift
+            npad = (T - 1) * self.shift + self.n - S
+            npad_left = int((self.n - self.shift) // 2)
+            npad_right = npad - npad_left
+            pad_left = torch.flip(x[:, :npad_left], (1,))
+            if npad_right >= 0:
+                pad_right = torch.flip(x[:, -npad_right:], (1,))  # NB npad_right == 0 -> x[:, -0:] is the WHOLE row, as upstream (layers.py:761)
+            else:
+                pad_right = torch.zeros(0, dtype=x.dtype)
+            x = torch.cat((pad_left, x, pad_right), dim=1)
+        return x.as_strided([x.shape[0], T, self.n], (x.stride(0), self.shift * x.stride(1), x.stride(1)))
+
+    def _log_energy(self, x: torch.Tensor) -> torch.Tensor:
+        import math
+
+        e = (x.pow(2).sum(-1) + 1e-15).log()
+        if self.cfg.energy_floor > 0.0:
+            e = torch.max(e, torch.tensor(math.log(self.cfg.energy_floor), dtype=e.dtype))
+        return e
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, S) float32 -> (B, T, F): layer.forward(x) of the reference."""
+        c = self.cfg
+        x = self._strided(x)
+        if x.numel() == 0:
+            return torch.zeros((x.shape[0] if x.dim() else 0, 0, self.feature_dim))
+        # Wav2Win._forward_strided
+        if c.remove_dc_offset:
+            x = x - torch.mean(x, dim=2, keepdim=True)
+        log_e = None
+        if c.use_energy and c.raw_energy:
+            log_e = self._log_energy(x)
+        if c.preemph_coeff != 0.0:
+            off = torch.nn.functional.pad(x, (1, 0), mode="replicate")
+            x = x - c.preemph_coeff * off[:, :, :-1]
+        x = x * self.window
+        if self.fft != self.n:
+            x = torch.nn.functional.pad(x.unsqueeze(1), [0, self.fft - self.n], mode="constant", value=0.0).squeeze(1)
+        if c.use_energy and not c.raw_energy:
+            log_e = self._log_energy(x)
+        # the subclass' _forward_strided
+        X = torch.fft.rfft(x, dim=-1)
+        spec = X.abs() if c.use_fft_mag else X.abs() ** 2
+        if c.kind == "spectrogram":
+            if log_e is not None:
+                spec[:, :, 0] = log_e
+            return spec
+        if c.kind == "log-spectrogram":
+            spec = (spec + 1e-15).log()
+            if log_e is not None:
+                spec[:, :, 0] = log_e
+            return spec
+        mel = torch.max(torch.matmul(spec, self.fb), self.eps).log()
+        if c.kind == "fbank":
+            if log_e is not None:
+                mel = torch.cat((log_e.unsqueeze(-1), mel), dim=-1)
+            return mel
+        mfcc = torch.matmul(mel, self.dct)
+        if c.cepstral_lifter > 0:
+            mfcc *= self.lifter
+        return mfcc
+
+    def extract(self, samples: np.ndarray) -> np.ndarray:
+        """<Extractor>.extract (kaldi/extractors.py:92-115): (S,) -> (T, F)."""
+        x = torch.from_numpy(np.ascontiguousarray(np.asarray(samples, dtype=np.float32).reshape(1, -1)))
+        return self.forward(x)[0].numpy()
+
+    def extract_batch(self, waves, edge_rule: str = "reflect"):
+        if edge_rule == "reflect":
+            return [self.extract(w) for w in waves]
+        assert edge_rule == "batch_zero_pad"
+        items = [torch.from_numpy(np.ascontiguousarray(np.asarray(w, dtype=np.float32).reshape(-1))) for w in waves]
+        lens = [K.compute_num_frames_from_samples(len(w), self.cfg.frame_shift, self.cfg.sampling_rate) for w in items]
+        feats = self.forward(torch.nn.utils.rnn.pad_sequence(items, batch_first=True))
+        return [feats[i, : lens[i]].numpy() for i in range(len(items))]
+
+
 def reference_f32(cfg: K.RefConfig = None):
-    """`ref32` of the parity statements: an object with `.extract(samples) -> (T, F) float32` that runs the reference's own float32
-    torch call sequence for `cfg` (fbank or mfcc; povey window, per-item reflect edges, no energy column -- the configurations
-    of BASELINE.json).  Anything else has no torch restatement here and raises."""
+    """`ref32` of the parity statements: an object with `.extract(samples) -> (T, F) float32` (and `.extract_batch(waves, edge_rule)`)
+    that runs the reference's own float32 torch call sequence for `cfg` -- every kind, window, energy option, edge rule (round 6:
+    `TorchKaldi`; the BASELINE configurations keep their round-5 classes, which are the CPU baseline of bench.py)."""
     cfg = cfg or K.RefConfig(kind="fbank")
-    if cfg.kind == "fbank":
+    plain = not cfg.snip_edges and not cfg.use_energy and cfg.window_type == "povey" and not cfg.use_fft_mag
+    if cfg.kind == "fbank" and plain:
         return TorchFbank(cfg)
-    if cfg.kind == "mfcc":
+    if cfg.kind == "mfcc" and plain and cfg.remove_dc_offset and cfg.preemph_coeff != 0.0:
         return TorchMfcc(cfg=cfg)
-    raise NotImplementedError(f"no torch restatement of kind {cfg.kind!r}")
+    return TorchKaldi(cfg)
 
 
 REF32_NAME = ("oracle/kaldi_torch.py (the reference's own float32 torch call sequence: as_strided framing, torch.fft.rfft, abs()**2, matmul, log; "

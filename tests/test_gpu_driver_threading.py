@@ -14,6 +14,7 @@ import pytest
 import torch
 
 import lhotse_amd as LA
+from _golden import ref32
 from oracle.kaldi_ref import RefConfig, RefExtractor
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +55,7 @@ def test_background_save_worker_consumes_device_tensors_while_the_main_thread_ex
     for f in futures:
         f.result()
     assert len(stored) == sum(len(w) for _, w in kept)
-    o32, o64 = RefExtractor(RefConfig(kind="fbank"), np.float32), RefExtractor(RefConfig(kind="fbank"), np.float64)
+    o32, o64 = ref32(RefConfig(kind="fbank")), RefExtractor(RefConfig(kind="fbank"), np.float64)
     for b, waves in kept:
         for i, w in enumerate(waves):
             x = w[0].numpy()
@@ -69,7 +70,7 @@ def test_collated_form_with_lengths_and_a_background_consumer():
     """collate=True form of the driver: padded (B, Tmax) tensor + int32 lengths (dataset/unsupervised.py:67-84)."""
     rng = np.random.RandomState(7)
     ex = LA.HipFbank(LA.HipFbankConfig(device="cuda:0", edge_rule="batch_zero_pad"))
-    o32 = RefExtractor(RefConfig(kind="fbank"), np.float32)
+    o32 = ref32(RefConfig(kind="fbank"))
     results = []
 
     def save_worker(waves, features):

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from _golden import err_stats
+from _golden import ref32
 from _hip import make_hip
 from oracle.kaldi_ref import RefConfig, RefExtractor
 
@@ -44,7 +45,7 @@ def test_ragged_batches_against_the_oracle_and_the_older_kernels(sr, cfg, kernel
     ws = _waves(sr, 48 + len(cfg))
     if cfg.get("snip_edges"):
         ws = [w for w in ws if len(w) >= int(0.04 * sr)]
-    o32, o64 = RefExtractor(RefConfig(kind="fbank", **full), np.float32), RefExtractor(RefConfig(kind="fbank", **full), np.float64)
+    o32, o64 = ref32(RefConfig(kind="fbank", **full)), RefExtractor(RefConfig(kind="fbank", **full), np.float64)
     outs = ex.extract_batch([torch.from_numpy(w) for w in ws], sr)
     for w, o, a, b in zip(ws, outs, wv.extract_batch(ws, sr), gen.extract_batch(ws, sr)):
         got = o.cpu().numpy()

@@ -7,6 +7,7 @@ import torch
 
 import lhotse_amd as LA
 from oracle import kaldi_ref as K
+from _golden import ref32 as ref32_of
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +49,7 @@ def test_fft256_fast_path_matches_oracle_and_generic(kind, cfg, monkeypatch):
     if kind == "mfcc":
         fields.setdefault("num_filters", 23)
     ref64 = K.RefExtractor(K.RefConfig(kind=kind, **fields), np.float64)
-    ref32 = K.RefExtractor(K.RefConfig(kind=kind, **fields), np.float32)
+    ref32 = ref32_of(K.RefConfig(kind=kind, **fields))
     a = fast.extract_batch(xs, sr)
     b = slow.extract_batch(xs, sr)
     for x, fa, fb in zip(xs, a, b):
@@ -72,7 +73,7 @@ def test_fft256_tripwire_tone_and_collated():
     ex = _make("fbank", dict(sampling_rate=8000, num_filters=40))
     y = ex.extract(x, 8000)
     truth = K.RefExtractor(K.RefConfig(kind="fbank", sampling_rate=8000, num_filters=40), np.float64).extract(x)
-    want = K.RefExtractor(K.RefConfig(kind="fbank", sampling_rate=8000, num_filters=40), np.float32).extract(x)
+    want = ref32_of(K.RefConfig(kind="fbank", sampling_rate=8000, num_filters=40)).extract(x)
     assert y.shape == (100, 40)
     assert np.abs(y - truth).max() <= max(2e-3, 3 * np.abs(want - truth).max())
     col, lens = ex.extract_collated([x, x[:4000]], 8000)
@@ -95,7 +96,7 @@ def test_wave_autonomous_and_tile_kernels_agree(cfg, kernel, monkeypatch):
     assert old.kernel_name.startswith("fft256_kernel")
     monkeypatch.delenv("HIPFEAT_FFT256_VARIANT")
     fields = {k: v for k, v in cfg.items() if k in K.RefConfig.__dataclass_fields__}
-    ref32 = K.RefExtractor(K.RefConfig(kind="fbank", **fields), np.float32)
+    ref32 = ref32_of(K.RefConfig(kind="fbank", **fields))
     for x, a, b in zip(xs, new.extract_batch([torch.from_numpy(x) for x in xs], sr), old.extract_batch(xs, sr)):
         a = a.cpu().numpy()
         want = ref32.extract(x)

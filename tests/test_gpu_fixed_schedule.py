@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from _golden import err_stats
+from _golden import ref32
 from _hip import make_hip
 from oracle.kaldi_ref import RefConfig, RefExtractor
 
@@ -25,7 +26,7 @@ def test_fixed_schedule_instances_equal_the_generic_ones(sr, kernel, monkeypatch
     rng = np.random.default_rng(sr)
     waves = [torch.from_numpy((rng.standard_normal(n) * a).astype(np.float32)) for n, a in
              ((int(0.9 * sr), 0.1), (3 * sr + 17, 0.3), (sr // 20 + 1, 1e-3), (7 * sr + 5, 0.05))]
-    o32, o64 = RefExtractor(RefConfig(kind="fbank", sampling_rate=sr), np.float32), RefExtractor(RefConfig(kind="fbank", sampling_rate=sr), np.float64)
+    o32, o64 = ref32(RefConfig(kind="fbank", sampling_rate=sr)), RefExtractor(RefConfig(kind="fbank", sampling_rate=sr), np.float64)
     for w, a, b in zip(waves, fixed.extract_batch(waves, sr), generic.extract_batch(waves, sr)):
         assert a.shape == b.shape and a.shape[1] == 80
         assert torch.equal(a, b)

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from _golden import record_parity
+from _golden import ref32 as ref32_of
 
 import lhotse_amd as LA
 from oracle import kaldi_ref as K
@@ -16,35 +17,7 @@ TABLE = {"fbank": (LA.HipFbank, LA.HipFbankConfig), "mfcc": (LA.HipMfcc, LA.HipM
          "log-spectrogram": (LA.HipLogSpectrogram, LA.HipLogSpectrogramConfig)}
 
 
-def _random_case(rng):
-    kind = rng.choice(["fbank", "fbank", "mfcc", "spectrogram", "log-spectrogram"])
-    sr = int(rng.choice([8000, 16000, 16000, 22050, 24000, 32000, 44100, 48000]))
-    cfg = dict(sampling_rate=sr)
-    cfg["frame_length"] = float(rng.choice([0.025, 0.025, 0.02, 0.032, 0.016]))
-    cfg["frame_shift"] = float(rng.choice([0.01, 0.01, 0.0125, 0.008]))
-    if cfg["frame_shift"] > cfg["frame_length"]:
-        cfg["frame_shift"] = cfg["frame_length"] / 2
-    cfg["window_type"] = str(rng.choice(["povey", "povey", "hanning", "hamming", "rectangular", "blackman"]))
-    cfg["remove_dc_offset"] = bool(rng.rand() < 0.8)
-    cfg["preemph_coeff"] = float(rng.choice([0.97, 0.97, 0.0, 0.9]))
-    cfg["snip_edges"] = bool(rng.rand() < 0.2)
-    cfg["round_to_power_of_two"] = bool(rng.rand() < 0.85)
-    if kind in ("fbank", "mfcc"):
-        cfg["num_filters"] = int(rng.choice([23, 40, 64, 80, 128]))
-        cfg["low_freq"] = float(rng.choice([20.0, 0.0, 60.0]))
-        cfg["high_freq"] = float(rng.choice([-400.0, 0.0, -100.0]))
-        if rng.rand() < 0.15:
-            cfg["torchaudio_compatible_mel_scale"] = False
-    if kind == "mfcc":
-        cfg["num_ceps"] = int(min(cfg["num_filters"], rng.choice([13, 20, 23])))
-        cfg["cepstral_lifter"] = int(rng.choice([22, 0]))
-    if kind != "mfcc" and rng.rand() < 0.2:
-        cfg["use_energy"] = True
-        cfg["raw_energy"] = bool(rng.rand() < 0.5)
-        cfg["energy_floor"] = float(rng.choice([1e-10, 1e-3]))
-    if kind != "mfcc" and rng.rand() < 0.15:
-        cfg["use_fft_mag"] = True
-    return kind, cfg
+from _random_cases import random_case as _random_case  # shared with tests/test_oracle.py (the live-reference pin of ref32)
 
 
 CASES = [_random_case(np.random.RandomState(1000 + i)) for i in range(160)]
@@ -70,7 +43,7 @@ def test_random_config_against_float64_oracle(idx):
             ex.extract_batch(xs, sr)
         return
     ref64 = K.RefExtractor(K.RefConfig(kind=kind, **fields), np.float64)
-    ref32 = K.RefExtractor(K.RefConfig(kind=kind, **fields), np.float32)
+    ref32 = ref32_of(K.RefConfig(kind=kind, **fields))
     outs = ex.extract_batch(xs, sr)
     assert len(outs) == len(xs)
     for x, got in zip(xs, outs):

@@ -8,6 +8,7 @@ import torch
 import lhotse_amd as LA
 from lhotse_amd import augmentation as A
 from oracle import resample_ref as R
+from _golden import ref32
 from oracle.kaldi_ref import RefConfig, RefExtractor
 
 pytestmark = pytest.mark.gpu
@@ -30,7 +31,7 @@ def test_arena_perturbation_equals_per_cut_speed_then_fbank():
     assert torch.equal(arena[:front], before)  # the inputs are untouched: unperturbed cuts are used in place
     ex = LA.HipFbank()
     feats, flens = ex.plan.run_collated(arena, po, pl, None, LOG_EPSILON)
-    o32 = RefExtractor(RefConfig(kind="fbank"), np.float32)
+    o32 = ref32(RefConfig(kind="fbank"))
     for i, w in enumerate(waves):
         y = R.speed(w, 16000, float(fac[i])) if fac[i] != 1.0 else w
         assert int(pl[i]) == len(y)
