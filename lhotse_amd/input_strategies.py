@@ -47,6 +47,97 @@ def _bank_ratio_ok(sampling_rate: int, factor: float) -> bool:
     return g > 0 and (orig // g, new // g) in BANK_RATIOS
 
 
+def _perturb_in_arena(arena, offsets, lengths, factors, sampling_rate, tail_start):
+    """(indirection for the CPU stand-in of the tests)"""
+    from .augmentation import perturb_speed_in_arena
+
+    return perturb_speed_in_arena(arena, offsets, lengths, factors, sampling_rate, tail_start)
+
+
+class FusedMiniBatch:
+    """The device-facing half of ``HipOnTheFlyFeatures`` -- packing a (partly speed-perturbed) mini-batch into one arena, the launch pair
+    of ``hipfeat_minibatch_*`` (or the per-factor route), the collated feature tensor -- WITHOUT any lhotse type in its interface:
+    plain waveforms, factors and sample counts in, tensors out.  ``HipOnTheFlyFeatures`` inherits these methods unchanged; on a machine
+    without lhotse (the GPU box of the test suite) the class is usable on its own, so that the GPU tests drive the product's code and not
+    a restatement of it (tests/test_gpu_reference_drivers.py holds it to what lhotse's K2SpeechRecognitionDataset returned with the
+    reference's CPU Speed + Fbank on the same files)."""
+
+    def __init__(self, extractor, return_audio: bool = False) -> None:
+        if not hasattr(extractor, "extract_collated"):
+            raise TypeError("FusedMiniBatch needs a Hip* extractor (with extract_collated)")
+        self.extractor = extractor
+        self.return_audio = return_audio
+
+    def features_of(self, audios: List[torch.Tensor], factors: List[float], wants: List[int], sampling_rate: int):
+        """What ``HipOnTheFlyFeatures.__call__`` does between reading the audio and returning: ``audios`` as read from the files (the
+        segments in front of a pending ``Speed``), ``factors`` still to be applied (1.0 = none), ``wants`` = samples each cut must end up
+        with (``compute_num_samples(cut.duration)``) -> ``(feats (B, Tmax, F) on the extractor's device, feat_lens)``."""
+        if any(f != 1.0 for f in factors):
+            feats, feat_lens, _ = self._perturb_and_extract(audios, factors, wants, sampling_rate)
+            return feats, feat_lens
+        return self.extractor.extract_collated(audios, sampling_rate=sampling_rate, padding_value=LOG_EPSILON)
+
+    def _speed_bank(self, factors, sr: int, device):
+        """The bank of the factors met so far on this device (rebuilt when a new factor shows up); None if one of them is not among
+        the mixed launch's ratios."""
+        from ._lib import ERR_UNSUPPORTED, HipFeatError
+        from .augmentation import HipSpeedBank
+
+        need = {float(f) for f in factors if float(f) != 1.0}
+        cache = self.__dict__.setdefault("_banks", {})
+        key = (int(sr), str(device))
+        refused = cache.setdefault("refused", set())
+        if need & refused:
+            return None
+        bank = cache.get(key)
+        if bank is None or not need <= set(bank.factors):
+            have = set() if bank is None else set(bank.factors)
+            # only the factors whose resampling ratio round(sr * f) : sr reduces to one of the mixed launch's compile-time ratios can be
+            # served by a bank; every other factor is refused ON ITS OWN (ADVICE r4: a mini-batch with {0.9, 0.95} used to blacklist 0.9
+            # as well, and every later 0.9 / 1.1 mini-batch silently fell back to the three-launch route)
+            bad = {f for f in need - have if not _bank_ratio_ok(sr, f)}
+            if bad:
+                refused |= bad
+                return None
+            try:
+                bank = cache[key] = HipSpeedBank(sorted(have | need), sr, device)
+            except HipFeatError as e:
+                if e.status != ERR_UNSUPPORTED:
+                    raise
+                return None  # (this mini-batch goes per factor; nothing is blacklisted on a guess)
+        return bank
+
+    def _perturb_and_extract(self, audios: List[torch.Tensor], factors: List[float], wants: List[int], sr: int):
+        """Pack the (partly unperturbed) batch, resample the cuts with a pending factor into the tail of the same buffer, extract."""
+        from .augmentation import perturbed_tail_floats
+        from .extractors import _as_1d_float
+
+        ex = self.extractor
+        ex._check_sr(sr)
+        items = [_as_1d_float(a.squeeze() if a.ndim > 1 else a, "HipOnTheFlyFeatures") for a in audios]
+        with torch.no_grad():
+            packed, offs, lens = ex._pack(items)
+            front = int(packed.numel())
+            arena = torch.empty(((front + 3) & ~3) + perturbed_tail_floats(lens, factors, sr), dtype=torch.float32, device=packed.device)
+            arena[:front].copy_(packed, non_blocking=True)
+            zero_pad = getattr(ex.config, "edge_rule", "reflect") == "batch_zero_pad"  # as extract_collated
+            want = np.ascontiguousarray(wants, dtype=np.int64)
+            bank = self._speed_bank(factors, sr, packed.device) if hasattr(ex.plan, "handle") else None
+            if bank is not None:  # ONE launch for all factors + the padding rows, then the feature launch (hipfeat_minibatch_*)
+                feats, frames, po, pl = bank.extract_collated(ex.plan, arena, np.ascontiguousarray(offs, dtype=np.int64),
+                                                              np.ascontiguousarray(lens, dtype=np.int64), bank.index_of(factors), front,
+                                                              float(LOG_EPSILON), max_samples=want, zero_pad_batch=zero_pad)
+            else:  # factors outside the mixed launch's compile-time ratios: one resample launch per factor
+                po, pl = _perturb_in_arena(arena, offs, lens, factors, sr, front)
+                pl = np.minimum(pl, want)  # a sample or two to truncate (recording.py:1058-1060)
+                padded = np.full(len(pl), int(pl.max()), dtype=np.int64) if zero_pad else None
+                feats, frames = ex.plan.run_collated(arena, po, pl, padded, float(LOG_EPSILON))
+        perturbed = None
+        if self.return_audio:
+            perturbed = [arena[int(o) : int(o) + int(n)].cpu() for o, n in zip(po, pl)]
+        return feats, torch.from_numpy(np.asarray(frames, dtype=np.int64)), perturbed
+
+
 if HAVE_LHOTSE:  # pragma: no cover - authoring container only
     from lhotse.audio.utils import suppress_audio_loading_errors  # type: ignore
     from lhotse.dataset.collation import collate_vectors, read_audio_from_cuts  # type: ignore
@@ -110,13 +201,7 @@ if HAVE_LHOTSE:  # pragma: no cover - authoring container only
             return torch.from_numpy(audio), 1.0, int(audio.shape[-1])
         return None
 
-    def _perturb_in_arena(arena, offsets, lengths, factors, sampling_rate, tail_start):
-        """(indirection for the CPU stand-in of the tests)"""
-        from .augmentation import perturb_speed_in_arena
-
-        return perturb_speed_in_arena(arena, offsets, lengths, factors, sampling_rate, tail_start)
-
-    class HipOnTheFlyFeatures(OnTheFlyFeatures):
+    class HipOnTheFlyFeatures(OnTheFlyFeatures, FusedMiniBatch):
         """Same constructor as ``OnTheFlyFeatures`` plus ``return_device`` (``None`` keeps the padded feature tensor on the
         extractor's GPU, ready for the training step; ``"cpu"`` hands back a host tensor like the reference does) and
         ``gpu_speed_perturb`` (see the module docstring)."""
@@ -169,7 +254,7 @@ if HAVE_LHOTSE:  # pragma: no cover - authoring container only
             assert len(rates) == 1, f"one launch per batch needs a single sampling rate, got {sorted(rates)}"
             sr = rates.pop()
             perturbed = None
-            if any(f != 1.0 for f in factors):
+            if any(f != 1.0 for f in factors):  # (FusedMiniBatch.features_of, with the perturbed samples kept for `return_audio`)
                 feats, feat_lens, perturbed = self._perturb_and_extract(audios, factors, wants, sr)
             else:
                 feats, feat_lens = self.extractor.extract_collated(audios, sampling_rate=sr, padding_value=LOG_EPSILON)
@@ -180,66 +265,6 @@ if HAVE_LHOTSE:  # pragma: no cover - authoring container only
             if self.fault_tolerant:  # the cuts that survived audio loading
                 result.append(cuts)
             return tuple(result)
-
-        def _speed_bank(self, factors, sr: int, device):
-            """The bank of the factors met so far on this device (rebuilt when a new factor shows up); None if one of them is not among
-            the mixed launch's ratios."""
-            from ._lib import ERR_UNSUPPORTED, HipFeatError
-            from .augmentation import HipSpeedBank
-
-            need = {float(f) for f in factors if float(f) != 1.0}
-            cache = self.__dict__.setdefault("_banks", {})
-            key = (int(sr), str(device))
-            refused = cache.setdefault("refused", set())
-            if need & refused:
-                return None
-            bank = cache.get(key)
-            if bank is None or not need <= set(bank.factors):
-                have = set() if bank is None else set(bank.factors)
-                # only the factors whose resampling ratio round(sr * f) : sr reduces to one of the mixed launch's compile-time ratios can be
-                # served by a bank; every other factor is refused ON ITS OWN (ADVICE r4: a mini-batch with {0.9, 0.95} used to blacklist 0.9
-                # as well, and every later 0.9 / 1.1 mini-batch silently fell back to the three-launch route)
-                bad = {f for f in need - have if not _bank_ratio_ok(sr, f)}
-                if bad:
-                    refused |= bad
-                    return None
-                try:
-                    bank = cache[key] = HipSpeedBank(sorted(have | need), sr, device)
-                except HipFeatError as e:
-                    if e.status != ERR_UNSUPPORTED:
-                        raise
-                    return None  # (this mini-batch goes per factor; nothing is blacklisted on a guess)
-            return bank
-
-        def _perturb_and_extract(self, audios: List[torch.Tensor], factors: List[float], wants: List[int], sr: int):
-            """Pack the (partly unperturbed) batch, resample the cuts with a pending factor into the tail of the same buffer, extract."""
-            from .augmentation import perturbed_tail_floats
-            from .extractors import _as_1d_float
-
-            ex = self.extractor
-            ex._check_sr(sr)
-            items = [_as_1d_float(a.squeeze() if a.ndim > 1 else a, "HipOnTheFlyFeatures") for a in audios]
-            with torch.no_grad():
-                packed, offs, lens = ex._pack(items)
-                front = int(packed.numel())
-                arena = torch.empty(((front + 3) & ~3) + perturbed_tail_floats(lens, factors, sr), dtype=torch.float32, device=packed.device)
-                arena[:front].copy_(packed, non_blocking=True)
-                zero_pad = getattr(ex.config, "edge_rule", "reflect") == "batch_zero_pad"  # as extract_collated
-                want = np.ascontiguousarray(wants, dtype=np.int64)
-                bank = self._speed_bank(factors, sr, packed.device) if hasattr(ex.plan, "handle") else None
-                if bank is not None:  # ONE launch for all factors + the padding rows, then the feature launch (hipfeat_minibatch_*)
-                    feats, frames, po, pl = bank.extract_collated(ex.plan, arena, np.ascontiguousarray(offs, dtype=np.int64),
-                                                                  np.ascontiguousarray(lens, dtype=np.int64), bank.index_of(factors), front,
-                                                                  float(LOG_EPSILON), max_samples=want, zero_pad_batch=zero_pad)
-                else:  # factors outside the mixed launch's compile-time ratios: one resample launch per factor
-                    po, pl = _perturb_in_arena(arena, offs, lens, factors, sr, front)
-                    pl = np.minimum(pl, want)  # a sample or two to truncate (recording.py:1058-1060)
-                    padded = np.full(len(pl), int(pl.max()), dtype=np.int64) if zero_pad else None
-                    feats, frames = ex.plan.run_collated(arena, po, pl, padded, float(LOG_EPSILON))
-            perturbed = None
-            if self.return_audio:
-                perturbed = [arena[int(o) : int(o) + int(n)].cpu() for o, n in zip(po, pl)]
-            return feats, torch.from_numpy(np.asarray(frames, dtype=np.int64)), perturbed
 
 else:
 

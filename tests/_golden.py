@@ -97,3 +97,33 @@ def record_parity(suite: str, case, kernel: str, got, want, truth, rel_tol: floa
     }
     PARITY_LOG.append(rec)
     return rec
+
+
+def load_driver_goldens():
+    """-> (arrays, meta): what lhotse's own drivers stored / returned with the reference's Fbank on the corpus of oracle/driver_corpus.py
+    (tests/golden/drivers.npz + drivers.json, written by oracle/make_golden_drivers.py under the real lhotse; stored compactly, see
+    `compact` / `expand` there -- the decoder below is `expand`, kept here so that the GPU box needs nothing but the fixtures)."""
+    import json
+
+    with open(os.path.join(GOLDEN_DIR, "drivers.json")) as f:
+        meta = json.load(f)
+    z = dict(np.load(os.path.join(GOLDEN_DIR, "drivers.npz")))
+    pad = np.float32(-23.025850929940457)  # LOG_EPSILON (lhotse/utils.py:50-51)
+    out = {k: v for k, v in z.items() if "@" not in k and not k.endswith("/shape") and not k.startswith("k2_speed/utt")}
+    for k in z:
+        if k.endswith("@rows") and not k.startswith("k2_plain/"):
+            name = k[: -len("@rows")]
+            m = z[f"per_cut/{name.partition('/')[2]}"].copy()
+            m[z[k]] = z[f"{name}@vals"]
+            out[name] = m
+    for tag in ("k2_plain", "k2_speed"):
+        full = np.full(tuple(int(x) for x in z[f"{tag}/shape"]), pad, dtype=np.float32)
+        for i, cid in enumerate(meta[tag]["cut_ids"]):
+            if tag == "k2_plain":
+                m = z[f"per_cut/{cid}"].copy()
+                m[z[f"k2_plain/{cid}@rows"]] = z[f"k2_plain/{cid}@vals"]
+            else:
+                m = z[f"k2_speed/{cid}"]
+            full[i, : len(m)] = m
+        out[f"{tag}/inputs"] = full
+    return out, meta
