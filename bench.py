@@ -942,7 +942,185 @@ class BulkSave:
         self.tmp.cleanup()
 
 
-WORKLOADS = {w.name: w for w in (Fbank16k, Mfcc40Libri, OnTheFly, BulkSave)}
+class Plumbing:
+    """BASELINE configs[0] / SURVEY 8d baseline C on the GPU box: 64 int16 WAV files on tmpfs -> decoding DataLoader worker processes ->
+    features -> storage + gzip JSONL manifest (tools/plumbing.py, which cites the lhotse driver each leg keeps the structure of).  A step =
+    ONE pass of the product's bulk driver (leg C) over `repeat` x 64 cuts; `extra` carries leg B (lhotse's batch-driver structure with
+    lhotse's own per-cut .npy save path around HipFbank) and, as `cpu_baseline`, leg A (the reference's per-cut CPU driver restated:
+    num_jobs = 1 and num_jobs = cores/4).  lhotse itself cannot run here (not installed on the box; a Python reference cannot travel):
+    the REAL drivers are timed next to legs A in the authoring container, profiles/r06_plumbing_container.json."""
+
+    name = "plumbing"
+    host_bound = True
+    metric = "cuts/sec (64 x 10 s 16 kHz int16 WAV files on tmpfs -> decode -> 80-dim log-mel fbank -> storage + manifest; decode-, PCIe- and host-inclusive)"
+    default_cuts = 100  # passes over the 64 files per step (6400 cuts)
+    cpu_mode, cpu_what = "", "Fbank"
+
+    def __init__(self, dev, rank, args):
+        import tempfile
+
+        import numpy as np
+        import torch
+
+        import lhotse_amd
+
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import plumbing as P
+
+        self.P, self.np, self.torch, self.rank = P, np, torch, rank
+        self.repeat = args.cuts or self.default_cuts
+        self.workers = int(os.environ.get("BENCH_LOADER_WORKERS", "0")) or P.default_workers()
+        self.stripes = max(1, int(getattr(args, "stripes", 8) or 8))
+        self.ex = lhotse_amd.HipFbank(lhotse_amd.HipFbankConfig(device=f"cuda:{dev.index}"))
+        self.plan = self.ex.plan
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        self.tmp = tempfile.TemporaryDirectory(prefix=f"hipfeat_plumb_r{rank}_", dir=base)
+        self.fs = "tmpfs (/dev/shm)" if base else "the default temporary directory"
+        self.paths = P.write_corpus(os.path.join(self.tmp.name, "wav"), 64, seed=rank)
+        self.cuts = P.make_cuts(self.paths, self.repeat)
+        self.units = len(self.cuts)
+        self.audio_seconds = 10.0 * self.units
+        self.algo_bytes = ALGO_BYTES_PER_CUT * self.units
+        self.kernel = self.plan.kernel_name
+        self.settle = 0
+        self._run = 0
+        self.last = None
+        self.workload = (f"BASELINE configs[0] with the GPU in it: 64 x 10 s 16 kHz mono int16 WAV files on {self.fs}, visited {self.repeat} x per step "
+                         f"({self.units} cuts, 600 s batches) -> {self.workers} DataLoader worker processes decode (stdlib wave, int16 / 32768) and serialise the manifest "
+                         f"line halves -> hipfeat_host_pipeline -> hip_archive striped over {self.stripes} file(s) + gzip JSONL manifest flushed per batch "
+                         "(the product's bulk driver; lhotse's own drivers cannot run on this box, see extra.plumbing.what)")
+
+    def _dir(self, tag):
+        self._run += 1
+        return os.path.join(self.tmp.name, f"{tag}{self._run}")
+
+    def step(self):
+        import shutil
+
+        prev = self.last
+        self.last = self.P.hip_bulk(self.ex, self.cuts, self._dir("bulk"), self.workers, stripes=self.stripes)
+        if prev:
+            shutil.rmtree(os.path.dirname(prev["manifest"]), ignore_errors=True)
+
+    def clear(self):
+        pass
+
+    def parity(self, rank):
+        """What the last timed pass stored, read back through the manifest + archive reader, against the oracle on the decoded files."""
+        from oracle.kaldi_ref import RefConfig, RefExtractor
+        from oracle.kaldi_torch import reference_f32
+
+        np, P = self.np, self.P
+        o32, o64 = reference_f32(RefConfig(kind="fbank")), RefExtractor(RefConfig(kind="fbank"), np.float64)
+        rs = np.random.RandomState(4321 + rank)
+        stats = []
+        for j in rs.choice(self.units, size=min(16, self.units), replace=False):
+            x = P.read_wav(self.cuts[int(j)].path)[0]
+            stats.append(compare(P.read_back(self.last, int(j)), o32.extract(x), o64.extract(x)))
+        return fold(stats)
+
+    def extra(self, args):
+        import shutil
+
+        P, out = self.P, {}
+        small = P.make_cuts(self.paths, max(1, self.repeat // 4))
+
+        def run(fn, *a, **k):
+            d = self._dir("x")
+            r = fn(*a[:2], d, *a[2:], **k)
+            shutil.rmtree(d, ignore_errors=True)
+            r.pop("archive_paths", None), r.pop("manifest", None)
+            return r
+
+        for wk in sorted({4, self.workers}):
+            run(P.hip_batch_numpy_files, self.ex, small[:640], wk)  # warm (worker start-up, page cache)
+            out[f"B hip_batch_numpy_files (lhotse's batch driver + NumpyFilesWriter path), {wk} loader workers"] = run(P.hip_batch_numpy_files, self.ex, small, wk)
+        for pcm16, half in ((False, False), (True, True)):
+            run(P.hip_bulk, self.ex, small[:640], self.workers, pcm16=pcm16, half=half, stripes=self.stripes)
+            out[f"C hip_bulk ({'int16' if pcm16 else 'float32'} -> {'hip_archive_f16' if half else 'hip_archive'}), {self.workers} loader workers"] = \
+                run(P.hip_bulk, self.ex, self.cuts, self.workers, pcm16=pcm16, half=half, stripes=self.stripes)
+        run(P.hip_bulk, self.ex, small[:640], 4, stripes=self.stripes)
+        out["C hip_bulk (float32 -> hip_archive), 4 loader workers"] = run(P.hip_bulk, self.ex, small, 4, stripes=self.stripes)
+        if not args.no_cpu_baseline:
+            ncpu = len(os.sched_getaffinity(0))
+            for jobs in sorted({1, max(1, min(64, ncpu // 4))}):
+                n = 64 * (2 if jobs == 1 else max(2, min(40, jobs)))
+                out[f"A cpu_per_cut (compute_and_store_features(Fbank(), NumpyFilesWriter, num_jobs={jobs}) restated; kind = port)"] = run(P.cpu_per_cut, P.make_cuts(self.paths, n // 64), jobs)
+        out["what"] = ("cuts/s of whole passes incl. WAV decode, storage and manifest; shares are of wall time.  A = the reference's per-cut CPU driver restated with "
+                       "the reference's torch call sequence as the extractor (oracle/kaldi_torch.py: the checker / baseline, never the product path); B = the structure of "
+                       "CutSet.compute_and_store_features_batch (lhotse/cut/set.py:2296-2408) around HipFbank with lhotse's own save path (one .npy per cut, one "
+                       "json.dumps + flush per cut on ONE save thread); C = the product's bulk driver.  lhotse cannot run on this box; the real drivers are timed "
+                       "next to leg A in the authoring container: profiles/r06_plumbing_container.json")
+        return {"plumbing": out}
+
+    def close(self):
+        self.tmp.cleanup()
+
+
+class _HostEvent:
+    """Stand-in for torch.cuda.Event in the CPU self-test of the N > 1 plumbing (BENCH_SELFTEST_STUB=1): host clock."""
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other) -> float:
+        return (other.t - self.t) * 1e3
+
+
+def _sync(dev) -> None:
+    if dev.type == "cuda":
+        import torch
+
+        torch.cuda.synchronize(dev)
+
+
+def _event_pairs(dev, n: int):
+    if dev.type != "cuda":
+        return [(_HostEvent(), _HostEvent()) for _ in range(n)]
+    import torch
+
+    return [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+
+
+class SelfTestStub:
+    """NOT a measurement: a workload without a device, selected ONLY by BENCH_SELFTEST_STUB=1, so that everything main() does around a
+    workload at N > 1 -- group set-up, the contract's barriers, MAX / gather of the per-rank figures, the parity reduction, the host-fed
+    gather, the assembly of the one JSON line -- can run at world_size 8 over gloo on a machine without GPUs (tests/test_bench_world.py;
+    VERDICT r5 task 6: only the driver can launch 8 GPUs, so the path has to be right by construction)."""
+
+    name = "selftest_stub"
+    host_bound = True
+    metric = "SELF-TEST (no device work): the N > 1 plumbing of bench.py"
+    default_cuts = 10
+    cpu_mode, cpu_what = "", "none"
+
+    def __init__(self, dev, rank, args):
+        self.rank, self.units, self.audio_seconds, self.algo_bytes = rank, 10, 100.0, ALGO_BYTES_PER_CUT * 10
+        self.kernel, self.settle, self.workload = "selftest_stub", 0, "SELF-TEST stub (BENCH_SELFTEST_STUB=1): no device work"
+
+    def step(self):
+        time.sleep(0.001 * (1 + self.rank % 3))
+
+    def clear(self):
+        pass
+
+    def parity(self, rank):
+        import numpy as np
+
+        rs = np.random.RandomState(rank)
+        truth = rs.randn(50, 80) - 5.0
+        want = (truth + 1e-6 * rs.randn(50, 80)).astype(np.float32)
+        got = (want + np.float32(1e-6) * rs.randn(50, 80).astype(np.float32)).astype(np.float32)
+        return fold([compare(got, want, truth)])
+
+    def extra(self, args):
+        return {"host_fed_cuts_per_s": {"batch_60": 100.0 * (self.rank + 1), "what": "self-test"}}
+
+    def close(self):
+        pass
+
+
+WORKLOADS = {w.name: w for w in (Fbank16k, Mfcc40Libri, OnTheFly, BulkSave, Plumbing)}
 
 
 def host_fed(ex, seconds: float = 2.0):
@@ -1068,6 +1246,34 @@ def init_dist(backend: str, dev):
     return dist, backend
 
 
+def group_report(dist, backend_used, world: int, rank: int, local_rank: int, dev, cdev, numa):
+    """`config.group`: what the process group consists of, as seen by EVERY rank (gather_json: all_reduce / all_gather of byte tensors)."""
+    import torch
+
+    me = {"rank": rank, "local_rank": local_rank, "device": str(dev), "visible_devices": torch.cuda.device_count() if torch.cuda.is_available() else 0,
+          "pid": os.getpid(), "numa": numa}
+    if dev.type == "cuda":
+        try:
+            props = torch.cuda.get_device_properties(dev)
+            me["device_name"], me["gcn_arch"] = props.name, getattr(props, "gcnArchName", None)
+            me["pci_bus_id"] = getattr(props, "pci_bus_id", None)
+        except Exception as e:  # noqa: BLE001
+            me["device_name"] = repr(e)
+    out = {"world_size": world, "backend": None if dist is None else ("rccl" if backend_used == "nccl" else backend_used)}
+    if backend_used == "nccl":
+        try:
+            out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:  # noqa: BLE001
+            out["rccl_version"] = repr(e)
+    if dist is None:
+        out["ranks"] = [me]
+        return out
+    out["ranks"] = gather_json(me, dist, world, cdev)
+    out["ranks_seen"] = len(out["ranks"])
+    out["distinct_devices"] = len({(r.get("pci_bus_id"), r["device"]) if r.get("pci_bus_id") is not None else r["device"] for r in out["ranks"]})
+    return out
+
+
 def bind_numa(local_rank: int, mode: str):
     """Bind this rank (and every thread it starts later: packing threads, the save thread, pinned-staging first touch) to the CPUs of
     the NUMA node its GPU hangs off -- lhotse_amd.sharding.bind_to_gpu_numa_node, the helper compute_and_store_features_sharded uses.
@@ -1090,12 +1296,12 @@ def timed_region(w, steps: int, warmup: int, dev, dist, cdev, world: int):
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        _sync(dev)
 
     # everything the timed region needs is prepared BEFORE the warm-up: a device that idles for a millisecond between the warm-up and the
     # timed steps (host-side set-up, a big memset) drops out of its steady power state, and the first ~5 timed launches then run ~20 % slower
     # -- a quarter of the driver's 20 steps (tools/launch_ramp2.py).  Between the two there is only the contract's barrier.
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    evs = _event_pairs(dev, steps)
     if hasattr(w, "settle_device"):
         w.settle_device()
     for _ in range(warmup):
@@ -1277,6 +1483,35 @@ def sub_config(name: str, args, dev, rank: int, dist, cdev, world: int):
         w.close()
 
 
+def sub_plumbing(args, dev, rank: int):
+    """`extra.configs.plumbing`: one warm + two timed passes of the product's bulk driver over 64 WAV files x 50 (leg C), the other legs
+    and the CPU per-cut baseline as its `legs` (tools/plumbing.py) -- BASELINE configs[0] / SURVEY 8d baseline C."""
+    import copy
+
+    a = copy.copy(args)
+    a.cuts = 50
+    w = Plumbing(dev, rank, a)
+    try:
+        w.step()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            w.step()
+        dt = time.perf_counter() - t0
+        out = {"metric": w.metric, "value": round(2 * w.units / dt, 1), "unit": "cuts/s", "steps": 2, "warmup": 1, "ms_per_step": round(dt / 2 * 1e3, 2),
+               "workload": w.workload, "cuts_per_step": w.units, "stage_split_of_the_last_pass": {k: v for k, v in w.last.items() if k.endswith("_share")}}
+        if not args.no_parity:
+            from oracle import parity_bar
+
+            f = w.parity(rank)
+            v = parity_bar.verdict(f)
+            out["parity"] = {"pass": v["pass"], "rel_l2_max": float(f"{f['rel_l2_max']:.3e}"), "max_abs_max": float(f"{f['max_abs_max']:.3e}"), "n": f["n"],
+                             "what": "cuts read back through the manifest + archive reader of the last timed pass vs the oracle on the decoded files"}
+        out["legs"] = w.extra(a)["plumbing"]
+        return out
+    finally:
+        w.close()
+
+
 def after_idle(w, dev, idle_s: float = 2.0, launches: int = 25):
     """The OTHER regime (VERDICT r4 / ADVICE r4): the package idles for `idle_s`, then `launches` back-to-back launches with no settle --
     the per-launch times of the ramp, and the rate the contract's 5 warm-ups + 20 steps see on their own."""
@@ -1359,7 +1594,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default per config: >= 1 s of GPU time)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="fbank16k", choices=sorted(WORKLOADS), help="fbank16k = BASELINE configs[1] (default), mfcc40_libri = configs[3], onthefly = configs[4], bulk_save = the offline path end to end (SURVEY 8d iii)")
+    ap.add_argument("--config", default="fbank16k", choices=sorted(WORKLOADS), help="fbank16k = BASELINE configs[1] (default), mfcc40_libri = configs[3], onthefly = configs[4], bulk_save = the offline path end to end (SURVEY 8d iii), plumbing = configs[0] with the GPU in it (WAV files -> decode -> features -> storage + manifest)")
     ap.add_argument("--cuts", type=int, default=0, help="cuts per GPU per step (onthefly: mini-batches per step); default per config")
     ap.add_argument("--prefetch", type=int, default=1, help="onthefly: mini-batches per call (a loader that prefetches K packs them into one arena and gets K dense tensors "
                     "from ONE pair of launches); default 1")
@@ -1382,7 +1617,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default; falls back to gloo if it cannot be initialised) or gloo (self-test of the N>1 path on one GPU)")
     args = ap.parse_args()
     if not args.steps:
-        args.steps = {"fbank16k": 250, "mfcc40_libri": 200, "onthefly": 60, "bulk_save": 5}[args.config]
+        args.steps = {"fbank16k": 250, "mfcc40_libri": 200, "onthefly": 60, "bulk_save": 5, "plumbing": 3}[args.config]
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)  # does not return
@@ -1394,22 +1629,30 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
-    # one GPU per rank; ranks wrap around when fewer devices are visible (a launcher that narrows *_VISIBLE_DEVICES per rank, or the
-    # gloo self-test where all ranks share the one GPU of the box)
-    local_rank = local_rank % torch.cuda.device_count()
+    stub = bool(os.environ.get("BENCH_SELFTEST_STUB"))  # the N > 1 plumbing without a device (SelfTestStub): tests only, says so in the line
     all_cpus = sorted(os.sched_getaffinity(0))
-    numa = bind_numa(local_rank, args.numa)  # before the first pinned allocation and before any worker thread exists
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if stub:
+        dev = torch.device("cpu")
+        numa = {"bound": False, "why": "BENCH_SELFTEST_STUB: no device", "rank": rank}
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback in the product path)"
+        # one GPU per rank; ranks wrap around when fewer devices are visible (a launcher that narrows *_VISIBLE_DEVICES per rank, or the
+        # gloo self-test where all ranks share the one GPU of the box)
+        local_rank = local_rank % torch.cuda.device_count()
+        numa = bind_numa(local_rank, args.numa)  # before the first pinned allocation and before any worker thread exists
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist, backend_used = None, None
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):  # BENCH_FORCE_DIST: exercise the RCCL path with a single rank (self-test)
-        dist, backend_used = init_dist(args.dist_backend, dev)
+        dist, backend_used = init_dist("gloo" if stub else args.dist_backend, dev)
     cdev = dev if (dist is not None and backend_used == "nccl") else torch.device("cpu")  # where collective tensors live
+    # who is in the group: every rank's device, visible-device count, NUMA binding and (on RCCL) the library version, gathered with the same
+    # plain tensor collectives as everything else -- the driver's first 8-GPU record then PROVES that RCCL saw 8 ranks on 8 devices
+    group = group_report(dist, backend_used, world, rank, local_rank, dev, cdev, numa)
 
     if args.total_cuts and args.config != "fbank16k":
         ap.error("--total-cuts is defined for --config fbank16k")
-    w = WORKLOADS[args.config](dev, rank, args)
+    w = (SelfTestStub if stub else WORKLOADS[args.config])(dev, rank, args)
 
     tr = timed_region(w, args.steps, args.warmup, dev, dist, cdev, world)
     elapsed, launch_ms = tr["elapsed"], tr["launch_ms"]
@@ -1421,7 +1664,7 @@ def main():
 
     # ---- the other BASELINE configs under the same (driver) clock: configs[3] and configs[4], every rank, same contract
     other = {}
-    if args.config == "fbank16k" and not args.no_other_configs and not args.no_extra and not args.total_cuts and args.input == "uniform":
+    if args.config == "fbank16k" and not args.no_other_configs and not args.no_extra and not args.total_cuts and args.input == "uniform" and not stub:
         for name in ("mfcc40_libri", "onthefly"):
             other[name] = sub_config(name, args, dev, rank, dist, cdev, world)
 
@@ -1430,12 +1673,23 @@ def main():
     if not args.no_extra:
         if dist is not None:
             dist.barrier()
-        local = w.extra(args)
+        try:
+            local = w.extra(args) or {}
+        except Exception as e:  # noqa: BLE001 -- every rank must still take part in the collectives below: an error travels as data
+            local = {"error": repr(e)}
         if dist is not None:
             dist.barrier()
-        extra = gather_extras(local, dist, world, cdev) if local else {}
-        if args.config == "fbank16k" and hasattr(w, "settle_device"):
+        extra = gather_extras(local, dist, world, cdev)  # unconditionally, on every rank
+        if args.config == "fbank16k" and hasattr(w, "settle_device") and not stub:
             extra.update(after_idle(w, dev))
+    # ---- BASELINE configs[0] with the GPU in it (WAV files -> decode -> features -> storage + manifest): N = 1 only (a host-bound leg per
+    # rank would only measure the ranks' competition for the host), after everything else, and never at the cost of the line
+    if (args.config == "fbank16k" and world == 1 and not args.no_other_configs and not args.no_extra and not args.total_cuts and args.input == "uniform"
+            and not stub and not os.environ.get("BENCH_NO_PLUMBING")):
+        try:
+            other["plumbing"] = sub_plumbing(args, dev, rank)
+        except Exception as e:  # noqa: BLE001
+            other["plumbing"] = {"error": repr(e)}
     if other:
         extra["configs"] = other
 
@@ -1471,6 +1725,9 @@ def main():
                 "dist_backend": None if dist is None else ("rccl" if backend_used == "nccl" else backend_used),
                 "rank_launch_ms": [round(x, 4) for x in tr["rank_launch_ms"]],
                 "numa": numa,
+                "numa_per_rank": [r.get("numa") for r in group["ranks"]],
+                "group": group,
+                **({"SELFTEST": "BENCH_SELFTEST_STUB=1: no device work was done; this line is NOT a measurement"} if stub else {}),
             },
             "parity": parity,
             "roofline": roof,
@@ -1499,7 +1756,7 @@ def main():
             }
         if extra:
             res["extra"] = extra
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not stub:
             os.sched_setaffinity(0, all_cpus)  # the CPU baseline's worker processes get the whole host, whatever --numa did to this rank
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.cpu_procs, w.cpu_mode, w.cpu_what)
         print(json.dumps(res), flush=True)

@@ -1,0 +1,369 @@
+"""
+BASELINE configs[0] / SURVEY 8d "Config 1" + baseline C: the PLUMBING around the extractor -- int16 WAV files on tmpfs -> decode ->
+features -> one .npy per cut (or the product's archive) + a gzip JSONL manifest -- as cuts/s, with the stage split.
+
+Why this module restates lhotse's driver loops instead of calling them: lhotse is not installed on the GPU box and a Python reference
+cannot travel there (task rules).  Each leg keeps the STRUCTURE of the driver it stands for (processes, threads, argument forms, what is
+written, when it is flushed) and cites it; tools/plumbing_reference.py runs the REAL drivers next to legs A1 / A2 in the authoring container
+(8 vCPU, no GPU) so that the restated loops can be read against the real ones on the same machine (profiles/r06_plumbing_container.json).
+
+  A  cpu_per_cut(num_jobs)    CutSet.compute_and_store_features(Fbank(), NumpyFilesWriter, num_jobs)         lhotse/cut/set.py:1981-2195
+                              N processes x torch.set_num_threads(1) (bin/modes/features.py:25-32): decode -> Fbank.extract -> np.save
+                              -> manifest line.  The extractor is the reference's own torch call sequence (oracle/kaldi_torch.py, bit-equal
+                              to the live reference): `cpu_baseline.kind == "port"`.  CHECKER / BASELINE ONLY (the one leg that touches oracle/).
+  B  hip_batch_numpy_files    CutSet.compute_and_store_features_batch(HipFbank(), NumpyFilesWriter, num_workers=W)   lhotse/cut/set.py:2197-2408
+                              DataLoader worker processes decode -> extract_batch(list of (1, T)) on the main thread under no_grad ->
+                              ONE save thread: per cut .npy + json.dumps(manifest dict) into a gzip JSONL, flushed per cut.
+  C  hip_bulk                 lhotse_amd.compute_and_store_features_batch's native route (storage.py): workers decode AND serialise the
+                              line halves -> hipfeat_host_pipeline (pack / H2D / kernel / D2H) -> archive thread (hipfeat_archive_append,
+                              striped) -> manifest thread (hipfeat_manifest_lines + gzip + flush per batch).
+
+The corpus: 64 x 10 s 16 kHz mono int16 WAVs of seeded uniform noise (the content does not matter to any stage); a pass visits every file
+`repeat` times (cut ids differ, as several cuts of one recording would) so that a timed leg lasts about a second.
+"""
+from __future__ import annotations
+
+import dataclasses
+import gzip
+import json
+import os
+import sys
+import time
+import wave
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List, Optional
+
+import numpy as np
+
+SR = 16000
+SAMPLES = 160000
+FRAMES = 1000
+NUM_MELS = 80
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# corpus
+# ----------------------------------------------------------------------------------------------------------------------------------
+def write_corpus(directory: str, n_files: int = 64, seed: int = 0) -> List[str]:
+    os.makedirs(directory, exist_ok=True)
+    rs = np.random.RandomState(seed)
+    paths = []
+    for i in range(n_files):
+        pcm = (rs.uniform(-0.5, 0.5, size=SAMPLES) * 32767.0).astype(np.int16)
+        p = os.path.join(directory, f"rec{i:03d}.wav")
+        with wave.open(p, "wb") as f:
+            f.setnchannels(1)
+            f.setsampwidth(2)
+            f.setframerate(SR)
+            f.writeframes(pcm.tobytes())
+        paths.append(p)
+    return paths
+
+
+def read_wav(path: str, pcm16: bool = False) -> np.ndarray:
+    """(1, T): float32 = int16 / 32768 (what lhotse's audio backends return for a PCM_16 file), or the int16 samples themselves."""
+    with wave.open(path, "rb") as f:
+        raw = f.readframes(f.getnframes())
+    x = np.frombuffer(raw, dtype=np.int16)
+    return x.reshape(1, -1).copy() if pcm16 else (x.astype(np.float32) / 32768.0).reshape(1, -1)
+
+
+@dataclasses.dataclass
+class Sup:  # the JSON-scalar fields of a SupervisionSegment (lhotse/supervision.py:44-120)
+    id: str
+    recording_id: str
+    start: float
+    duration: float
+    channel: int = 0
+    text: str = None
+    language: str = None
+    speaker: str = None
+    gender: str = None
+    custom: dict = None
+    alignment: dict = None
+
+
+@dataclasses.dataclass
+class Src:
+    type: str
+    channels: list
+    source: str
+
+
+@dataclasses.dataclass
+class Rec:  # Recording (lhotse/audio/recording.py:59-120)
+    id: str
+    sources: list
+    sampling_rate: int
+    num_samples: int
+    duration: float
+    channel_ids: list = None
+    transforms: list = None
+
+
+class Cut:  # what lhotse_amd.storage._mono_cut_dict reads off a MonoCut
+    __slots__ = ("id", "start", "duration", "channel", "recording_id", "supervisions", "custom", "recording", "sampling_rate", "path")
+
+
+def make_cuts(paths: List[str], repeat: int) -> List[Cut]:
+    cuts = []
+    for r in range(repeat):
+        for i, p in enumerate(paths):
+            c = Cut()
+            n = r * len(paths) + i
+            c.id, c.start, c.duration, c.channel, c.recording_id, c.sampling_rate, c.path = f"cut-{n:07d}", 0.0, SAMPLES / SR, 0, f"rec{i:03d}", SR, p
+            c.supervisions = [Sup(id=c.id, recording_id=c.recording_id, start=0.0, duration=c.duration, text="SYNTHETIC UTTERANCE " * 4, language="English",
+                                  speaker=f"spk{n % 251}")]
+            c.custom = None
+            c.recording = Rec(id=c.recording_id, sources=[Src("file", [0], p)], sampling_rate=SR, num_samples=SAMPLES, duration=c.duration, channel_ids=[0])
+            cuts.append(c)
+    return cuts
+
+
+def batches_of(cuts: List[Cut], batch_cuts: int = 60) -> List[List[int]]:
+    """600 s batches (lhotse's default batch_duration): 60 x 10 s."""
+    return [list(range(i, min(i + batch_cuts, len(cuts)))) for i in range(0, len(cuts), batch_cuts)]
+
+
+def cut_manifest_dict(c: Cut, feat: Dict) -> Dict:
+    """MonoCut.to_dict() with features attached (lhotse/cut/mono.py, features/base.py:556-600), None fields dropped as asdict_nonull does."""
+    nn = lambda d: {k: v for k, v in d.items() if v is not None}  # noqa: E731
+    return {"id": c.id, "start": c.start, "duration": c.duration, "channel": c.channel,
+            "supervisions": [nn(dataclasses.asdict(s)) for s in c.supervisions], "features": feat,
+            "recording": nn({**dataclasses.asdict(c.recording), "sources": [dataclasses.asdict(s) for s in c.recording.sources]}), "type": "MonoCut"}
+
+
+def features_dict(c: Cut, type_name: str, num_frames: int, storage_type: str, storage_path: str, storage_key: str) -> Dict:
+    return {"type": type_name, "num_frames": num_frames, "num_features": NUM_MELS, "frame_shift": 0.01, "sampling_rate": SR, "start": c.start,
+            "duration": c.duration, "storage_type": storage_type, "storage_path": storage_path, "storage_key": storage_key,
+            "recording_id": c.recording_id, "channels": c.channel}
+
+
+def numpy_files_write(storage_dir: str, key: str, value: np.ndarray) -> str:
+    """NumpyFilesWriter.write (lhotse/features/io.py:499-525)."""
+    sub = os.path.join(storage_dir, key[:3])
+    os.makedirs(sub, exist_ok=True)
+    np.save(os.path.join(sub, key + ".npy"), value, allow_pickle=False)
+    return os.path.join(key[:3], key + ".npy")
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# leg A: the CPU per-cut driver (baseline C of SURVEY 8d), restated; oracle/ is touched HERE ONLY
+# ----------------------------------------------------------------------------------------------------------------------------------
+def _cpu_job(job: int, cuts: List[Cut], out_dir: str) -> int:
+    import torch
+
+    torch.set_num_threads(1)  # lhotse/bin/modes/features.py:25-32
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle.kaldi_torch import TorchFbank
+
+    ex = TorchFbank()
+    store = os.path.join(out_dir, f"feats-{job}")
+    with gzip.open(os.path.join(out_dir, f"cuts-{job}.jsonl.gz"), "wt") as man:
+        for c in cuts:
+            feats = ex.extract(read_wav(c.path)[0])
+            key = numpy_files_write(store, c.id, feats)
+            assert feats.shape == (FRAMES, NUM_MELS)
+            man.write(json.dumps(cut_manifest_dict(c, features_dict(c, "kaldi-fbank", feats.shape[0], "numpy_files", store, key))) + "\n")
+    return len(cuts)
+
+
+def cpu_per_cut(cuts: List[Cut], out_dir: str, num_jobs: int) -> Dict:
+    """Leg A.  Job i takes cuts i, i + N, ... (LazySlicer, cut/set.py:2158-2160); worker processes are forked HERE (the reference spawns:
+    process start-up is outside the timed loop of a corpus-sized run either way, so it is excluded: workers are started, warmed with one
+    cut, then released together)."""
+    import multiprocessing as mp
+
+    os.makedirs(out_dir, exist_ok=True)
+    ctx = mp.get_context("fork")
+    go, ready = ctx.Event(), ctx.Queue()
+    res = ctx.Queue()
+
+    def body(j):
+        try:
+            _cpu_job(j, cuts[:1], os.path.join(out_dir, f"warm{j}"))  # imports, first-call costs
+            ready.put(j)
+            go.wait()
+            t0 = time.perf_counter()
+            n = _cpu_job(j, cuts[j::num_jobs], out_dir)
+            res.put((n, time.perf_counter() - t0))
+        except BaseException as e:  # noqa: BLE001
+            ready.put(-1)
+            res.put((0, repr(e)))
+
+    ps = [ctx.Process(target=body, args=(j,)) for j in range(num_jobs)]
+    for p in ps:
+        os.makedirs(os.path.join(out_dir, f"warm{ps.index(p)}"), exist_ok=True)
+        p.start()
+    for _ in ps:
+        ready.get(timeout=300)
+    t0 = time.perf_counter()
+    go.set()
+    outs = [res.get(timeout=1200) for _ in ps]
+    wall = time.perf_counter() - t0
+    for p in ps:
+        p.join(timeout=30)
+    n = sum(o[0] for o in outs)
+    return {"cuts_per_s": round(n / wall, 1), "cuts": n, "seconds": round(wall, 3), "num_jobs": num_jobs,
+            "per_process_cuts_per_s": round(n / wall / num_jobs, 1), "errors": [o[1] for o in outs if isinstance(o[1], str)] or None}
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# loader side of legs B / C (DataLoader worker processes)
+# ----------------------------------------------------------------------------------------------------------------------------------
+class DecodeDataset:
+    """UnsupervisedWaveformDataset(collate=False) (lhotse/dataset/unsupervised.py:46-82) over WAV paths; with `template` it also
+    serialises the two halves of every cut's manifest line, as lhotse_amd.storage's FragmentingWaveformDataset does in the workers."""
+
+    def __init__(self, cuts: List[Cut], pcm16: bool = False, template: Optional[Dict] = None, frame_shift: float = 0.01):
+        self.cuts, self.pcm16, self.template, self.frame_shift = cuts, pcm16, template, frame_shift
+        self._rc = {}
+
+    def __getitem__(self, idx: List[int]):
+        audio = [read_wav(self.cuts[i].path, self.pcm16) for i in idx]
+        out = {"idx": list(idx), "audio": audio}
+        if self.template is not None:
+            from lhotse_amd.storage import manifest_fragments
+
+            out["frags"] = [manifest_fragments(self.cuts[i], self.template, self.frame_shift, self._rc) for i in idx]
+        return out
+
+
+def _loader(ds, batches, num_workers: int):
+    from torch.utils.data import DataLoader
+
+    return DataLoader(ds, batch_size=None, sampler=batches, num_workers=num_workers, prefetch_factor=4 if num_workers else None,
+                      persistent_workers=False)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# leg B: lhotse's batch driver around HipFbank, lhotse's own save path
+# ----------------------------------------------------------------------------------------------------------------------------------
+def hip_batch_numpy_files(ex, cuts: List[Cut], out_dir: str, num_workers: int, keep: Optional[Dict] = None) -> Dict:
+    import torch
+
+    os.makedirs(out_dir, exist_ok=True)
+    store = os.path.join(out_dir, "feats")
+    batches = batches_of(cuts)
+    busy = {"save": 0.0}
+
+    def _save_worker(man, idx, features):
+        t0 = time.perf_counter()
+        for i, feat_mat in zip(idx, features):
+            c = cuts[i]
+            if isinstance(feat_mat, torch.Tensor):
+                feat_mat = feat_mat.cpu().numpy()
+            key = numpy_files_write(store, c.id, feat_mat)
+            assert feat_mat.shape == (FRAMES, NUM_MELS), feat_mat.shape  # validate_features' frame-count contract
+            man.write(json.dumps(cut_manifest_dict(c, features_dict(c, ex.name, feat_mat.shape[0], "numpy_files", store, key))) + "\n")
+            man.flush()  # cuts_writer.write(cut, flush=True), cut/set.py:2363
+            if keep is not None and i in keep:
+                keep[i] = feat_mat.copy()
+        busy["save"] += time.perf_counter() - t0
+
+    t_ext = t_load = 0.0
+    futures = []
+    t0 = time.perf_counter()
+    with gzip.open(os.path.join(out_dir, "cuts.jsonl.gz"), "wt") as man, ThreadPoolExecutor(max_workers=1) as executor:
+        it = iter(_loader(DecodeDataset(cuts), batches, num_workers))
+        while True:
+            ta = time.perf_counter()
+            try:
+                batch = next(it)
+            except StopIteration:
+                break
+            tb = time.perf_counter()
+            with torch.no_grad():
+                features = ex.extract_batch(batch["audio"], sampling_rate=SR)
+            t_ext += time.perf_counter() - tb
+            t_load += tb - ta
+            futures.append(executor.submit(_save_worker, man, batch["idx"], features))
+        for f in futures:
+            f.result()
+    wall = time.perf_counter() - t0
+    return {"cuts_per_s": round(len(cuts) / wall, 1), "cuts": len(cuts), "seconds": round(wall, 3), "num_workers": num_workers,
+            "main_thread_waiting_for_the_loader_share": round(t_load / wall, 3), "main_thread_extract_share": round(t_ext / wall, 3),
+            "save_thread_busy_share": round(busy["save"] / wall, 3)}
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# leg C: the product's bulk driver (native pipeline + striped archive + spliced lines), fed by decoding workers
+# ----------------------------------------------------------------------------------------------------------------------------------
+def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = False, half: bool = False, stripes: int = 8) -> Dict:
+    from lhotse_amd import storage as S
+
+    os.makedirs(out_dir, exist_ok=True)
+    storage = "hip_archive_f16" if half else "hip_archive"
+    template = {"type": ex.name, "num_features": NUM_MELS, "frame_shift": ex.frame_shift, "sampling_rate": SR, "storage_type": storage, "storage_path": ""}
+    batches = batches_of(cuts)
+    busy = {"save": 0.0, "wait": 0.0, "lines": 0.0}
+    stats: Dict = {}
+    t_load = [0.0]
+
+    def timed_batches(loader):
+        it = iter(loader)
+        while True:
+            ta = time.perf_counter()
+            try:
+                b = next(it)
+            except StopIteration:
+                return
+            t_load[0] += time.perf_counter() - ta
+            yield b
+
+    t0 = time.perf_counter()
+    with gzip.open(os.path.join(out_dir, "cuts.jsonl.gz"), "wb") as manifest, \
+            S.NativeArchive(os.path.join(out_dir, "feats"), mode="w", np_dtype="<f2" if half else "<f4", stripes=stripes, name=storage) as ar:
+
+        def extract(batch):
+            pending, frames = S._batch_features_pending(ex, [a.reshape(-1) for a in batch["audio"]], SR, None, half=half)
+            return batch["frags"], pending, frames
+
+        def save(frags, pending, frames):
+            ta = time.perf_counter()
+            host = pending.wait()
+            tb = time.perf_counter()
+            fr = np.ascontiguousarray(frames, dtype=np.int64)
+            file_of, byte_off = ar.append(host, fr)
+            del host
+            pending.release()
+            busy["wait"] += tb - ta
+            busy["save"] += time.perf_counter() - tb
+            return frags, fr, file_of, byte_off
+
+        def lines(frags, fr, file_of, byte_off):
+            ta = time.perf_counter()
+            blob = ar.lines([f[0] for f in frags], [f[1] for f in frags], fr, np.fromiter((f[2] for f in frags), dtype=np.int64, count=len(frags)),
+                            file_of, byte_off, NUM_MELS)
+            manifest.write(blob)
+            manifest.flush()
+            busy["lines"] += time.perf_counter() - ta
+
+        S.pump_batches(timed_batches(_loader(DecodeDataset(cuts, pcm16=pcm16, template=template, frame_shift=ex.frame_shift), batches, num_workers)),
+                       extract, save, stats=stats, finish=lines)
+        paths = [str(p) for p in ar.paths]
+    wall = time.perf_counter() - t0
+    return {"cuts_per_s": round(len(cuts) / wall, 1), "cuts": len(cuts), "seconds": round(wall, 3), "num_workers": num_workers, "input": "int16" if pcm16 else "float32",
+            "storage": storage, "stripes": stripes, "main_thread_waiting_for_the_loader_share": round(t_load[0] / wall, 3),
+            "main_thread_submit_share": round(stats.get("extract_s", 0.0) / wall, 3), "main_thread_blocked_on_the_save_threads_share": round(stats.get("wait_s", 0.0) / wall, 3),
+            "archive_thread_busy_share": round(busy["save"] / wall, 3), "archive_thread_waiting_for_the_device_share": round(busy["wait"] / wall, 3),
+            "manifest_thread_busy_share": round(busy["lines"] / wall, 3), "archive_paths": paths, "manifest": os.path.join(out_dir, "cuts.jsonl.gz")}
+
+
+def read_back(result: Dict, index: int) -> np.ndarray:
+    """Cut `index` of a leg-C run, through the archive reader named by its manifest line."""
+    from lhotse_amd import storage as S
+
+    with gzip.open(result["manifest"], "rt") as f:
+        for k, ln in enumerate(f):
+            if k == index:
+                d = json.loads(ln)["features"]
+                return S.HipArchiveReader(d["storage_path"]).read(d["storage_key"])
+    raise IndexError(index)
+
+
+def default_workers() -> int:
+    n = len(os.sched_getaffinity(0))
+    return max(2, min(32, n // 4))
