@@ -1041,11 +1041,15 @@ class Plumbing:
                 run(P.hip_bulk, self.ex, self.cuts, self.workers, pcm16=pcm16, half=half, stripes=self.stripes)
         run(P.hip_bulk, self.ex, small[:640], 4, stripes=self.stripes)
         out["C hip_bulk (float32 -> hip_archive), 4 loader workers"] = run(P.hip_bulk, self.ex, small, 4, stripes=self.stripes)
+        out[f"C hip_bulk (float32 -> hip_archive), {self.workers} loader workers, one array per cut through the worker queue (lhotse's transport)"] = \
+            run(P.hip_bulk, self.ex, small, self.workers, stripes=self.stripes, packed=False)
         if not args.no_cpu_baseline:
             ncpu = len(os.sched_getaffinity(0))
             for jobs in sorted({1, max(1, min(64, ncpu // 4))}):
                 n = 64 * (2 if jobs == 1 else max(2, min(40, jobs)))
-                out[f"A cpu_per_cut (compute_and_store_features(Fbank(), NumpyFilesWriter, num_jobs={jobs}) restated; kind = port)"] = run(P.cpu_per_cut, P.make_cuts(self.paths, n // 64), jobs)
+                d = self._dir("a")
+                out[f"A cpu_per_cut (compute_and_store_features(Fbank(), NumpyFilesWriter, num_jobs={jobs}) restated; kind = port)"] = P.cpu_per_cut(P.make_cuts(self.paths, n // 64), d, jobs)
+                shutil.rmtree(d, ignore_errors=True)
         out["what"] = ("cuts/s of whole passes incl. WAV decode, storage and manifest; shares are of wall time.  A = the reference's per-cut CPU driver restated with "
                        "the reference's torch call sequence as the extractor (oracle/kaldi_torch.py: the checker / baseline, never the product path); B = the structure of "
                        "CutSet.compute_and_store_features_batch (lhotse/cut/set.py:2296-2408) around HipFbank with lhotse's own save path (one .npy per cut, one "
@@ -1498,7 +1502,10 @@ def sub_plumbing(args, dev, rank: int):
             w.step()
         dt = time.perf_counter() - t0
         out = {"metric": w.metric, "value": round(2 * w.units / dt, 1), "unit": "cuts/s", "steps": 2, "warmup": 1, "ms_per_step": round(dt / 2 * 1e3, 2),
-               "workload": w.workload, "cuts_per_step": w.units, "stage_split_of_the_last_pass": {k: v for k, v in w.last.items() if k.endswith("_share")}}
+               "workload": w.workload, "cuts_per_step": w.units,
+               "last_pass": {k: v for k, v in w.last.items() if k.endswith("_share") or k in ("cuts_per_s", "cuts_per_s_incl_worker_start", "seconds_to_first_batch", "transport")},
+               "what": "value = whole passes incl. the start of the loader's worker processes (a pass is ~1 s: a corpus-sized run amortises that start); "
+                       "last_pass.cuts_per_s = the rate behind the first batch"}
         if not args.no_parity:
             from oracle import parity_bar
 

@@ -180,7 +180,10 @@ __global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 
       {
         const float* x = xs + mul24(g, shift) + 2 * q;
         v2 z[32];
-        v2 win[NROWS];
+        // with all 32 input rows live the window (64 more VGPRs) put 8 registers into scratch (VERDICT r5 task 7): there it is fetched in
+        // two bursts of 16 rows after the mean, in front of the rows it multiplies -- same products, bit-identical
+        constexpr bool kWinLate = NROWS == 32;
+        v2 win[kWinLate ? 16 : NROWS];
         float pv[NROWS];  // left neighbour of each pair's first sample (the frame's first sample replicates itself, layers.py:166)
 #pragma unroll
         for (int n1 = 0; n1 < NROWS; ++n1) {
@@ -190,10 +193,12 @@ __global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 
         }
 #pragma unroll
         for (int n1 = 0; n1 < NROWS; ++n1) pv[n1] = n1 == 0 ? x[q == 0 ? 0 : -1] : x[64 * n1 - 1];
+        if (!kWinLate) {
 #pragma unroll
-        for (int n1 = 0; n1 < NROWS; ++n1) {
-          win[n1] = cwin[n1 * 32 + q];
-          HFC_SEP();
+          for (int n1 = 0; n1 < NROWS; ++n1) {
+            win[n1] = cwin[n1 * 32 + q];
+            HFC_SEP();
+          }
         }
         // the pass twiddles W_1024^(q k1) come from global memory (L1): requested BEFORE the next span, so that the wait for them
         // (vmcnt is in order) does not include the span's trip to HBM
@@ -237,24 +242,37 @@ __global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 
         // y[n] = (x[n] - mu) - c (x[n-1] - mu) = x[n] - c x[n-1] - (1 - c) mu, times the window
         {
           const float nc = -c, mu1 = (1.0f - c) * mu;
+          if (kWinLate) {
 #pragma unroll
-          for (int n1 = 0; n1 < NROWS; ++n1) {
-            v2 t;
-            t.x = fmaf(nc, pv[n1], z[n1].x);
-            t.y = fmaf(nc, z[n1].x, z[n1].y);
-            z[n1] = (t - v2{mu1, mu1}) * win[n1];
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                win[i] = cwin[(16 * h + i) * 32 + q];
+                HFC_SEP();
+              }
+#pragma unroll
+              for (int i = 0; i < 16; ++i) {
+                const int n1 = 16 * h + i;
+                v2 t;
+                t.x = fmaf(nc, pv[n1 < NROWS ? n1 : 0], z[n1].x);
+                t.y = fmaf(nc, z[n1].x, z[n1].y);
+                z[n1] = (t - v2{mu1, mu1}) * win[i];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int n1 = 0; n1 < NROWS; ++n1) {
+              v2 t;
+              t.x = fmaf(nc, pv[n1], z[n1].x);
+              t.y = fmaf(nc, z[n1].x, z[n1].y);
+              z[n1] = (t - v2{mu1, mu1}) * win[n1];
+            }
           }
         }
 #pragma unroll
         for (int n1 = NROWS; n1 < 32; ++n1) z[n1] = v2{0.f, 0.f};
         fft32<NROWS>(z, a);
-        if (kTwLate && kPrefetch) {
-          asm volatile("" : "+v"(a[0].x), "+v"(a[31].y) : : "memory");  // not before the FFT's results exist (hipcc would hoist the loads)
-#pragma unroll
-          for (int k1 = 1; k1 < 32; ++k1) twp[k1] = gt[k1 * 32];
-          if (r + 1 < p.rounds && f0 + 2 * nwaves < cd.num_frames) stage_span(f0 + 2 * nwaves, (unsigned)lane_o * 4u);
-        }
-        if (kTwLate && !kPrefetch) {  // two bursts of 16: request, multiply, request, multiply
+        if (kTwLate) {  // two bursts of 16: request, multiply, request, multiply
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             asm volatile("" : "+v"(a[16 * h].x), "+v"(a[16 * h + 15].y) : : "memory");
@@ -263,6 +281,7 @@ __global__ __launch_bounds__(64 * (W12 ? kXWavesFixed : kXMaxWaves), (W12 ? 3 : 
 #pragma unroll
             for (int k1 = 16 * h + (h == 0 ? 1 : 0); k1 < 16 * h + 16; ++k1) a[k1] = cmul2(a[k1], twp[k1]);
           }
+          if (kPrefetch && r + 1 < p.rounds && f0 + 2 * nwaves < cd.num_frames) stage_span(f0 + 2 * nwaves, (unsigned)lane_o * 4u);
         } else {
 #pragma unroll
           for (int k1 = 1; k1 < 32; ++k1) a[k1] = cmul2(a[k1], twp[k1]);

@@ -43,7 +43,8 @@ __device__ __forceinline__ float row8i_negate_index(float keep, float v) {
 
 // OUT = 0 fbank, 1 MFCC, 2 (log-)spectrogram -- see kernel_fft512b.hpp
 template <int NROWS, int OUT>
-__global__ __launch_bounds__(256, 5) void fft256_kernel(const Fft512Params p) {
+// (16 live input rows: 2-3 VGPRs went to scratch under the 5-blocks register cap; those instances take 4 blocks per CU -- VERDICT r5 task 7)
+__global__ __launch_bounds__(256, (NROWS > 13 ? 4 : 5)) void fft256_kernel(const Fft512Params p) {
   constexpr bool MFCC = OUT == 1, SPEC = OUT == 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   HF_POISON_LDS(smem);

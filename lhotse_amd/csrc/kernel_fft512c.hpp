@@ -171,8 +171,19 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
   // window on top of that does not fit (10 spilled registers, - 2.5 %).
   constexpr bool kMfcc = MODE == 2 || MODE == 3;
   constexpr int DCH = MODE == 3 ? kCDctChunksSmall : kCDctChunks;
+#ifdef HIPFEAT_ABL_MFCC_TWS  // round-6 experiment (VERDICT r5 task 4): MODE 2 keeps the split-step twiddles in registers as MODE 3 does, paid for
+  // by reading the last four chunks of DCT operands from memory every round (tools/r6_mfcc_ab.sh; result in DESIGN section 4.1)
+  constexpr bool kTwsExp = MODE == 2 && NROWS <= 13;
+#else
+  constexpr bool kTwsExp = false;
+#endif
+  // chunks of DCT operands resident in registers: all of them, except where they do not fit -- with 16 live input rows (32 ms frames) MODE 2
+  // spilled 17 VGPRs into scratch (VERDICT r5 task 7: no instance with scratch); there 5 of the 10 chunks stay resident and the other 5 are
+  // re-read from memory (L1 / L2 hits, 5 x 16 B per lane) while the filterbank runs.  Same operands in the same order: bit-identical.
+  constexpr int DREG = kTwsExp ? 6 : (MODE == 2 && NROWS > 13) ? 5 : DCH;
+  constexpr bool kDctLate = DREG < DCH;
   constexpr bool kRegTw = !kMfcc && NROWS <= 13;  // (16 live input rows leave no room either: 24 spilled registers)
-  constexpr bool kRegTws = kRegTw || (MODE == 3 && NROWS <= 13);  // the split-step twiddles alone
+  constexpr bool kRegTws = kRegTw || (MODE == 3 && NROWS <= 13) || kTwsExp;  // the split-step twiddles alone
   v2 twpreg[kRegTw ? 16 : 1], twsreg[kRegTws ? 8 : 1];
   if (kRegTw) {
 #pragma unroll
@@ -183,11 +194,11 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
     for (int k2 = 0; k2 < 8; ++k2) twsreg[k2] = ctws[k2 * 16 + (lane & 15)];
   }
   // MFCC: the DCT operands of this lane (its cepstral coefficient x every filter) and its lifter value stay in registers
-  f32x4 dw[kMfcc ? DCH : 1];
+  f32x4 dw[kMfcc ? DREG : 1];
   float lift = 1.0f;
   if (kMfcc) {
 #pragma unroll
-    for (int c4 = 0; c4 < DCH; ++c4) dw[c4] = *reinterpret_cast<const f32x4*>(p.dct_tab + (c4 * 64 + lane) * 4);
+    for (int c4 = 0; c4 < DREG; ++c4) dw[c4] = *reinterpret_cast<const f32x4*>(p.dct_tab + (c4 * 64 + lane) * 4);
     lift = p.dct_tab[DCH * 256 + lane];
   }
 #ifdef HIPFEAT_PHASE_TIMERS
@@ -401,6 +412,11 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
     // the next round's span (requested at the start of this round) must have landed before this round's stores join the
     // same in-order vmcnt queue: waiting here instead of at the top of the next round never waits for the stores
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    f32x4 dwx[kDctLate ? DCH - DREG : 1];  // the non-resident DCT operand chunks of this round: in flight during the filterbank
+    if (kDctLate) {
+#pragma unroll
+      for (int c4 = DREG; c4 < DCH; ++c4) dwx[c4 - DREG] = *reinterpret_cast<const f32x4*>(p.dct_tab + (c4 * 64 + lane_o) * 4);
+    }
     float* orow = p.out + (cd.out_row + f0) * p.out_stride;
     constexpr int S = MODE == 0 ? kCMaxSets : 1, T = MODE == 0 ? kCMaxSteps : 2 * kCMaxSteps;  // S x T = 32 steps either way
     int lt_poff[S], lt_col[S];
@@ -492,8 +508,9 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
       for (int c4 = 0; c4 < DCH; ++c4) {
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
-          d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(al[c4][i], dw[c4][i], d0, 0, 0, 0);
-          d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(al[c4][i + 1], dw[c4][i + 1], d1, 0, 0, 0);
+          const f32x4 w4 = (kDctLate && c4 >= DREG) ? dwx[c4 >= DREG ? c4 - DREG : 0] : dw[c4 < DREG ? c4 : 0];
+          d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(al[c4][i], w4[i], d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(al[c4][i + 1], w4[i + 1], d1, 0, 0, 0);
         }
       }
       d0 += d1;

@@ -434,15 +434,17 @@ def _fragmenting_dataset_class():
             `hipfeat_fragments`: per cut the two halves of its manifest line + the frame count they state (`manifest_fragments`), or None
             for cuts that have to go through lhotse's own objects."""
 
-            def __init__(self, collate: bool, template: Optional[Dict], frame_shift: float):
+            def __init__(self, collate: bool, template: Optional[Dict], frame_shift: float, pack: bool = True):
                 super().__init__(collate=collate)
-                self.hipfeat_template, self.hipfeat_frame_shift = template, frame_shift
+                self.hipfeat_template, self.hipfeat_frame_shift, self.hipfeat_pack = template, frame_shift, pack
 
             def __getitem__(self, batch_cuts):
                 batch = super().__getitem__(batch_cuts)
                 cache = self.__dict__.setdefault("_hipfeat_rec_cache", {})
                 t = self.hipfeat_template
                 batch["hipfeat_fragments"] = None if t is None else [manifest_fragments(c, t, self.hipfeat_frame_shift, cache, MonoCut) for c in batch["cuts"]]
+                if self.hipfeat_pack and not self.collate:
+                    pack_batch_audio(batch)
                 return batch
 
         FragmentingWaveformDataset.__module__, FragmentingWaveformDataset.__qualname__ = __name__, "FragmentingWaveformDataset"
@@ -454,6 +456,40 @@ def __getattr__(name):  # PEP 562: `lhotse_amd.storage.FragmentingWaveformDatase
     if name == "FragmentingWaveformDataset" and HAVE_LHOTSE:
         return _fragmenting_dataset_class()
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
+def pack_batch_audio(batch: Dict) -> None:
+    """Round 6: the un-collated batch of lhotse's waveform dataset is a LIST of (1, T) float32 arrays; through a DataLoader's worker
+    queue every one of them becomes its own shared-memory segment (created, filled, its descriptor passed, mapped and unmapped again in
+    the main process): measured with 64 x 10 s WAV files, that transport -- not decoding, not the extractor -- bounds the batch driver at
+    1-3 k cuts/s (profiles/r06_bench_plumbing.json, leg B).  Here, still inside the worker, the cuts are packed into ONE float32 tensor
+    (every cut on a 16-byte boundary, as the extractor's staging wants them) + their lengths: one segment per batch.  The main process
+    takes 1-D views of it (`unpack_batch_audio`).  Left alone: anything that is not a list of mono float32 arrays."""
+    audio = batch.get("audio")
+    if not isinstance(audio, (list, tuple)) or len(audio) == 0:
+        return
+    if not all(isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[0] == 1 for a in audio):
+        return
+    lens = np.array([a.shape[1] for a in audio], dtype=np.int64)
+    offs = np.zeros(len(audio) + 1, dtype=np.int64)
+    np.cumsum((lens + 3) & ~3, out=offs[1:])
+    buf = torch.empty(int(offs[-1]), dtype=torch.float32)
+    flat = buf.numpy()
+    for a, o, n in zip(audio, offs, lens):
+        flat[o : o + n] = a[0]
+    batch["audio"], batch["hipfeat_lens"] = buf, torch.from_numpy(lens)
+
+
+def unpack_batch_audio(batch: Dict):
+    """The waveforms of a batch as the extractor takes them: 1-D views of the packed tensor (no copy), or whatever the dataset delivered."""
+    lens = batch.get("hipfeat_lens")
+    if lens is None:
+        return batch["audio"]
+    buf, o, out = batch["audio"], 0, []
+    for n in lens.tolist():
+        out.append(buf[o : o + n])
+        o += (n + 3) & ~3
+    return out
 
 
 def write_lines(manifest, blob: bytes) -> None:
@@ -706,7 +742,7 @@ def compute_and_store_features_batch(
 
     def run(writer, loader, save, finish, half: bool, template_of):
         def extract(batch):
-            batch_cuts, waves = batch["cuts"], batch["audio"]
+            batch_cuts, waves = batch["cuts"], unpack_batch_audio(batch)
             lens = batch["audio_lens"] if collate else None
             if len(batch_cuts) == 0:
                 return None
@@ -731,7 +767,9 @@ def compute_and_store_features_batch(
 
             # lhotse's waveform dataset + the halves of every cut's manifest line, made where the cut is loaded (the DataLoader's worker
             # processes when num_workers > 0); a module-level class: picklable, so the `spawn` start method works too
-            loader = DataLoader(_fragmenting_dataset_class()(collate, base, frame_shift), batch_size=None, sampler=sampler, num_workers=num_workers)
+            # (packed in the worker -- one shared-memory segment per batch instead of one per cut -- unless an augment_fn wants the per-cut arrays)
+            loader = DataLoader(_fragmenting_dataset_class()(collate, base, frame_shift, pack=augment_fn is None), batch_size=None, sampler=sampler,
+                                num_workers=num_workers)
 
             def save(archive, batch_cuts, pending, frames: List[int], template: Dict, frags):
                 frames = np.ascontiguousarray(frames, dtype=np.int64)
@@ -777,7 +815,7 @@ def compute_and_store_features_batch(
         return manifest.open_manifest()
 
     # ---- any other registered FeaturesWriter: per-cut write() calls, manifests through Python objects ------------------------------
-    loader = DataLoader(UnsupervisedWaveformDataset(collate=collate), batch_size=None, sampler=sampler, num_workers=num_workers)
+    loader = DataLoader(_fragmenting_dataset_class()(collate, None, frame_shift, pack=augment_fn is None), batch_size=None, sampler=sampler, num_workers=num_workers)
 
     def save(writer, batch_cuts, pending, frames: List[int], template: Dict, frags):
         check_frames(batch_cuts, frames)

@@ -653,3 +653,30 @@ def test_native_path_enforces_the_frame_count_contract_and_stops_on_write_errors
     with pytest.raises(OSError, match="No space left"):
         LA.compute_and_store_features_batch(many, ex, tmp_path / "full", manifest_path=tmp_path / "full.jsonl.gz", batch_duration=0.4, num_workers=0)
     assert calls["n"] < 15
+
+
+def test_loader_workers_hand_over_one_packed_tensor_per_batch(tmp_path, cutset, cpu_device):
+    """Round 6: the product's waveform dataset packs an un-collated batch into ONE float32 tensor inside the DataLoader worker (one
+    shared-memory segment per batch instead of one per cut: the transport, not decoding, bounded the batch driver); the main process
+    extracts from 1-D views of it.  Same features, same manifests as the per-cut arrays -- and an augment_fn keeps the per-cut arrays."""
+    import lhotse_amd as LA
+    from lhotse_amd import storage as S
+
+    ds = S.FragmentingWaveformDataset(False, None, 0.01)
+    batch = ds[cutset]
+    assert isinstance(batch["audio"], torch.Tensor) and batch["audio"].ndim == 1 and batch["audio"].dtype == torch.float32
+    lens = batch["hipfeat_lens"].tolist()
+    assert lens == [c.num_samples for c in cutset]
+    views = S.unpack_batch_audio(batch)
+    for v, c in zip(views, cutset):
+        assert v.data_ptr() % 16 == 0 and np.array_equal(v.numpy(), c.load_audio()[0])
+    plain = S.FragmentingWaveformDataset(False, None, 0.01, pack=False)[cutset]
+    assert isinstance(plain["audio"], list) and "hipfeat_lens" not in plain and S.unpack_batch_audio(plain) is plain["audio"]
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cpu"))
+    a = S.compute_and_store_features_batch(cutset, ex, tmp_path / "a", manifest_path=tmp_path / "a.jsonl.gz", batch_duration=3.0, num_workers=2)
+    b = S.compute_and_store_features_batch(cutset, ex, tmp_path / "b", manifest_path=tmp_path / "b.jsonl.gz", batch_duration=3.0, num_workers=2,
+                                           augment_fn=lambda w, sr: w)
+    fa, fb = {c.id: c.load_features() for c in a}, {c.id: c.load_features() for c in b}
+    assert sorted(fa) == sorted(fb) == sorted(c.id for c in cutset)
+    for k in fa:
+        assert np.array_equal(fa[k], fb[k]) and np.array_equal(fa[k], ex.extract(cutset[k].load_audio(), 16000))
