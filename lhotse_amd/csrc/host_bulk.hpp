@@ -246,11 +246,14 @@ struct ArchiveFiles {
     else for (int f = 0; f < nf; ++f) write((size_t)f);
     for (int f = 0; f < nf; ++f) {
       if (rc[f]) {
+        // a failed append (ENOSPC on one stripe) leaves NO trace: every file is cut back to its size before the batch and no size[] moves,
+        // so that rows never exist without manifest lines and a resumed run appends where the last complete batch ended
+        for (int q = 0; q < nf; ++q) (void)::ftruncate(fds[q], (off_t)size[q]);
         *errfile = f;
         return rc[f];
       }
-      size[f] += start_byte[f + 1] - start_byte[f];
     }
+    for (int f = 0; f < nf; ++f) size[f] += start_byte[f + 1] - start_byte[f];
     return 0;
   }
 };

@@ -105,7 +105,25 @@ static inline int64_t pipe_now_ns() {
 
 // The worker's side of one batch: everything that touches the staging sets and the streams.  Returns a status; on failure the
 // message is in this thread's g_err.
+static hipfeat_status pipe_process_batch(hipfeat_host_pipeline* p, PipeJob& j, PipeOut o);
+
+// A batch that fails half-way (a HIP error, a refused launch) has left part of its uploads / launches / downloads on the two streams and
+// its staging set's events un-recorded: the streams are drained HERE, on the worker, and the set is marked idle, so that the batches
+// queued behind it find a consistent slot (three tickets later the slot used to be reused after "synchronising" stale events).
 static hipfeat_status pipe_process(hipfeat_host_pipeline* p, PipeJob& j, PipeOut o) {
+  const hipfeat_status st = pipe_process_batch(p, j, o);
+  if (st != HIPFEAT_OK) {
+    const std::string why = g_err;  // (the synchronisation below must not replace the batch's own message)
+    DeviceGuard g(p->device);
+    (void)hipStreamSynchronize(p->s_in);
+    (void)hipStreamSynchronize(p->s_out);
+    p->in[j.ticket % kPipeInSlots].used = false;
+    snprintf(g_err, sizeof(g_err), "%s", why.c_str());
+  }
+  return st;
+}
+
+static hipfeat_status pipe_process_batch(hipfeat_host_pipeline* p, PipeJob& j, PipeOut o) {
   const hipfeat_plan* plan = p->plan;
   const int F = plan->feature_dim;
   const int64_t batch = (int64_t)j.items.size();
@@ -322,7 +340,8 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_submit(hipfeat_host_
       const hipfeat_status cl = hipfeat_check_length(zero_pad_batch ? max_len : h_num_samples[b], c.frame_length, c.frame_shift, 0);
       if (cl != HIPFEAT_OK) return cl;
     }
-    if (T <= 0) return fail(HIPFEAT_ERR_TOO_SHORT, "cut %lld: %lld samples yield no frames", (long long)b, (long long)h_num_samples[b]);
+    // (snip_edges: a cut shorter than one frame has ZERO rows, as in the reference (layers.py:745-746) and in build_descs -- not an error)
+    if (T < 0 || (T == 0 && !c.snip_edges)) return fail(HIPFEAT_ERR_TOO_SHORT, "cut %lld: %lld samples yield no frames", (long long)b, (long long)h_num_samples[b]);
     j->row0[(size_t)b + 1] = j->row0[(size_t)b] + T;
     if (h_num_frames) h_num_frames[b] = T;
   }
@@ -382,9 +401,10 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_submit(hipfeat_host_
 }
 
 // waits until the batch has been enqueued by the worker; -> its status (message copied into this thread's error slot)
-static hipfeat_status pipe_await_enqueued(hipfeat_host_pipeline* p, int64_t ticket, hipEvent_t* done) {
+static hipfeat_status pipe_await_enqueued(hipfeat_host_pipeline* p, int64_t ticket, hipEvent_t* done, bool* unknown = nullptr) {
   std::unique_lock<std::mutex> lk(p->mu);
   auto it = p->jobs.find(ticket);
+  if (unknown) *unknown = it == p->jobs.end();
   if (it == p->jobs.end()) return fail(HIPFEAT_ERR_INVALID, "host pipeline: ticket %lld is not outstanding", (long long)ticket);
   std::shared_ptr<PipeJob> j = it->second;
   p->cv_done.wait(lk, [&] { return j->enqueued; });
@@ -406,16 +426,13 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_wait(hipfeat_host_pi
 extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_release(hipfeat_host_pipeline* p, int64_t ticket) {
   if (!p) return fail(HIPFEAT_ERR_INVALID, "pipeline is NULL");
   hipEvent_t ev = nullptr;
-  hipfeat_status st = pipe_await_enqueued(p, ticket, &ev);  // never before the worker is done with the caller's waveforms
-  {
+  bool unknown = false;
+  hipfeat_status st = pipe_await_enqueued(p, ticket, &ev, &unknown);  // never before the worker is done with the caller's waveforms
+  if (unknown) return st;  // (its own answer: nothing to give back)
+  if (st == HIPFEAT_OK) {
     DeviceGuard g(p->device);
-    if (st == HIPFEAT_OK) {
-      (void)hipEventSynchronize(ev);  // a buffer is never handed out again while its download is in flight
-    } else if (std::string(g_err).find("not outstanding") == std::string::npos) {  // a batch that failed half-way: whatever part was enqueued
-      (void)hipStreamSynchronize(p->s_in);
-      (void)hipStreamSynchronize(p->s_out);
-    }
-  }
+    (void)hipEventSynchronize(ev);  // a buffer is never handed out again while its download is in flight
+  }  // (a batch that failed half-way was drained by the worker itself: pipe_process)
   std::lock_guard<std::mutex> lk(p->mu);
   auto it = p->jobs.find(ticket);
   if (it == p->jobs.end()) return fail(HIPFEAT_ERR_INVALID, "host pipeline: ticket %lld is not outstanding", (long long)ticket);

@@ -569,11 +569,20 @@ class NativeHostPipeline:
         self.threads = int(threads)
         self._submit = self.lib.fn("hipfeat_host_pipeline_submit")
         self._waitf, self._releasef = self.lib.fn("hipfeat_host_pipeline_wait"), self.lib.fn("hipfeat_host_pipeline_release")
+        # Tickets whose result buffers (page-locked memory the LIBRARY owns) are still with a caller.  close() while some are outstanding --
+        # extractor.to(), a dropped plan, __del__ -- is DEFERRED until the last of them is released: a save thread that already holds the
+        # array of wait() would otherwise read freed memory.  `_after_close` (the plan's close) runs behind the deferred destroy.
+        self._state = threading.Lock()
+        self._outstanding = set()
+        self._closing = False
+        self._after_close = None
 
     def submit(self, items: Sequence[ArrayLike], zero_pad_batch: bool = False, half: bool = False) -> PendingFeatures:
         """1-D HOST waveforms (all float32 or all int16 PCM; numpy arrays or CPU tensors) -> PendingFeatures."""
         import ctypes
 
+        if self._closing or not self.handle:
+            raise _lib.HipFeatError(_lib.ERR_INVALID, "the host pipeline is closed (extractor moved or plan dropped)")
         B = len(items)
         pcm = _is_pcm16(items[0])
         keep, ptrs, lens = [], np.empty(B, dtype=np.uint64), np.empty(B, dtype=np.int64)
@@ -601,6 +610,8 @@ class NativeHostPipeline:
         item = 2 if half else 4
         buf = (ctypes.c_char * (rows * F * item)).from_address(int(res[0]))
         arr = np.frombuffer(buf, dtype=np.float16 if half else np.float32).reshape(rows, F)
+        with self._state:
+            self._outstanding.add(int(res[2]))
         return PendingFeatures(self, int(res[2]), arr, frames, keep)
 
     def stats(self) -> Dict[str, float]:
@@ -619,11 +630,34 @@ class NativeHostPipeline:
     def _release(self, ticket: int) -> None:
         if self.handle:
             self._releasef(self.handle, int(ticket))
+        with self._state:
+            self._outstanding.discard(int(ticket))
+            last = self._closing and not self._outstanding
+        if last:
+            self._destroy()
 
-    def close(self):
-        if self.handle:
+    def _destroy(self) -> None:
+        with self._state:
             h, self.handle = self.handle, 0
+            after, self._after_close = self._after_close, None
+        if h:
             self.lib.raw("hipfeat_host_pipeline_destroy", h)
+        if after is not None:
+            after()
+
+    def close(self, after=None) -> bool:
+        """Destroy the pipeline -- now, or (tickets outstanding) when the last of them is released.  `after` runs behind the destroy
+        (the owner's plan.close: the pipeline borrows the plan).  -> whether it happened now."""
+        with self._state:
+            if after is not None:
+                prev = self._after_close
+                self._after_close = after if prev is None else (lambda: (prev(), after()))
+            self._closing = True
+            deferred = bool(self._outstanding) and bool(self.handle)
+        if deferred:
+            return False
+        self._destroy()
+        return True
 
     def __del__(self):
         try:
@@ -737,12 +771,14 @@ class _HipExtractor(FeatureExtractor):
         # extractor would record / wait on the OLD device's streams while the kernel runs on the new one
         self.__dict__.pop("_pipeline", None)
         native = self.__dict__.pop("_native_pipeline", None)
-        if native is not None:
-            native.close()  # (before the plan it borrows)
         self._staging = None
-        if self._plan is not None:
-            self._plan.close()
-            self._plan = None
+        plan, self._plan = self._plan, None
+        if native is not None:
+            # before the plan it borrows -- and, while results of it are still with a save thread, NOT YET: the pipeline (and behind it the
+            # plan) is destroyed when the last outstanding batch is released (NativeHostPipeline.close)
+            native.close(after=(plan.close if plan is not None else None))
+        elif plan is not None:
+            plan.close()
 
     @property
     def plan(self) -> _Plan:

@@ -337,6 +337,12 @@ class NativeArchive:
         self.item = 2 if np_dtype == "<f2" else 4
         self.paths = stripe_paths(storage_path, max(1, int(stripes)))
         self.paths[0].parent.mkdir(parents=True, exist_ok=True)
+        if mode == "w":  # an earlier run with MORE stripes left feats.<k>.hfa files this run would neither truncate nor name
+            stem = str(self.paths[0])[: -len(ARCHIVE_SUFFIX)]
+            k = len(self.paths)
+            while Path(f"{stem}.{k}{ARCHIVE_SUFFIX}").exists():
+                Path(f"{stem}.{k}{ARCHIVE_SUFFIX}").unlink()
+                k += 1
         raw = [str(p).encode("utf-8") for p in self.paths]
         arr = (ctypes.c_char_p * len(raw))(*raw)
         h = np.zeros(1, dtype=np.uint64)

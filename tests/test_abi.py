@@ -192,3 +192,70 @@ def test_experiment_switches_are_not_in_the_product_library():
         assert name not in blob, name
     for name in (b"HIPFEAT_FORCE_GENERIC", b"HIPFEAT_NO_FIXED_SCHEDULE", b"HIPFEAT_NO_FLAT", b"HIPFEAT_PIPE_CHUNKS"):
         assert name in blob, name
+
+
+def test_archive_overwrite_drops_stale_stripes_and_failed_appends_leave_no_trace(tmp_path):
+    """Host-only entry points (no GPU needed): ADVICE r5 -- (i) opening for overwrite with fewer stripes than an earlier run removes the
+    higher-numbered files; (ii) an append that fails on one stripe leaves every file at its size before the batch."""
+    import numpy as np
+
+    from lhotse_amd import storage as S
+
+    rs = np.random.RandomState(0)
+    frames = np.array([30, 50, 20, 40], dtype=np.int64)
+    host = rs.rand(int(frames.sum()), 80).astype(np.float32)
+    with S.NativeArchive(tmp_path / "feats", mode="w", stripes=4) as ar:
+        ar.append(host, frames)
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["feats.1.hfa", "feats.2.hfa", "feats.3.hfa", "feats.hfa"]
+    with S.NativeArchive(tmp_path / "feats", mode="w", stripes=2) as ar:
+        f, o = ar.append(host, frames)
+        sizes = [ar.size(0), ar.size(1)]
+        assert sum(sizes) == host.nbytes
+        # (ii) binary32 archive, a batch whose second run cannot be written: stripe 1's descriptor is swapped for a read-only one
+        import os
+
+        ro = os.open(str(ar.paths[1]), os.O_RDONLY)
+        # the library keeps its own descriptors; emulate the failure through the public surface instead: a non-finite f16 batch is refused
+        # BEFORE anything is written (same no-trace guarantee), sizes unchanged
+        os.close(ro)
+    with S.NativeArchive(tmp_path / "h", mode="w", np_dtype="<f2", stripes=2, name="hip_archive_f16") as ar:
+        ar.append(host.astype(np.float16), frames)
+        before = [ar.size(0), ar.size(1)]
+        bad = host.astype(np.float16)
+        bad[-1, -1] = np.inf
+        import pytest
+
+        with pytest.raises(ValueError):
+            ar.append(bad, frames)
+        assert [ar.size(0), ar.size(1)] == before
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["feats.1.hfa", "feats.hfa", "h.1.hfa", "h.hfa"]
+    assert sum(os.path.getsize(tmp_path / n) for n in ("h.hfa", "h.1.hfa")) == host.size * 2
+
+
+def test_archive_append_failing_on_one_stripe_is_rolled_back(tmp_path):
+    """The ENOSPC case of ADVICE r5: stripe 1 of the archive is /dev/full (every write fails with ENOSPC).  Stripe 0's run of the batch IS
+    written -- and must be cut off again: both sizes stay where they were, the error names the failing file, the archive keeps working."""
+    import numpy as np
+    import pytest
+
+    from lhotse_amd import _lib
+    from lhotse_amd import storage as S
+
+    if not os.path.exists("/dev/full"):
+        pytest.skip("no /dev/full")
+    rs = np.random.RandomState(0)
+    frames = np.array([100, 100], dtype=np.int64)
+    host = rs.rand(200, 80).astype(np.float32)
+    with S.NativeArchive(tmp_path / "feats", mode="w", stripes=1) as ar:  # 32 000 bytes already in stripe 0
+        ar.append(host[:100], frames[:1])
+    os.symlink("/dev/full", tmp_path / "feats.1.hfa")
+    with S.NativeArchive(tmp_path / "feats", mode="a", stripes=2) as ar:
+        before = [ar.size(0), ar.size(1)]
+        assert before == [32000, 0]
+        with pytest.raises(_lib.HipFeatError, match="archive file 1 failed: No space left"):
+            ar.append(host, frames)
+        assert [ar.size(0), ar.size(1)] == before and os.path.getsize(tmp_path / "feats.hfa") == 32000  # stripe 0's run was cut off again
+    with S.NativeArchive(tmp_path / "feats", mode="a", stripes=1) as ar:
+        _, off = ar.append(host[100:], frames[1:])
+        assert int(off[0]) == 32000  # the next complete batch lands where the last complete one ended
+    assert np.array_equal(S.HipArchiveReader(tmp_path / "feats.hfa").read("32000:100:80"), host[100:])

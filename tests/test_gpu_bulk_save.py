@@ -140,3 +140,53 @@ def test_native_archive_and_lines_behind_the_native_pipeline(tmp_path):
     readers = {q: S.HipArchiveReader(q) for q in paths}
     for d, w in zip(lines, flat):
         assert np.array_equal(readers[d["storage_path"]].read(d["storage_key"]), ex.extract(w, 16000))
+
+
+def test_moving_the_extractor_with_a_result_outstanding_defers_the_teardown():
+    """PendingFeatures.wait() hands out a view of page-locked memory the LIBRARY owns; `extractor.to()` / a dropped plan used to
+    destroy the pipeline -- and free that memory -- under a save thread that still held the array.  The teardown (pipeline, then the plan it
+    borrows) now waits for the last outstanding batch to be released; the moved extractor works on a new plan meanwhile."""
+    ex = LA.HipFbank()
+    waves = _batches(31, 1)[0]
+    p, frames = S._batch_features_pending(ex, [torch.from_numpy(w) for w in waves], 16000, None)
+    assert p.ticket is not None
+    arr = p.wait()  # (what the save thread would hold on to)
+    old_pipe, old_plan = ex._native_pipe(), ex.plan
+    ex.to("cuda:0")  # drops plan + pipeline
+    assert old_pipe.handle != 0 and old_plan.handle != 0, "torn down under an outstanding result"
+    want = np.concatenate([ex.extract(w, 16000) for w in waves])  # the moved extractor: new plan, new kernels launched, allocator busy
+    assert ex.plan is not old_plan and ex._native_pipe() is not old_pipe
+    assert np.array_equal(arr, want)  # the old buffer is still intact
+    with pytest.raises(LA._lib.HipFeatError):
+        old_pipe.submit([torch.from_numpy(waves[0])])  # a closing pipeline takes no new batches
+    p.release()
+    assert old_pipe.handle == 0 and old_plan.handle == 0  # now it went, pipeline first, then its plan
+
+
+def test_snip_edges_cut_shorter_than_a_frame_is_an_empty_matrix_in_the_native_pipeline():
+    """hipfeat_host_pipeline_submit refused T == 0 where build_descs (and the reference, layers.py:745-746) accept it."""
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ex = LA.HipFbank(LA.HipFbankConfig(snip_edges=True))
+    rs = np.random.RandomState(2)
+    waves = [rs.rand(16000).astype(np.float32) - 0.5, rs.rand(300).astype(np.float32) - 0.5, rs.rand(401).astype(np.float32) - 0.5]
+    p, frames = S._batch_features_pending(ex, [torch.from_numpy(w) for w in waves], 16000, None)
+    assert p.ticket is not None and list(frames) == [98, 0, 1]
+    got = p.wait().copy()
+    p.release()
+    assert got.shape == (99, 80) and np.array_equal(got[:98], ex.extract(waves[0], 16000)) and np.array_equal(got[98:], ex.extract(waves[2], 16000))
+
+
+def test_overwriting_with_fewer_stripes_removes_the_stale_ones(tmp_path):
+    ex = LA.HipFbank()
+    waves = _batches(8, 1)[0]
+    host, frames = S._batch_features_on_host(ex, [torch.from_numpy(w) for w in waves], 16000, None)
+    with S.NativeArchive(tmp_path / "feats", mode="w", stripes=4) as ar:
+        ar.append(host, np.asarray(frames))
+        assert len(ar.paths) == 4
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["feats.1.hfa", "feats.2.hfa", "feats.3.hfa", "feats.hfa"]
+    with S.NativeArchive(tmp_path / "feats", mode="w", stripes=2) as ar:
+        ar.append(host, np.asarray(frames))
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["feats.1.hfa", "feats.hfa"]
