@@ -191,7 +191,7 @@ def fold(stats):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------------------------------------------
-SETTLE_LAUNCHES = int(os.environ.get("BENCH_SETTLE", "150"))  # (BENCH_SETTLE=0: counter passes, tools/r5_traffic.sh) untimed launches at construction of the headline workload (~0.5 s): the package's steady power state
+SETTLE_LAUNCHES = int(os.environ.get("BENCH_SETTLE", "150"))  # (BENCH_SETTLE=0: counter passes, tools/collect.sh traffic) untimed launches at construction of the headline workload (~0.5 s): the package's steady power state
 FILL_CHUNK = 500  # cuts per uniform_() call: part of the definition of the synthetic input (the generator's stream position)
 
 

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * kCWaves, 4) void fft512c_kernel(const Fft512cP
       // "their" row (all n2) back
       float* exf = myreg + mul24(g, kCExFrameStride);
       v2 b[16];
-#ifdef HIPFEAT_ABL_NO_EXCHANGE  // experiment builds (tools/r4_lds_conflicts.sh): which phase owns the LDS bank conflicts?  (wrong results)
+#ifdef HIPFEAT_ABL_NO_EXCHANGE  // experiment builds (round 4: profiles/r04_lds_conflicts.txt): which phase owns the LDS bank conflicts?  (wrong results)
 #pragma unroll
       for (int n2 = 0; n2 < 16; ++n2) b[n2] = a[n2];
 #else

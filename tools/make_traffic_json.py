@@ -3,7 +3,7 @@
 bench kernel, stamped with the sha256 of the kernel sources they were measured on (bench.py refuses the numbers once those files change).
 
     python tools/make_traffic_json.py <summary.txt> <cuts per dispatch> [label of the summary file in profiles/] [power probe json line file]
-    python tools/make_traffic_json.py --config mfcc40_libri|onthefly <dir of tools/r5_traffic.sh>   (adds / replaces traffic.json["configs"][<name>])"""
+    python tools/make_traffic_json.py --config mfcc40_libri|onthefly <dir of tools/collect.sh traffic>   (adds / replaces traffic.json["configs"][<name>])"""
 import json
 import os
 import re
@@ -77,7 +77,7 @@ def config_entry(name: str, root: str):
         "algorithmic_bytes_per_step": algo,
         "steps_profiled": steps,
         "per_kernel": per_kernel,
-        "source": f"tools/r5_traffic.sh ({root}): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `bench.py --config {name} --steps 2 --warmup 1`, "
+        "source": f"tools/collect.sh traffic ({root}): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `bench.py --config {name} --steps 2 --warmup 1`, "
                   "counters summed over all dispatches per kernel / passes over the workload",
         "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 under-count of 16 B/lane coalesced reads, MI355X_MICROARCH.md HBM section; the resampler's reads are "
                        "4 B/lane strided gathers for which the factor is uncalibrated -- its fetch figure is an upper bound); WRITE_SIZE KiB x 1024",
@@ -135,7 +135,7 @@ def main():
         "source_files": SOURCES,
         "source_sha256_16": bench.kernel_source_hash(SOURCES),
     }
-    if len(sys.argv) > 4:  # shader clock the chip held while the bench kernel ran for seconds (rocm-smi samples, tools/r4_collect.sh)
+    if len(sys.argv) > 4:  # shader clock the chip held while the bench kernel ran for seconds (rocm-smi samples, tools/collect.sh power)
         probe = json.loads(open(sys.argv[4]).readline())
         out["sclk_MHz_under_load"] = probe["sclk_MHz_median"]
         out["package_power_W_under_load"] = probe["package_power_W_median"]

@@ -222,8 +222,9 @@ class DecodeDataset:
         self._rc = {}
 
     def __getitem__(self, idx: List[int]):
+        t0 = time.perf_counter()
         audio = [read_wav(self.cuts[i].path, self.pcm16) for i in idx]
-        out = {"idx": list(idx), "audio": audio}
+        out = {"idx": list(idx), "audio": audio, "worker_decode_s": time.perf_counter() - t0}
         if self.packed:  # what lhotse_amd.storage.pack_batch_audio does in the product's dataset: ONE tensor per batch through the worker queue
             import torch
 
