@@ -52,7 +52,8 @@ def test_total_cuts_is_the_same_corpus_and_the_same_rate_as_the_default_form():
 
 @pytest.mark.parametrize("flags", [("--config", "mfcc40_libri", "--cuts", "600", "--steps", "3"), ("--config", "onthefly", "--cuts", "6", "--steps", "2", "--no-extra"),
                                    ("--config", "onthefly", "--cuts", "8", "--steps", "2", "--prefetch", "4", "--streams", "2", "--no-extra"),
-                                   ("--config", "bulk_save", "--cuts", "2", "--steps", "1", "--no-extra")])
+                                   ("--config", "bulk_save", "--cuts", "2", "--steps", "1", "--no-extra"),
+                                   ("--config", "plumbing", "--cuts", "4", "--steps", "1", "--no-extra")])
 def test_the_other_configs_run_and_pass_their_in_run_parity(flags):
     """Small instances of every `--config`: one JSON line, in-run oracle parity `pass`, the contract's keys."""
     res, err = _bench(*flags)
@@ -65,8 +66,14 @@ def test_the_default_line_carries_the_other_baseline_configs_and_both_regimes():
     and [4] measured under the same contract with their own in-run parity, on-the-fly priced both ways (`frac` and `frac_end_to_end`),
     and the after-idle regime next to the sustained `value` (VERDICT r4 tasks 2 and 6)."""
     res, err = _bench("--steps", "20", "--warmup", "5")
-    cfgs = res["extra"]["configs"]
-    assert set(cfgs) == {"mfcc40_libri", "onthefly"}
+    cfgs = dict(res["extra"]["configs"])
+    assert set(cfgs) == {"mfcc40_libri", "onthefly", "plumbing"}
+    plumb = cfgs.pop("plumbing")  # round 6: BASELINE configs[0] with the GPU in it (host-bound: WAV files -> loader workers -> features -> storage)
+    assert "error" not in plumb, plumb
+    assert plumb["value"] > 0 and plumb["parity"]["pass"] is True and plumb["last_pass"]["cuts_per_s"] > 0
+    legs = plumb["legs"]
+    assert any(k.startswith("A cpu_per_cut") for k in legs) and any(k.startswith("B hip_batch_numpy_files") for k in legs) and any(k.startswith("C hip_bulk") for k in legs)
+    assert all(v["cuts_per_s"] > 0 for k, v in legs.items() if isinstance(v, dict)), legs
     for name, c in cfgs.items():
         assert c["parity"]["pass_rel_l2"] is True and c["value"] > 0 and c["roofline"]["frac"] > 0 and c["steps"] > 0, (name, c)
         assert c["ms_per_step"] * c["steps"] < 5000  # a few seconds of GPU together
