@@ -244,11 +244,11 @@ class DecodeDataset:
         return out
 
 
-def _loader(ds, batches, num_workers: int):
+def _loader(ds, batches, num_workers: int, context: Optional[str] = None):
     from torch.utils.data import DataLoader
 
     return DataLoader(ds, batch_size=None, sampler=batches, num_workers=num_workers, prefetch_factor=4 if num_workers else None,
-                      persistent_workers=False)
+                      persistent_workers=False, multiprocessing_context=(context if num_workers else None))
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
