@@ -73,6 +73,11 @@ def main():
     with tempfile.TemporaryDirectory(dir=base) as td:
         paths = P.write_corpus(os.path.join(td, "wav"), 64)
         cuts = P.make_cuts(paths, passes)
+        if os.environ.get("HIPFEAT_WAIT"):
+            r = run(cuts, 8, "as delivered", 0)
+            r["HIPFEAT_WAIT"] = os.environ["HIPFEAT_WAIT"]
+            print(json.dumps(r), flush=True)
+            return
         print(json.dumps(run(cuts, 8, "as delivered", 0)), flush=True)
         print(json.dumps(run(cuts, 8, "as delivered", 0, fork_first=True)), flush=True)
         print(json.dumps(run(cuts, 8, "as delivered", 0, context="spawn")), flush=True)
