@@ -998,7 +998,10 @@ class Plumbing:
         import shutil
 
         prev = self.last
-        self.last = self.P.hip_bulk(self.ex, self.cuts, self._dir("bulk"), self.workers, stripes=self.stripes)
+        # this process holds a live HIP context: workers FORKED off it would slow every device round trip by ~30 ms while they live
+        # (lhotse_amd/_lib.py, profiles/r06_loader_pipeline_probe.txt) -- the product's driver starts them through a fork server in that
+        # situation, and so does this step
+        self.last = self.P.hip_bulk(self.ex, self.cuts, self._dir("bulk"), self.workers, stripes=self.stripes, context="forkserver")
         if prev:
             shutil.rmtree(os.path.dirname(prev["manifest"]), ignore_errors=True)
 
@@ -1019,30 +1022,48 @@ class Plumbing:
             stats.append(compare(P.read_back(self.last, int(j)), o32.extract(x), o64.extract(x)))
         return fold(stats)
 
-    def extra(self, args):
+    def _fresh(self, *flags, repeat=None):
+        """One leg in a FRESH process (tools/plumbing.py main): the GPU is first touched at the first batch, after the loader's workers were
+        forked -- the order lhotse's own driver produces.  -> the JSON lines of its passes."""
+        import subprocess
+
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "plumbing.py"), "--wav-dir", os.path.dirname(self.paths[0]), "--repeat", str(repeat or self.repeat),
+               "--stripes", str(self.stripes), *[str(f) for f in flags]]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HIPFEAT_NO_FORK_WARNING="1"))
+        rows = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if p.returncode != 0 or not rows:
+            return {"error": (p.stderr or p.stdout)[-600:]}
+        return rows
+
+    def extra(self, args, full: bool = True):
         import shutil
 
         P, out = self.P, {}
-        small = P.make_cuts(self.paths, max(1, self.repeat // 4))
+        keep = ("cuts_per_s", "cuts_per_s_incl_worker_start", "seconds_to_first_batch", "cuts", "num_workers", "worker_start", "transport", "input", "storage")
 
-        def run(fn, *a, **k):
-            d = self._dir("x")
-            r = fn(*a[:2], d, *a[2:], **k)
-            shutil.rmtree(d, ignore_errors=True)
-            r.pop("archive_paths", None), r.pop("manifest", None)
-            return r
+        def brief(rows, k=0):
+            if isinstance(rows, dict):
+                return rows
+            r = rows[min(k, len(rows) - 1)]
+            return {**{a: r[a] for a in keep if a in r}, **{a: v for a, v in r.items() if a.endswith("_share")}}
 
-        for wk in sorted({4, self.workers}):
-            run(P.hip_batch_numpy_files, self.ex, small[:640], wk)  # warm (worker start-up, page cache)
-            out[f"B hip_batch_numpy_files (lhotse's batch driver + NumpyFilesWriter path), {wk} loader workers"] = run(P.hip_batch_numpy_files, self.ex, small, wk)
-        for pcm16, half in ((False, False), (True, True)):
-            run(P.hip_bulk, self.ex, small[:640], self.workers, pcm16=pcm16, half=half, stripes=self.stripes)
-            out[f"C hip_bulk ({'int16' if pcm16 else 'float32'} -> {'hip_archive_f16' if half else 'hip_archive'}), {self.workers} loader workers"] = \
-                run(P.hip_bulk, self.ex, self.cuts, self.workers, pcm16=pcm16, half=half, stripes=self.stripes)
-        run(P.hip_bulk, self.ex, small[:640], 4, stripes=self.stripes)
-        out["C hip_bulk (float32 -> hip_archive), 4 loader workers"] = run(P.hip_bulk, self.ex, small, 4, stripes=self.stripes)
-        out[f"C hip_bulk (float32 -> hip_archive), {self.workers} loader workers, one array per cut through the worker queue (lhotse's transport)"] = \
-            run(P.hip_bulk, self.ex, small, self.workers, stripes=self.stripes, packed=False)
+        W = self.workers
+        small = max(4, self.repeat // 4)
+        # fresh processes, workers forked before the GPU is touched (pass 0 of each) -----------------------------------------------------
+        for wk in sorted({4, W} if full else {W}):
+            out[f"B hip_batch_numpy_files, {wk} loader workers"] = brief(self._fresh("--leg", "B", "--workers", wk, "--passes", 1, repeat=small))
+        out[f"C hip_bulk float32 -> hip_archive, {W} loader workers"] = brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1))
+        if full:
+            out[f"C hip_bulk int16 -> hip_archive_f16, {W} loader workers"] = brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--pcm16", "--half"))
+            out["C hip_bulk float32 -> hip_archive, 4 loader workers"] = brief(self._fresh("--leg", "C", "--workers", 4, "--passes", 1, repeat=small))
+            out[f"C hip_bulk float32 -> hip_archive, {W} loader workers, one array per cut through the worker queue (lhotse's transport)"] = \
+                brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--per-cut-transport", repeat=small))
+        # the hazard: the same leg with the GPU touched BEFORE the workers are forked, and its remedy (fork server) -------------------------
+        out[f"C hip_bulk float32 -> hip_archive, {W} loader workers, FORKED AFTER the GPU was touched"] = \
+            brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--gpu-first", repeat=small))
+        if full:
+            out[f"C hip_bulk float32 -> hip_archive, {W} loader workers, fork server, GPU touched before"] = \
+                brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--gpu-first", "--context", "forkserver"))
         if not args.no_cpu_baseline:
             ncpu = len(os.sched_getaffinity(0))
             for jobs in sorted({1, max(1, min(64, ncpu // 4))}):
@@ -1050,11 +1071,14 @@ class Plumbing:
                 d = self._dir("a")
                 out[f"A cpu_per_cut (compute_and_store_features(Fbank(), NumpyFilesWriter, num_jobs={jobs}) restated; kind = port)"] = P.cpu_per_cut(P.make_cuts(self.paths, n // 64), d, jobs)
                 shutil.rmtree(d, ignore_errors=True)
-        out["what"] = ("cuts/s of whole passes incl. WAV decode, storage and manifest; shares are of wall time.  A = the reference's per-cut CPU driver restated with "
-                       "the reference's torch call sequence as the extractor (oracle/kaldi_torch.py: the checker / baseline, never the product path); B = the structure of "
-                       "CutSet.compute_and_store_features_batch (lhotse/cut/set.py:2296-2408) around HipFbank with lhotse's own save path (one .npy per cut, one "
-                       "json.dumps + flush per cut on ONE save thread); C = the product's bulk driver.  lhotse cannot run on this box; the real drivers are timed "
-                       "next to leg A in the authoring container: profiles/r06_plumbing_container.json")
+        out["what"] = ("cuts/s BEHIND the first batch (the start of the worker processes is reported next to it) of whole passes incl. WAV decode, storage and manifest; "
+                       "shares are of wall time.  A = the reference's per-cut CPU driver restated with the reference's torch call sequence as the extractor "
+                       "(oracle/kaldi_torch.py: the checker / baseline, never the product path); B = the structure of CutSet.compute_and_store_features_batch "
+                       "(lhotse/cut/set.py:2296-2408) around HipFbank with lhotse's own save path (one .npy per cut, one json.dumps + flush per cut on ONE save "
+                       "thread) and lhotse's transport (one array per cut through the worker queue); C = the product's bulk driver (one packed tensor per batch).  "
+                       "B and C run in FRESH processes (tools/plumbing.py): the GPU is first touched at the first batch, after the workers were forked, as under "
+                       "lhotse's driver.  The two last C legs show the fork hazard (lhotse_amd/_lib.py) and its remedy.  lhotse itself cannot run on this box; "
+                       "the real drivers are timed next to leg A in the authoring container: profiles/r06_plumbing_container.json")
         return {"plumbing": out}
 
     def close(self):
@@ -1513,7 +1537,7 @@ def sub_plumbing(args, dev, rank: int):
             v = parity_bar.verdict(f)
             out["parity"] = {"pass": v["pass"], "rel_l2_max": float(f"{f['rel_l2_max']:.3e}"), "max_abs_max": float(f"{f['max_abs_max']:.3e}"), "n": f["n"],
                              "what": "cuts read back through the manifest + archive reader of the last timed pass vs the oracle on the decoded files"}
-        out["legs"] = w.extra(a)["plumbing"]
+        out["legs"] = w.extra(a, full=False)["plumbing"]  # (the full set of legs: bench.py --config plumbing)
         return out
     finally:
         w.close()

@@ -280,3 +280,53 @@ def addr(a: Optional[np.ndarray]) -> Optional[int]:
 
 def i64(values) -> np.ndarray:
     return np.ascontiguousarray(values, dtype=np.int64)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# fork() with a live HIP context (round 6)
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Measured on MI355X / ROCm 7.2 (tools/loader_pipeline_probe.py, profiles/r06_loader_pipeline_probe.txt): while child processes that were
+# fork()ed AFTER this process created its HIP context are alive -- a DataLoader's workers -- every host <-> device round trip of the parent
+# (upload, launch, download of one 60-cut batch) completes ~30 ms late: 1.35 k cuts/s through the host pipeline instead of 6.7 k.  Polling
+# instead of interrupt waits does not help (the work itself finishes late).  Workers that were forked BEFORE the context existed, or started
+# by a fork server / spawn, do not have the effect.  lhotse's own batch driver forks its workers when the loop over the DataLoader starts
+# (lhotse/cut/set.py:2302-2304, :2374), i.e. before the first extract_batch -- and the Hip* extractors create their plan lazily at that
+# first call, so a fresh process is fine.  A process that has used the GPU before (an earlier run, another extractor, torch.cuda) is not.
+_PLANS_CREATED = 0
+_FORK_WARNED = False
+
+
+def note_plan_created() -> None:
+    global _PLANS_CREATED
+    _PLANS_CREATED += 1
+
+
+def hip_live() -> bool:
+    """Has this process touched the GPU (a plan of this package, or torch's own context)?"""
+    if _PLANS_CREATED:
+        return True
+    try:
+        import torch
+
+        return bool(torch.cuda.is_initialized())
+    except Exception:  # noqa: BLE001
+        return False
+
+
+def _before_fork() -> None:
+    global _FORK_WARNED
+    if _FORK_WARNED or not hip_live() or os.environ.get("HIPFEAT_NO_FORK_WARNING"):
+        return
+    _FORK_WARNED = True
+    import warnings
+
+    warnings.warn(
+        "lhotse_amd: this process is fork()ing while it holds a live HIP context.  While the children live (DataLoader workers), every host <-> device "
+        "round trip of THIS process was measured ~30 ms slower on MI355X / ROCm 7.2.  Start the workers before the first use of the GPU (the Hip* "
+        "extractors create their plan lazily), or use multiprocessing_context='forkserver' for the DataLoader "
+        "(lhotse_amd.compute_and_store_features_batch does so on its own when the GPU is already in use).  HIPFEAT_NO_FORK_WARNING=1 silences this.",
+        RuntimeWarning, stacklevel=2)
+
+
+if hasattr(os, "register_at_fork"):
+    os.register_at_fork(before=_before_fork)

@@ -99,25 +99,6 @@ struct hipfeat_host_pipeline {
   std::atomic<int64_t> ns_busy{0}, ns_pack{0}, ns_slot_wait{0}, n_batches{0};
 };
 
-// Waiting for an event.  hipEventSynchronize blocks on an interrupt-driven signal; in a process that has fork()ed while its HIP context was
-// live (a DataLoader's worker processes: lhotse's batch driver forks them, cut/set.py:2302-2304) every such wait was measured to return
-// ~30 ms late on MI355X / ROCm 7.2 (tools/loader_pipeline_probe.py, profiles/r06_loader_pipeline_probe.txt: 32 ms per 60-cut batch against
-// 1.9 ms when the workers are forked before the plan exists or are started by a fork server).  HIPFEAT_WAIT=poll (routing switch) waits by
-// polling hipEventQuery with short sleeps instead.
-static hipError_t pipe_event_wait(hipEvent_t ev) {
-  static const int poll = [] {
-    const char* v = route_env("HIPFEAT_WAIT");
-    return (v && std::string(v) == "poll") ? 1 : 0;
-  }();
-  if (!poll) return hipEventSynchronize(ev);
-  for (int spins = 0;; ++spins) {
-    const hipError_t e = hipEventQuery(ev);
-    if (e != hipErrorNotReady) return e;
-    if (spins > 200) std::this_thread::sleep_for(std::chrono::microseconds(50));
-    else std::this_thread::yield();
-  }
-}
-
 static inline int64_t pipe_now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -153,8 +134,8 @@ static hipfeat_status pipe_process_batch(hipfeat_host_pipeline* p, PipeJob& j, P
   // chunk events they wait on are recorded again and before its device buffers are written
   if (s.used) {
     const int64_t t0 = pipe_now_ns();
-    HIP_TRY(pipe_event_wait(s.uploaded));
-    HIP_TRY(pipe_event_wait(s.downloaded));
+    HIP_TRY(hipEventSynchronize(s.uploaded));
+    HIP_TRY(hipEventSynchronize(s.downloaded));
     p->ns_slot_wait.fetch_add(pipe_now_ns() - t0, std::memory_order_relaxed);
   }
   const size_t in_bytes = (size_t)j.total * in_item;
@@ -438,7 +419,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_wait(hipfeat_host_pi
   hipfeat_status st = pipe_await_enqueued(p, ticket, &ev);
   if (st != HIPFEAT_OK) return st;
   DeviceGuard g(p->device);
-  HIP_TRY(pipe_event_wait(ev));  // (outside the lock: other threads keep submitting)
+  HIP_TRY(hipEventSynchronize(ev));  // (outside the lock: other threads keep submitting)
   return HIPFEAT_OK;
 }
 
@@ -450,7 +431,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_release(hipfeat_host
   if (unknown) return st;  // (its own answer: nothing to give back)
   if (st == HIPFEAT_OK) {
     DeviceGuard g(p->device);
-    (void)pipe_event_wait(ev);  // a buffer is never handed out again while its download is in flight
+    (void)hipEventSynchronize(ev);  // a buffer is never handed out again while its download is in flight
   }  // (a batch that failed half-way was drained by the worker itself: pipe_process)
   std::lock_guard<std::mutex> lk(p->mu);
   auto it = p->jobs.find(ticket);

@@ -247,6 +247,7 @@ class _Plan:
             _lib.addr(out),
         )
         self.handle = int(out[0])
+        _lib.note_plan_created()  # (the fork hazard: _lib.hip_live)
         self._pair_ok = os.environ.get("HIPFEAT_COLLATED_NO_PAIR") is None
         self.feature_dim = int(self.lib.raw("hipfeat_plan_feature_dim", self.handle))
         self.kernel_name = self.lib.string("hipfeat_plan_kernel_name", self.handle)

@@ -33,6 +33,7 @@ from __future__ import annotations
 
 import os
 import threading
+import warnings
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -675,9 +676,17 @@ def compute_and_store_features_batch(
     storage_type=None,
     overwrite: bool = False,
     archive_stripes: int = 1,
+    loader_start_method: Optional[str] = None,
+    worker_init_fn: Optional[Callable] = None,
 ):
     """``CutSet.compute_and_store_features_batch`` with the bulk save path of this module (same arguments; ``storage_type``
     defaults to ``HipArchiveWriter``).  Returns the CutSet with the ``Features`` manifests attached.
+
+    ``loader_start_method`` (round 6): how the DataLoader's worker processes are started -- ``None`` = ``"fork"`` (what lhotse's driver
+    gets from torch's default) unless this process ALREADY holds a live HIP context, in which case ``"forkserver"``: workers forked off a
+    process with a live context slow every device round trip of that process by ~30 ms while they live (``_lib.hip_live``; measured 1.35 k
+    against 5.5-6.7 k cuts/s).  Fork-server workers import lhotse afresh: process-global settings of the caller (a custom audio backend,
+    ``set_caching_enabled``) have to be re-established in ``worker_init_fn(worker_id)``.
 
     With the ``hip_archive`` / ``hip_archive_f16`` storages and a ``manifest_path`` the per-batch host work runs in libhipfeat
     (``NativeArchive``): the loader's worker processes serialise every cut's manifest line up to the storage fields
@@ -702,6 +711,21 @@ def compute_and_store_features_batch(
         raise ValueError(f"storage '{storage_type.name}' keeps binary16 rows, which cannot hold the linear-domain output of '{extractor.name}' "
                          "(overflow above 65504, flush to zero below 6e-8): use 'hip_archive'")
     frame_shift = extractor.frame_shift
+    loader_kw: Dict = {}
+    if num_workers > 0:
+        from . import _lib as _hiplib
+
+        method = loader_start_method
+        if method is None and _hiplib.hip_live():
+            method = "forkserver"
+            warnings.warn("lhotse_amd.compute_and_store_features_batch: this process already holds a live HIP context; the DataLoader's workers are started "
+                          "by a fork server (workers forked off such a process slow its device round trips by ~30 ms each while they live).  They import lhotse "
+                          "afresh: pass worker_init_fn to re-establish process-global settings, or loader_start_method='fork' to keep torch's default.",
+                          RuntimeWarning, stacklevel=2)
+        if method is not None and method != "fork":
+            loader_kw["multiprocessing_context"] = method
+        if worker_init_fn is not None:
+            loader_kw["worker_init_fn"] = worker_init_fn
     manifest = CutSet.open_writer(manifest_path, overwrite=overwrite)
     # rank / world pinned: under torchrun lhotse's samplers would otherwise split (and pad with duplicated cuts) what they are given once
     # more (lhotse/dataset/sampling/base.py:152-163); sharding over GPUs is explicit here (lhotse_amd.compute_and_store_features_sharded)
@@ -775,7 +799,7 @@ def compute_and_store_features_batch(
             # processes when num_workers > 0); a module-level class: picklable, so the `spawn` start method works too
             # (packed in the worker -- one shared-memory segment per batch instead of one per cut -- unless an augment_fn wants the per-cut arrays)
             loader = DataLoader(_fragmenting_dataset_class()(collate, base, frame_shift, pack=augment_fn is None), batch_size=None, sampler=sampler,
-                                num_workers=num_workers)
+                                num_workers=num_workers, **loader_kw)
 
             def save(archive, batch_cuts, pending, frames: List[int], template: Dict, frags):
                 frames = np.ascontiguousarray(frames, dtype=np.int64)
@@ -821,7 +845,8 @@ def compute_and_store_features_batch(
         return manifest.open_manifest()
 
     # ---- any other registered FeaturesWriter: per-cut write() calls, manifests through Python objects ------------------------------
-    loader = DataLoader(_fragmenting_dataset_class()(collate, None, frame_shift, pack=augment_fn is None), batch_size=None, sampler=sampler, num_workers=num_workers)
+    loader = DataLoader(_fragmenting_dataset_class()(collate, None, frame_shift, pack=augment_fn is None), batch_size=None, sampler=sampler, num_workers=num_workers,
+                        **loader_kw)
 
     def save(writer, batch_cuts, pending, frames: List[int], template: Dict, frags):
         check_frames(batch_cuts, frames)

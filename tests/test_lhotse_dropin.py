@@ -680,3 +680,61 @@ def test_loader_workers_hand_over_one_packed_tensor_per_batch(tmp_path, cutset, 
     assert sorted(fa) == sorted(fb) == sorted(c.id for c in cutset)
     for k in fa:
         assert np.array_equal(fa[k], fb[k]) and np.array_equal(fa[k], ex.extract(cutset[k].load_audio(), 16000))
+
+
+def test_the_batch_driver_starts_its_workers_through_a_fork_server_when_the_gpu_is_already_in_use(tmp_path, cutset, cpu_device, monkeypatch):
+    """Round 6 (profiles/r06_loader_pipeline_probe.txt): DataLoader workers FORKED off a process with a live HIP context slow that process's
+    device round trips by ~30 ms each.  The product's driver therefore asks for a fork server when `_lib.hip_live()`, says so, and keeps
+    torch's default otherwise / on request."""
+    import torch.utils.data as tud
+
+    import lhotse_amd as LA
+    from lhotse_amd import _lib
+    from lhotse_amd import storage as S
+
+    seen = []
+    real = tud.DataLoader
+
+    class Spy(real):
+        def __init__(self, *a, **k):
+            seen.append({x: k[x] for x in ("multiprocessing_context", "worker_init_fn") if x in k})
+            k.pop("multiprocessing_context", None)  # (the stub modules this container needs to import lhotse do not exist in a fork server's children)
+            super().__init__(*a, **k)
+
+    monkeypatch.setattr(tud, "DataLoader", Spy)
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cpu"))
+    kw = dict(batch_duration=3.0, num_workers=2)
+    monkeypatch.setattr(_lib, "hip_live", lambda: False)
+    S.compute_and_store_features_batch(cutset, ex, tmp_path / "a", manifest_path=tmp_path / "a.jsonl.gz", **kw)
+    assert seen[-1] == {}
+    monkeypatch.setattr(_lib, "hip_live", lambda: True)
+    init = lambda wid: None  # noqa: E731
+    with pytest.warns(RuntimeWarning, match="fork server"):
+        S.compute_and_store_features_batch(cutset, ex, tmp_path / "b", manifest_path=tmp_path / "b.jsonl.gz", worker_init_fn=init, **kw)
+    assert seen[-1] == {"multiprocessing_context": "forkserver", "worker_init_fn": init}
+    S.compute_and_store_features_batch(cutset, ex, tmp_path / "c", manifest_path=tmp_path / "c.jsonl.gz", loader_start_method="fork", **kw)
+    assert seen[-1] == {}
+    S.compute_and_store_features_batch(cutset, ex, tmp_path / "d", manifest_path=tmp_path / "d.jsonl.gz", batch_duration=3.0, num_workers=0)
+    assert seen[-1] == {}
+
+
+def test_forking_with_a_live_context_warns_once(monkeypatch):
+    import os
+
+    from lhotse_amd import _lib
+
+    monkeypatch.setattr(_lib, "hip_live", lambda: True)
+    monkeypatch.setattr(_lib, "_FORK_WARNED", False)
+    with pytest.warns(RuntimeWarning, match="live HIP context"):
+        pid = os.fork()
+        if pid == 0:
+            os._exit(0)
+        os.waitpid(pid, 0)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        pid = os.fork()  # a second fork: silent
+        if pid == 0:
+            os._exit(0)
+        os.waitpid(pid, 0)

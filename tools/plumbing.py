@@ -254,7 +254,7 @@ def _loader(ds, batches, num_workers: int, context: Optional[str] = None):
 # ----------------------------------------------------------------------------------------------------------------------------------
 # leg B: lhotse's batch driver around HipFbank, lhotse's own save path
 # ----------------------------------------------------------------------------------------------------------------------------------
-def hip_batch_numpy_files(ex, cuts: List[Cut], out_dir: str, num_workers: int, keep: Optional[Dict] = None) -> Dict:
+def hip_batch_numpy_files(ex, cuts: List[Cut], out_dir: str, num_workers: int, keep: Optional[Dict] = None, context: Optional[str] = None) -> Dict:
     import torch
 
     os.makedirs(out_dir, exist_ok=True)
@@ -281,7 +281,7 @@ def hip_batch_numpy_files(ex, cuts: List[Cut], out_dir: str, num_workers: int, k
     t0 = time.perf_counter()
     t_first = None
     with gzip.open(os.path.join(out_dir, "cuts.jsonl.gz"), "wt") as man, ThreadPoolExecutor(max_workers=1) as executor:
-        it = iter(_loader(DecodeDataset(cuts), batches, num_workers))
+        it = iter(_loader(DecodeDataset(cuts), batches, num_workers, context))  # (the workers start HERE: before `ex` has a plan if it is fresh)
         while True:
             ta = time.perf_counter()
             try:
@@ -301,7 +301,7 @@ def hip_batch_numpy_files(ex, cuts: List[Cut], out_dir: str, num_workers: int, k
     wall = time.perf_counter() - t0
     steady = (len(cuts) - len(batches[0])) / max(wall - (t_first or 0.0), 1e-9)
     return {"cuts_per_s": round(steady, 1), "cuts_per_s_incl_worker_start": round(len(cuts) / wall, 1), "seconds_to_first_batch": round(t_first or 0.0, 3),
-            "cuts": len(cuts), "seconds": round(wall, 3), "num_workers": num_workers,
+            "cuts": len(cuts), "seconds": round(wall, 3), "num_workers": num_workers, "worker_start": context or "fork",
             "main_thread_waiting_for_the_loader_share": round(t_load / wall, 3), "main_thread_extract_share": round(t_ext / wall, 3),
             "save_thread_busy_share": round(busy["save"] / wall, 3)}
 
@@ -309,7 +309,8 @@ def hip_batch_numpy_files(ex, cuts: List[Cut], out_dir: str, num_workers: int, k
 # ----------------------------------------------------------------------------------------------------------------------------------
 # leg C: the product's bulk driver (native pipeline + striped archive + spliced lines), fed by decoding workers
 # ----------------------------------------------------------------------------------------------------------------------------------
-def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = False, half: bool = False, stripes: int = 8, packed: bool = True) -> Dict:
+def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = False, half: bool = False, stripes: int = 8, packed: bool = True,
+             context: Optional[str] = None) -> Dict:
     from lhotse_amd import storage as S
 
     os.makedirs(out_dir, exist_ok=True)
@@ -368,14 +369,14 @@ def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
             manifest.flush()
             busy["lines"] += time.perf_counter() - ta
 
-        S.pump_batches(timed_batches(_loader(DecodeDataset(cuts, pcm16=pcm16, template=template, frame_shift=ex.frame_shift, packed=packed), batches, num_workers)),
+        S.pump_batches(timed_batches(_loader(DecodeDataset(cuts, pcm16=pcm16, template=template, frame_shift=ex.frame_shift, packed=packed), batches, num_workers, context)),
                        extract, save, stats=stats, finish=lines)
         paths = [str(p) for p in ar.paths]
     wall = time.perf_counter() - t0
     steady = (len(cuts) - len(batches[0])) / max(wall - (t_first[0] or 0.0), 1e-9)
     return {"cuts_per_s": round(steady, 1), "cuts_per_s_incl_worker_start": round(len(cuts) / wall, 1), "seconds_to_first_batch": round(t_first[0] or 0.0, 3),
             "cuts": len(cuts), "seconds": round(wall, 3), "num_workers": num_workers, "input": "int16" if pcm16 else "float32",
-            "transport": "one packed tensor per batch" if packed else "one array per cut",
+            "transport": "one packed tensor per batch" if packed else "one array per cut", "worker_start": context or "fork",
             "storage": storage, "stripes": stripes, "main_thread_waiting_for_the_loader_share": round(t_load[0] / wall, 3),
             "main_thread_submit_share": round(stats.get("extract_s", 0.0) / wall, 3), "main_thread_blocked_on_the_save_threads_share": round(stats.get("wait_s", 0.0) / wall, 3),
             "archive_thread_busy_share": round(busy["save"] / wall, 3), "archive_thread_waiting_for_the_device_share": round(busy["wait"] / wall, 3),
@@ -397,3 +398,56 @@ def read_back(result: Dict, index: int) -> np.ndarray:
 def default_workers() -> int:
     n = len(os.sched_getaffinity(0))
     return max(2, min(32, n // 4))
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# one leg in a FRESH process (what a user's script is): the GPU is first touched when the first batch is extracted, i.e. after the
+# loader's workers were forked -- the order lhotse's own driver produces (cut/set.py:2302-2304, :2374-2398).  bench.py calls this.
+# ----------------------------------------------------------------------------------------------------------------------------------
+def main() -> None:
+    import argparse
+    import shutil
+    import tempfile
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--leg", required=True, choices=["B", "C"])
+    ap.add_argument("--wav-dir", required=True)
+    ap.add_argument("--repeat", type=int, default=50)
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--pcm16", action="store_true")
+    ap.add_argument("--half", action="store_true")
+    ap.add_argument("--stripes", type=int, default=8)
+    ap.add_argument("--per-cut-transport", action="store_true")
+    ap.add_argument("--context", default=None)
+    ap.add_argument("--gpu-first", action="store_true", help="touch the GPU BEFORE the workers are forked (the hazardous order)")
+    ap.add_argument("--passes", type=int, default=2)
+    a = ap.parse_args()
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import lhotse_amd
+
+    paths = sorted(os.path.join(a.wav_dir, f) for f in os.listdir(a.wav_dir) if f.endswith(".wav"))
+    cuts = make_cuts(paths, a.repeat)
+    ex = lhotse_amd.HipFbank()  # (no plan yet: created lazily by the first extraction)
+    if a.gpu_first:
+        import torch
+
+        ex.extract(torch.zeros(16000), SR)
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+    best = None
+    with tempfile.TemporaryDirectory(prefix="hipfeat_leg_", dir=base) as td:
+        for k in range(a.passes):  # (pass 2 forks its workers with the plan of pass 1 alive unless a start method is given)
+            d = os.path.join(td, f"p{k}")
+            if a.leg == "B":
+                r = hip_batch_numpy_files(ex, cuts, d, a.workers, context=a.context)
+            else:
+                r = hip_bulk(ex, cuts, d, a.workers, pcm16=a.pcm16, half=a.half, stripes=a.stripes, packed=not a.per_cut_transport, context=a.context)
+            r.pop("archive_paths", None), r.pop("manifest", None)
+            r["pass"] = k
+            r["gpu_touched_before_the_workers_started"] = bool(a.gpu_first or k > 0)
+            shutil.rmtree(d, ignore_errors=True)
+            print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
