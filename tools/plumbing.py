@@ -247,6 +247,10 @@ class DecodeDataset:
 def _loader(ds, batches, num_workers: int, context: Optional[str] = None):
     from torch.utils.data import DataLoader
 
+    if context == "forkserver" and num_workers:
+        import multiprocessing as mp
+
+        mp.set_forkserver_preload(["torch", "torch.utils.data", "numpy", "plumbing", "lhotse_amd.storage"])  # (as lhotse_amd.storage's driver does)
     return DataLoader(ds, batch_size=None, sampler=batches, num_workers=num_workers, prefetch_factor=4 if num_workers else None,
                       persistent_workers=False, multiprocessing_context=(context if num_workers else None))
 
@@ -397,7 +401,7 @@ def read_back(result: Dict, index: int) -> np.ndarray:
 
 def default_workers() -> int:
     n = len(os.sched_getaffinity(0))
-    return max(2, min(32, n // 4))
+    return max(2, min(16, n // 4))
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
