@@ -72,7 +72,8 @@ def test_the_default_line_carries_the_other_baseline_configs_and_both_regimes():
     assert "error" not in plumb, plumb
     assert plumb["value"] > 0 and plumb["parity"]["pass"] is True and plumb["last_pass"]["cuts_per_s"] > 0
     legs = plumb["legs"]
-    assert any(k.startswith("A cpu_per_cut") for k in legs) and any(k.startswith("B hip_batch_numpy_files") for k in legs) and any(k.startswith("C hip_bulk") for k in legs)
+    # (leg A, the CPU per-cut driver, belongs to the CPU baseline: this test runs the line with --no-cpu-baseline)
+    assert any(k.startswith("B hip_batch_numpy_files") for k in legs) and any(k.startswith("C hip_bulk") for k in legs) and any("FORKED AFTER" in k for k in legs)
     assert all(v["cuts_per_s"] > 0 for k, v in legs.items() if isinstance(v, dict)), legs
     for name, c in cfgs.items():
         assert c["parity"]["pass_rel_l2"] is True and c["value"] > 0 and c["roofline"]["frac"] > 0 and c["steps"] > 0, (name, c)

@@ -46,9 +46,15 @@ for section in "$@"; do
           d="$OUT/traffic_$cfg/pass_$ctr"; mkdir -p "$d"
           BENCH_SETTLE=0 timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$d" -o p -- python bench.py --config $cfg --steps 2 --warmup 1 --no-parity --no-extra --no-cpu-baseline > "$d.log" 2>&1
         done
-        python tools/make_traffic_json.py --config $cfg "$OUT/traffic_$cfg" > "$OUT/traffic_$cfg/summary.txt" 2>&1; cat "$OUT/traffic_$cfg/summary.txt"
+        python tools/make_traffic_json.py --config $cfg "$OUT/traffic_$cfg" "$OUT/pmc_$cfg/summary.txt" > "$OUT/traffic_$cfg/summary.txt" 2>&1; tail -5 "$OUT/traffic_$cfg/summary.txt"
+        find "$OUT/traffic_$cfg" -name "*.csv" -size +2M -delete 2>/dev/null
       done
-      tools/pmc_profile.sh "$OUT/pmc_headline" --no-extra --no-parity > /dev/null 2>&1; cp "$OUT/pmc_headline/summary.txt" "$OUT/pmc_headline.txt" 2>/dev/null ;;
+      tools/pmc_profile.sh "$OUT/pmc_headline" --no-extra --no-parity --no-other-configs > /dev/null 2>&1; cp "$OUT/pmc_headline/summary.txt" "$OUT/pmc_headline.txt" 2>/dev/null
+      find "$OUT/pmc_headline" -name "*.csv" -size +2M -delete 2>/dev/null
+      # (profiles/traffic.json is written HERE, on the box: copy it back through gpurun_out)
+      probe=""; [ -f "$OUT/power_probe.txt" ] && probe="$OUT/power_probe.txt"
+      python tools/make_traffic_json.py "$OUT/pmc_headline.txt" 4000 "${PMC_LABEL:-profiles/r06_pmc.txt}" $probe > "$OUT/traffic_headline.json" 2>&1
+      cp profiles/traffic.json "$OUT/traffic.json" ;;
     configs)
       for cfg in mfcc40_libri onthefly bulk_save plumbing; do
         timeout 900 python bench.py --config $cfg > "$OUT/bench_$cfg.json" 2> "$OUT/bench_$cfg.err"; echo "$cfg rc=$?"

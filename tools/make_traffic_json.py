@@ -93,10 +93,36 @@ def config_entry(name: str, root: str):
     return entry
 
 
+def sq_counters(summary_path: str, kernel_prefix: str):
+    """The SQ counters of tools/pmc_any.sh's summary for the feature kernel (per-dispatch medians), VERDICT r5 task 4."""
+    out, take = {}, False
+    for ln in open(summary_path):
+        if ln.startswith("== "):
+            take = kernel_prefix in ln
+            if take:
+                out["device_symbol"] = ln[3:].strip()
+            continue
+        if not take:
+            continue
+        m = re.match(r"\s+(\w+)\s+per-dispatch median ([0-9.e+-]+)", ln)
+        if m:
+            out[m.group(1)] = float(m.group(2))
+        m = re.search(r"dispatch duration under profiling: median ([0-9.]+) us", ln)
+        if m:
+            out["duration_us_under_profiling"] = float(m.group(1))
+    return out
+
+
 def main():
     if sys.argv[1] == "--config":
         name, root = sys.argv[2], sys.argv[3]
         entry = config_entry(name, root)
+        if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):  # tools/pmc_any.sh summary of the same config (separate --pmc passes)
+            sym = {"mfcc40_libri": "fft512c_kernel<13, 12, 2, true>", "onthefly": "fft512c_kernel<13, 12, 0, true>"}[name]
+            entry["sq_counters_per_dispatch"] = sq_counters(sys.argv[4], sym)
+            if name == "onthefly":
+                entry["sq_counters_per_dispatch_prep_launch"] = sq_counters(sys.argv[4], "minibatch_prep_inline_kernel")
+            entry["sq_counters_source"] = f"tools/collect.sh pmc ({sys.argv[4]}): rocprofv3 --pmc SQ_* in two passes of `bench.py --config {name} --steps 2 --warmup 1`; per-frame table: profiles/r06_pmc_baseline_kernels.txt"
         path = os.path.join(ROOT, "profiles", "traffic.json")
         with open(path) as f:
             t = json.load(f)

@@ -221,6 +221,26 @@ class DecodeDataset:
         self.cuts, self.pcm16, self.template, self.frame_shift, self.packed = cuts, pcm16, template, frame_shift, packed
         self._rc = {}
 
+    def __getstate__(self):
+        """Workers started by spawn / a fork server receive the dataset by pickle, once per worker: the cut objects (thousands, with their
+        supervisions) are rebuilt there from (paths, repeat) instead of travelling -- lhotse's dataset objects are just as light (the cuts
+        stay with the sampler in the main process)."""
+        st = dict(self.__dict__)
+        paths = []
+        for c in self.cuts:
+            if c.path in paths:
+                break
+            paths.append(c.path)
+        if len(self.cuts) % len(paths) == 0 and all(c.path == paths[i % len(paths)] for i, c in enumerate(self.cuts)) and self.cuts[0].id == "cut-0000000":
+            st["cuts"] = ("make_cuts", paths, len(self.cuts) // len(paths))
+        st["_rc"] = {}
+        return st
+
+    def __setstate__(self, st):
+        if isinstance(st["cuts"], tuple) and st["cuts"][0] == "make_cuts":
+            st["cuts"] = make_cuts(st["cuts"][1], st["cuts"][2])
+        self.__dict__.update(st)
+
     def __getitem__(self, idx: List[int]):
         t0 = time.perf_counter()
         audio = [read_wav(self.cuts[i].path, self.pcm16) for i in idx]
