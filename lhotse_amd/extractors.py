@@ -724,6 +724,8 @@ def _as_1d_float(x: ArrayLike, what: str) -> ArrayLike:
     if isinstance(x, torch.Tensor):
         if x.dtype not in (torch.float32, torch.int16):
             raise TypeError(f"{what}: expected float32 (or int16 PCM) samples, got {x.dtype}")
+        if x.ndim == 1:
+            return x  # (the common case of the batch drivers: 60 views per batch, and a torch-level reshape each was a third of the calling thread's time)
         return x[0] if x.ndim == 2 else x.reshape(-1)
     x = np.asarray(x)
     if x.dtype not in (np.float32, np.int16):
