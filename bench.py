@@ -1035,6 +1035,27 @@ class Plumbing:
             return {"error": (p.stderr or p.stdout)[-600:]}
         return rows
 
+    def _shared_gpu(self, procs: int, workers: int):
+        """Leg C in `procs` FRESH processes that share this GPU (each with its own plan, pipeline, archive and `workers` loader workers),
+        started together: what one GPU takes when the loader-bound driver is run as several processes -- the sharded driver accepts any
+        number of ranks per device.  Aggregate = cuts of all processes behind their first batches / the span of their steady regions."""
+        import subprocess
+
+        start = time.time() + 12.0  # (imports and plan creation of all processes are over by then)
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "plumbing.py"), "--leg", "C", "--wav-dir", os.path.dirname(self.paths[0]), "--repeat", str(self.repeat),
+               "--stripes", str(self.stripes), "--workers", str(workers), "--passes", "1", "--start-at", str(start)]
+        ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIPFEAT_NO_FORK_WARNING="1")) for _ in range(procs)]
+        rows = []
+        for p in ps:
+            o, _ = p.communicate(timeout=900)
+            rows += [json.loads(ln) for ln in o.splitlines() if ln.startswith("{")]
+        key = f"C hip_bulk float32 -> hip_archive, {procs} PROCESSES sharing the GPU x {workers} loader workers each"
+        if len(rows) != procs:
+            return {key: {"error": f"{len(rows)} of {procs} processes answered"}}
+        t0, t1 = min(r["steady_region_epoch"][0] for r in rows), max(r["steady_region_epoch"][1] for r in rows)
+        return {key: {"cuts_per_s": round(sum(r["steady_cuts"] for r in rows) / (t1 - t0), 1), "per_process_cuts_per_s": [r["cuts_per_s"] for r in rows],
+                      "processes": procs, "num_workers": workers, "cuts": sum(r["cuts"] for r in rows)}}
+
     def extra(self, args, full: bool = True):
         import shutil
 
@@ -1064,6 +1085,8 @@ class Plumbing:
         if full:
             out[f"C hip_bulk float32 -> hip_archive, {W} loader workers, fork server, GPU touched before"] = \
                 brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--gpu-first", "--context", "forkserver"))
+        if full:
+            out.update(self._shared_gpu(4, 8))
         if not args.no_cpu_baseline:
             ncpu = len(os.sched_getaffinity(0))
             for jobs in sorted({1, max(1, min(64, ncpu // 4))}):

@@ -398,7 +398,9 @@ def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
         paths = [str(p) for p in ar.paths]
     wall = time.perf_counter() - t0
     steady = (len(cuts) - len(batches[0])) / max(wall - (t_first[0] or 0.0), 1e-9)
-    return {"cuts_per_s": round(steady, 1), "cuts_per_s_incl_worker_start": round(len(cuts) / wall, 1), "seconds_to_first_batch": round(t_first[0] or 0.0, 3),
+    now = time.time()
+    return {"steady_region_epoch": [round(now - wall + (t_first[0] or 0.0), 3), round(now, 3)], "steady_cuts": len(cuts) - len(batches[0]),
+            "cuts_per_s": round(steady, 1), "cuts_per_s_incl_worker_start": round(len(cuts) / wall, 1), "seconds_to_first_batch": round(t_first[0] or 0.0, 3),
             "cuts": len(cuts), "seconds": round(wall, 3), "num_workers": num_workers, "input": "int16" if pcm16 else "float32",
             "transport": "one packed tensor per batch" if packed else "one array per cut", "worker_start": context or "fork",
             "storage": storage, "stripes": stripes, "main_thread_waiting_for_the_loader_share": round(t_load[0] / wall, 3),
@@ -445,6 +447,7 @@ def main() -> None:
     ap.add_argument("--context", default=None)
     ap.add_argument("--gpu-first", action="store_true", help="touch the GPU BEFORE the workers are forked (the hazardous order)")
     ap.add_argument("--passes", type=int, default=2)
+    ap.add_argument("--start-at", type=float, default=0.0, help="epoch second at which to begin (several processes sharing one GPU start together)")
     a = ap.parse_args()
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
@@ -459,6 +462,8 @@ def main() -> None:
         ex.extract(torch.zeros(16000), SR)
     base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
     best = None
+    if a.start_at:
+        time.sleep(max(0.0, a.start_at - time.time()))
     with tempfile.TemporaryDirectory(prefix="hipfeat_leg_", dir=base) as td:
         for k in range(a.passes):  # (pass 2 forks its workers with the plan of pass 1 alive unless a start method is given)
             d = os.path.join(td, f"p{k}")
