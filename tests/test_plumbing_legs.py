@@ -60,3 +60,45 @@ def test_legs_on_a_tiny_corpus(tmp_path, cpu_plan):
             got = P.read_back(c, k)
             assert got.shape == (1000, 80)
             assert np.linalg.norm(got - want[k]) / np.linalg.norm(want[k]) <= (2e-3 if half else 1e-4)
+
+
+def test_ring_loader_leg_and_the_loader_itself(tmp_path, cpu_plan):
+    """Leg D: the shared-memory ring loader (lhotse_amd/ring_loader.py) feeding the bulk driver -- same stored features as leg C; and the
+    loader on its own: submission order, slot recycling under a slow consumer, an error inside a worker reaching the consumer."""
+    import plumbing as P
+
+    import lhotse_amd as LA
+    from lhotse_amd.ring_loader import RingLoader, pack_into
+    from oracle.kaldi_torch import TorchFbank
+
+    paths = P.write_corpus(str(tmp_path / "wav"), n_files=3, seed=5)
+    cuts = P.make_cuts(paths, 2)
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cpu"))
+    d = P.hip_ring(ex, cuts, str(tmp_path / "d"), num_workers=2, stripes=2)
+    assert d["cuts"] == 6 and "shared ring" in d["transport"]
+    for k in (0, 5):
+        want = TorchFbank().extract(P.read_wav(cuts[k].path)[0])
+        got = P.read_back(d, k)
+        assert got.shape == (1000, 80) and np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-4
+
+    def load(spec, out):  # spec = (seed, n): n floats of RandomState(seed), or an error
+        if spec[0] < 0:
+            raise ValueError("boom")
+        a = np.random.RandomState(spec[0]).rand(spec[1]).astype(np.float32)
+        used, offs, lens = pack_into(out, [a, a[:7]])
+        return used, {"offs": offs, "lens": lens, "seed": spec[0]}
+
+    with RingLoader(load, num_workers=3, slot_bytes=1 << 16, num_slots=4, start_method="fork") as rl:
+        held = []
+        for i, rb in enumerate(rl.batches([(s, 1000 + s) for s in range(40)])):
+            assert rb.index == i and rb.meta["seed"] == i
+            flat = rb.data.view(np.float32)
+            o, n = rb.meta["offs"].tolist(), rb.meta["lens"].tolist()
+            assert n == [1000 + i, 7] and o[1] % 4 == 0
+            assert np.array_equal(flat[o[0] : o[0] + n[0]], np.random.RandomState(i).rand(1000 + i).astype(np.float32))
+            held.append(rb)  # a consumer that keeps three batches (of four slots) before giving them back
+            if len(held) == 3:
+                held.pop(0).release()
+        del held
+        with pytest.raises(RuntimeError, match="boom"):
+            list(rl.batches([(1, 10), (-1, 0), (2, 10)]))

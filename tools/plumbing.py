@@ -409,6 +409,104 @@ def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
             "manifest_thread_busy_share": round(busy["lines"] / wall, 3), "archive_paths": paths, "manifest": os.path.join(out_dir, "cuts.jsonl.gz")}
 
 
+class DecodeIntoSlot:
+    """`load_batch` of lhotse_amd.ring_loader.RingLoader for this corpus: decode the batch's WAV files straight into the ring slot (packed),
+    serialise the manifest-line halves; what travels back is lengths + offsets + the halves."""
+
+    def __init__(self, cuts: List[Cut], pcm16: bool, template: Dict, frame_shift: float):
+        self.ds = DecodeDataset(cuts, pcm16=pcm16, template=template, frame_shift=frame_shift)
+
+    def __call__(self, idx: List[int], out: np.ndarray):
+        from lhotse_amd.ring_loader import pack_into
+        from lhotse_amd.storage import manifest_fragments
+
+        ds = self.ds
+        audio = [read_wav(ds.cuts[i].path, ds.pcm16)[0] for i in idx]
+        used, offs, lens = pack_into(out, audio)
+        frags = [manifest_fragments(ds.cuts[i], ds.template, ds.frame_shift, ds._rc) for i in idx]
+        return used, {"offs": offs, "lens": lens, "frags": frags}
+
+
+def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = False, half: bool = False, stripes: int = 8, context: Optional[str] = None) -> Dict:
+    """Leg D: leg C with the ring loader (lhotse_amd/ring_loader.py) in place of the DataLoader -- workers decode into slots of ONE shared
+    ring, the main process hands views of a slot to the host pipeline and frees the slot once the library has packed the batch."""
+    from lhotse_amd import storage as S
+    from lhotse_amd.ring_loader import RingLoader
+
+    os.makedirs(out_dir, exist_ok=True)
+    storage = "hip_archive_f16" if half else "hip_archive"
+    template = {"type": ex.name, "num_features": NUM_MELS, "frame_shift": ex.frame_shift, "sampling_rate": SR, "storage_type": storage, "storage_path": ""}
+    batches = batches_of(cuts)
+    item = 2 if pcm16 else 4
+    busy = {"save": 0.0, "wait": 0.0, "lines": 0.0}
+    stats: Dict = {}
+    t_load = [0.0]
+    t_first = [None]
+    t0 = time.perf_counter()
+    loader = RingLoader(DecodeIntoSlot(cuts, pcm16, template, ex.frame_shift), num_workers, slot_bytes=60 * (SAMPLES + 8) * item, start_method=context)
+
+    def timed(it):
+        while True:
+            ta = time.perf_counter()
+            try:
+                b = next(it)
+            except StopIteration:
+                return
+            tb = time.perf_counter()
+            t_load[0] += tb - ta
+            if t_first[0] is None:
+                t_first[0] = tb - t0
+            yield b
+
+    try:
+        with gzip.open(os.path.join(out_dir, "cuts.jsonl.gz"), "wb") as manifest, \
+                S.NativeArchive(os.path.join(out_dir, "feats"), mode="w", np_dtype="<f2" if half else "<f4", stripes=stripes, name=storage) as ar:
+
+            def extract(rb):
+                flat = rb.data.view(np.int16 if pcm16 else np.float32)
+                waves = [flat[o : o + n] for o, n in zip(rb.meta["offs"].tolist(), rb.meta["lens"].tolist())]
+                pending, frames = S._batch_features_pending(ex, waves, SR, None, half=half)
+                return rb, pending, frames
+
+            def save(rb, pending, frames):
+                ta = time.perf_counter()
+                host = pending.wait()  # (the library is done with the caller's buffers: the slot goes back to the ring)
+                frags = rb.meta["frags"]
+                rb.release()
+                tb = time.perf_counter()
+                fr = np.ascontiguousarray(frames, dtype=np.int64)
+                file_of, byte_off = ar.append(host, fr)
+                del host
+                pending.release()
+                busy["wait"] += tb - ta
+                busy["save"] += time.perf_counter() - tb
+                return frags, fr, file_of, byte_off
+
+            def lines(frags, fr, file_of, byte_off):
+                ta = time.perf_counter()
+                blob = ar.lines([f[0] for f in frags], [f[1] for f in frags], fr, np.fromiter((f[2] for f in frags), dtype=np.int64, count=len(frags)),
+                                file_of, byte_off, NUM_MELS)
+                manifest.write(blob)
+                manifest.flush()
+                busy["lines"] += time.perf_counter() - ta
+
+            S.pump_batches(timed(loader.batches(batches)), extract, save, stats=stats, finish=lines)
+            paths = [str(p) for p in ar.paths]
+    finally:
+        loader.close()
+    wall = time.perf_counter() - t0
+    steady = (len(cuts) - len(batches[0])) / max(wall - (t_first[0] or 0.0), 1e-9)
+    now = time.time()
+    return {"steady_region_epoch": [round(now - wall + (t_first[0] or 0.0), 3), round(now, 3)], "steady_cuts": len(cuts) - len(batches[0]),
+            "cuts_per_s": round(steady, 1), "cuts_per_s_incl_worker_start": round(len(cuts) / wall, 1), "seconds_to_first_batch": round(t_first[0] or 0.0, 3),
+            "cuts": len(cuts), "seconds": round(wall, 3), "num_workers": num_workers, "input": "int16" if pcm16 else "float32",
+            "transport": f"shared ring of {loader.num_slots} slots", "worker_start": loader.start_method, "storage": storage, "stripes": stripes,
+            "main_thread_waiting_for_the_loader_share": round(t_load[0] / wall, 3), "main_thread_submit_share": round(stats.get("extract_s", 0.0) / wall, 3),
+            "main_thread_blocked_on_the_save_threads_share": round(stats.get("wait_s", 0.0) / wall, 3), "archive_thread_busy_share": round(busy["save"] / wall, 3),
+            "archive_thread_waiting_for_the_device_share": round(busy["wait"] / wall, 3), "manifest_thread_busy_share": round(busy["lines"] / wall, 3),
+            "archive_paths": paths, "manifest": os.path.join(out_dir, "cuts.jsonl.gz")}
+
+
 def read_back(result: Dict, index: int) -> np.ndarray:
     """Cut `index` of a leg-C run, through the archive reader named by its manifest line."""
     from lhotse_amd import storage as S
@@ -436,7 +534,7 @@ def main() -> None:
     import tempfile
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--leg", required=True, choices=["B", "C"])
+    ap.add_argument("--leg", required=True, choices=["B", "C", "D"])
     ap.add_argument("--wav-dir", required=True)
     ap.add_argument("--repeat", type=int, default=50)
     ap.add_argument("--workers", type=int, default=8)
@@ -469,6 +567,8 @@ def main() -> None:
             d = os.path.join(td, f"p{k}")
             if a.leg == "B":
                 r = hip_batch_numpy_files(ex, cuts, d, a.workers, context=a.context)
+            elif a.leg == "D":
+                r = hip_ring(ex, cuts, d, a.workers, pcm16=a.pcm16, half=a.half, stripes=a.stripes, context=a.context)
             else:
                 r = hip_bulk(ex, cuts, d, a.workers, pcm16=a.pcm16, half=a.half, stripes=a.stripes, packed=not a.per_cut_transport, context=a.context)
             r.pop("archive_paths", None), r.pop("manifest", None)
