@@ -60,12 +60,13 @@ def _worker(shm_name: str, slot_bytes: int, num_slots: int, task_q, result_q, lo
 
 
 class RingBatch:
-    """One delivered batch: `data` = uint8 view of the used part of its slot (valid until `release()`), `meta` = what `load_batch` returned."""
+    """One delivered batch: `data` = uint8 view of the used part of its slot (valid until `release()`), `meta` = what `load_batch` returned,
+    `spec` = the object the batch was asked for with (it never left this process)."""
 
-    __slots__ = ("index", "slot", "data", "meta", "_loader", "_released")
+    __slots__ = ("index", "slot", "data", "meta", "spec", "_loader", "_released")
 
-    def __init__(self, loader, index, slot, data, meta):
-        self._loader, self.index, self.slot, self.data, self.meta, self._released = loader, index, slot, data, meta, False
+    def __init__(self, loader, index, slot, data, meta, spec=None):
+        self._loader, self.index, self.slot, self.data, self.meta, self.spec, self._released = loader, index, slot, data, meta, spec, False
 
     def release(self) -> None:
         """The slot may be overwritten from now on (callable from any thread, once)."""
@@ -83,7 +84,7 @@ class RingBatch:
 
 class RingLoader:
     def __init__(self, load_batch: Callable[[Any, np.ndarray], Tuple[int, Any]], num_workers: int, slot_bytes: int, num_slots: Optional[int] = None,
-                 start_method: Optional[str] = None, worker_init_fn: Optional[Callable[[int], None]] = None):
+                 start_method: Optional[str] = None, worker_init_fn: Optional[Callable[[int], None]] = None, preload: Iterable[str] = ()):
         import multiprocessing as mp
         from multiprocessing import shared_memory
 
@@ -97,13 +98,14 @@ class RingLoader:
             start_method = "forkserver" if _lib.hip_live() else "fork"
         self.start_method = start_method
         if start_method == "forkserver":
-            mp.set_forkserver_preload(["numpy", "torch", "lhotse_amd.ring_loader"])
+            # (the workers are forked off the SERVER: with the heavy imports done there once a worker starts in milliseconds)
+            mp.set_forkserver_preload(["numpy", "torch", "lhotse_amd.ring_loader", *preload])
         ctx = mp.get_context(start_method)
         self._shm = shared_memory.SharedMemory(create=True, size=self.slot_bytes * self.num_slots)
         self._ring = np.ndarray((self.slot_bytes * self.num_slots,), dtype=np.uint8, buffer=self._shm.buf)
         self._tasks, self._results = ctx.Queue(), ctx.Queue()
-        self._free: "queue.SimpleQueue[int]" = queue.SimpleQueue()
-        for s in range(self.num_slots):
+        self._free: "queue.LifoQueue[int]" = queue.LifoQueue()  # (a stack: a released slot is the next one filled -- the working set stays what is in flight)
+        for s in reversed(range(self.num_slots)):
             self._free.put(s)
         self._procs = [ctx.Process(target=_worker, args=(self._shm.name, self.slot_bytes, self.num_slots, self._tasks, self._results, load_batch, worker_init_fn, w),
                                    daemon=True) for w in range(self.num_workers)]
@@ -119,6 +121,7 @@ class RingLoader:
         submitted = delivered = 0
         exhausted = False
         done: Dict[int, Tuple[int, int, Any]] = {}
+        asked: Dict[int, Any] = {}
         while True:
             # hand out work while slots are free (never blocks: what is not free yet is picked up on a later turn)
             while not exhausted:
@@ -133,12 +136,13 @@ class RingLoader:
                     self._free.put(slot)
                     break
                 self._tasks.put((submitted, slot, spec))
+                asked[submitted] = spec
                 submitted += 1
             if delivered == submitted and exhausted:
                 return
             if delivered in done:
                 slot, used, meta = done.pop(delivered)
-                yield RingBatch(self, delivered, slot, self._ring[slot * self.slot_bytes : slot * self.slot_bytes + used], meta)
+                yield RingBatch(self, delivered, slot, self._ring[slot * self.slot_bytes : slot * self.slot_bytes + used], meta, asked.pop(delivered))
                 delivered += 1
                 continue
             if delivered == submitted:  # nothing in flight and no slot free: wait for the consumer to release one

@@ -673,7 +673,8 @@ def test_loader_workers_hand_over_one_packed_tensor_per_batch(tmp_path, cutset, 
     plain = S.FragmentingWaveformDataset(False, None, 0.01, pack=False)[cutset]
     assert isinstance(plain["audio"], list) and "hipfeat_lens" not in plain and S.unpack_batch_audio(plain) is plain["audio"]
     ex = LA.HipFbank(LA.HipFbankConfig(device="cpu"))
-    a = S.compute_and_store_features_batch(cutset, ex, tmp_path / "a", manifest_path=tmp_path / "a.jsonl.gz", batch_duration=3.0, num_workers=2)
+    a = S.compute_and_store_features_batch(cutset, ex, tmp_path / "a", manifest_path=tmp_path / "a.jsonl.gz", batch_duration=3.0, num_workers=2,
+                                           loader="dataloader")
     b = S.compute_and_store_features_batch(cutset, ex, tmp_path / "b", manifest_path=tmp_path / "b.jsonl.gz", batch_duration=3.0, num_workers=2,
                                            augment_fn=lambda w, sr: w)
     fa, fb = {c.id: c.load_features() for c in a}, {c.id: c.load_features() for c in b}
@@ -703,7 +704,7 @@ def test_the_batch_driver_starts_its_workers_through_a_fork_server_when_the_gpu_
 
     monkeypatch.setattr(tud, "DataLoader", Spy)
     ex = LA.HipFbank(LA.HipFbankConfig(device="cpu"))
-    kw = dict(batch_duration=3.0, num_workers=2)
+    kw = dict(batch_duration=3.0, num_workers=2, loader="dataloader")
     monkeypatch.setattr(_lib, "hip_live", lambda: False)
     S.compute_and_store_features_batch(cutset, ex, tmp_path / "a", manifest_path=tmp_path / "a.jsonl.gz", **kw)
     assert seen[-1] == {}
@@ -716,6 +717,25 @@ def test_the_batch_driver_starts_its_workers_through_a_fork_server_when_the_gpu_
     assert seen[-1] == {}
     S.compute_and_store_features_batch(cutset, ex, tmp_path / "d", manifest_path=tmp_path / "d.jsonl.gz", batch_duration=3.0, num_workers=0)
     assert seen[-1] == {}
+    # the ring loader (the default where it applies) takes the same decision
+    import lhotse_amd.ring_loader as R
+
+    started = []
+    real_ring = R.RingLoader
+
+    class SpyRing(real_ring):
+        def __init__(self, *a, **k):
+            started.append((k.get("start_method"), k.get("worker_init_fn")))
+            k["start_method"] = "fork"  # (as above: no stub modules behind a fork server in this container)
+            super().__init__(*a, **k)
+
+    monkeypatch.setattr(R, "RingLoader", SpyRing)
+    with pytest.warns(RuntimeWarning, match="fork server"):
+        S.compute_and_store_features_batch(cutset, ex, tmp_path / "e", manifest_path=tmp_path / "e.jsonl.gz", batch_duration=3.0, num_workers=2, worker_init_fn=init)
+    assert started[-1] == ("forkserver", init)
+    monkeypatch.setattr(_lib, "hip_live", lambda: False)
+    S.compute_and_store_features_batch(cutset, ex, tmp_path / "f", manifest_path=tmp_path / "f.jsonl.gz", batch_duration=3.0, num_workers=2)
+    assert started[-1] == (None, None) and len(seen) == 4  # (no DataLoader was built for the two ring runs)
 
 
 def test_forking_with_a_live_context_warns_once(monkeypatch):
@@ -738,3 +758,88 @@ def test_forking_with_a_live_context_warns_once(monkeypatch):
         if pid == 0:
             os._exit(0)
         os.waitpid(pid, 0)
+
+
+def test_ring_loader_behind_the_batch_driver_equals_the_dataloader(tmp_path, cutset, cpu_device, monkeypatch):
+    """Round 6: `loader="ring"` (the default where it applies) -- worker processes load every batch's audio straight into a slot of one
+    shared-memory ring (lhotse_amd/ring_loader.py + storage.LoadCutsIntoSlot) -- gives the DataLoader route's manifest character for
+    character and the same archive bytes; cuts whose audio fails to load are dropped with lhotse's warning as
+    UnsupervisedWaveformDataset drops them (lhotse/dataset/unsupervised.py:72-78); a batch that does not fit a slot travels by pickle;
+    where the ring does not apply the DataLoader is used, and asking for it there is an error."""
+    import lhotse_amd as LA
+    import lhotse_amd.ring_loader as R
+    from lhotse import CutSet, MonoCut, Recording, SupervisionSegment
+    from lhotse.audio import AudioSource
+    from lhotse_amd import storage as S
+
+    cuts = []
+    for k in range(5):
+        for c in cutset:
+            c = c.with_id(f"{c.id}-{k}")
+            c.supervisions = [SupervisionSegment(id=c.id, recording_id=c.recording_id, start=0.0, duration=c.duration, text=f"gęślą \"{k}\"", speaker=f"s{k}")]
+            cuts.append(c)
+    # one cut whose file holds half of what its manifest states: dropped by both loaders (DurationMismatchError is one of the errors
+    # suppress_audio_loading_errors swallows, lhotse/audio/utils.py:126-138)
+    ghost = Recording(id="ghost", sources=[AudioSource(type="file", channels=[0], source=str(tmp_path / "r0.wav"))], sampling_rate=16000, num_samples=32000, duration=2.0)
+    cuts.insert(7, MonoCut(id="ghost-cut", start=0, duration=2.0, channel=0, recording=ghost))
+    many = CutSet.from_cuts(cuts)
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cpu"))
+    kw = dict(batch_duration=4.0, num_workers=2)
+    want_cuts = list(S.compute_and_store_features_batch(many, ex, tmp_path / "dl", manifest_path=tmp_path / "dl.jsonl.gz", loader="dataloader", **kw))
+    want = _lines(tmp_path / "dl.jsonl.gz")
+    assert len(want) == 25 and "ghost-cut" not in {c.id for c in want_cuts}
+
+    made = []
+    real = R.RingLoader
+
+    class Spy(real):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+
+    monkeypatch.setattr(R, "RingLoader", Spy)
+    for tag, extra in (("ring", dict(loader="ring")), ("auto", {}), ("s2", dict(archive_stripes=2))):
+        before = dict(S.TEMPLATE_STATS)
+        got_cuts = list(S.compute_and_store_features_batch(many, ex, tmp_path / tag, manifest_path=tmp_path / f"{tag}.jsonl.gz", **kw, **extra))
+        assert S.TEMPLATE_STATS.get("native", 0) - before.get("native", 0) == 25, tag
+        assert len(made) > 0 and made[-1]._closed and not any(p.is_alive() for p in made[-1]._procs), tag
+        got = _lines(tmp_path / f"{tag}.jsonl.gz")
+        if "archive_stripes" not in extra:
+            assert [ln.replace(str(tmp_path / tag) + ".hfa", str(tmp_path / "dl") + ".hfa") for ln in got] == want, tag
+            assert (tmp_path / f"{tag}.hfa").read_bytes() == (tmp_path / "dl.hfa").read_bytes(), tag
+        assert [c.id for c in got_cuts] == [c.id for c in want_cuts]
+        for a, b in zip(got_cuts, want_cuts):
+            assert np.array_equal(a.load_features(), b.load_features())
+    assert len(made) == 3
+    # resume through the ring: nothing is extracted twice
+    size = os.path.getsize(tmp_path / "ring.hfa")
+    again = list(S.compute_and_store_features_batch(many, ex, tmp_path / "ring", manifest_path=tmp_path / "ring.jsonl.gz", loader="ring", **kw))
+    assert [c.id for c in again] == [c.id for c in want_cuts] and os.path.getsize(tmp_path / "ring.hfa") == size
+    # a batch that does not fit its slot (here: every batch -- the slots are made tiny) still arrives, by pickle
+    class Tiny(real):
+        def __init__(self, load_batch, num_workers, slot_bytes, num_slots=None, **k):
+            super().__init__(load_batch, num_workers, 4096, num_slots, **k)
+
+    monkeypatch.setattr(R, "RingLoader", Tiny)
+    S.compute_and_store_features_batch(many, ex, tmp_path / "tiny", manifest_path=tmp_path / "tiny.jsonl.gz", loader="ring", **kw)
+    assert (tmp_path / "tiny.hfa").read_bytes() == (tmp_path / "dl.hfa").read_bytes()
+    monkeypatch.setattr(R, "RingLoader", Spy)
+    # where it does not apply
+    n = len(made)
+    S.compute_and_store_features_batch(many, ex, tmp_path / "aug", manifest_path=tmp_path / "aug.jsonl.gz", augment_fn=lambda w, sr: w, **kw)
+    clean = CutSet.from_cuts(c for c in cuts if c.id != "ghost-cut")  # (collate_audio is not fault tolerant: lhotse/dataset/collation.py:207)
+    S.compute_and_store_features_batch(clean, ex, tmp_path / "col", manifest_path=tmp_path / "col.jsonl.gz", collate=True, **kw)
+    S.compute_and_store_features_batch(many, ex, tmp_path / "w0", manifest_path=tmp_path / "w0.jsonl.gz", batch_duration=4.0, num_workers=0)
+    assert len(made) == n
+    for bad in (dict(collate=True), dict(augment_fn=lambda w, sr: w), dict(num_workers=0)):
+        with pytest.raises(ValueError, match="loader='ring' serves"):
+            S.compute_and_store_features_batch(many, ex, tmp_path / "x", manifest_path=tmp_path / "x.jsonl.gz", loader="ring", **{**kw, **bad})
+    with pytest.raises(ValueError, match="expected None"):
+        S.compute_and_store_features_batch(many, ex, tmp_path / "x", manifest_path=tmp_path / "x.jsonl.gz", loader="queue", **kw)
+    # /dev/shm too small: the default falls back to the DataLoader with a warning, an explicit request raises
+    monkeypatch.setattr(S, "_shm_free_bytes", lambda: 1 << 20)
+    with pytest.warns(RuntimeWarning, match="using the DataLoader"):
+        S.compute_and_store_features_batch(many, ex, tmp_path / "small", manifest_path=tmp_path / "small.jsonl.gz", **kw)
+    assert (tmp_path / "small.hfa").read_bytes() == (tmp_path / "dl.hfa").read_bytes()
+    with pytest.raises(OSError, match="/dev/shm"):
+        S.compute_and_store_features_batch(many, ex, tmp_path / "small2", manifest_path=tmp_path / "small2.jsonl.gz", loader="ring", **kw)
