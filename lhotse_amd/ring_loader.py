@@ -10,6 +10,11 @@ batch alone is 5.5 ms).  Here the memory is allocated ONCE: a worker takes a fre
 loading function returns); the main process hands 1-D views of the slot to the extractor and gives the slot back when the library has
 packed the batch.  No per-batch mapping, no descriptor passing, no large unpickling.
 
+Every worker OWNS its slots (batch i goes to worker i mod W, into one of that worker's slots): a process pays a page fault for every
+page of the ring it touches for the first time, and with a free-for-all pool every worker ends up touching every slot -- measured on the
+GPU box (16-CPU cgroup quota) as 7 / 12 / 27 / 70 s of SYSTEM time for the same 12 800 cuts with 8 / 16 / 32 / 64 workers
+(profiles/r06_host_limits.txt).  With owned slots a worker faults its own 3-5 slots once.
+
 Nothing here knows lhotse: `load_batch(spec, out_bytes) -> (bytes_used, meta)` runs in the workers (lhotse_amd.storage supplies the one that
 calls `cut.load_audio()` and serialises the manifest-line halves; tools/plumbing.py one that decodes WAV files).  Batches are delivered in
 submission order.  Workers are started by `fork` unless this process already holds a live HIP context (lhotse_amd/_lib.py: the fork hazard),
@@ -73,7 +78,7 @@ class RingBatch:
         if not self._released:
             self._released = True
             self.data = None
-            self._loader._free.put(self.slot)
+            self._loader._give_back(self.slot)
 
     def __del__(self):
         try:
@@ -84,14 +89,19 @@ class RingBatch:
 
 class RingLoader:
     def __init__(self, load_batch: Callable[[Any, np.ndarray], Tuple[int, Any]], num_workers: int, slot_bytes: int, num_slots: Optional[int] = None,
-                 start_method: Optional[str] = None, worker_init_fn: Optional[Callable[[int], None]] = None, preload: Iterable[str] = ()):
+                 start_method: Optional[str] = None, worker_init_fn: Optional[Callable[[int], None]] = None, preload: Iterable[str] = (),
+                 consumer_holds: int = 12):
+        """`num_slots` (total; rounded up to a whole number per worker) -- default: two per worker (one being filled, one finished) + its
+        share of the `consumer_holds` slots the extractor / save threads keep at any time."""
         import multiprocessing as mp
         from multiprocessing import shared_memory
 
         assert num_workers >= 1 and slot_bytes > 0
-        self.num_workers = int(num_workers)
+        self.num_workers = W = int(num_workers)
         self.slot_bytes = (int(slot_bytes) + 4095) & ~4095
-        self.num_slots = int(num_slots or (2 * self.num_workers + 12))  # two per worker + what the extractor / save threads hold on to
+        per_worker = 2 + -(-int(consumer_holds) // W) if num_slots is None else max(1, -(-int(num_slots) // W))
+        self.slots_per_worker = per_worker
+        self.num_slots = per_worker * W
         if start_method is None:
             from . import _lib
 
@@ -103,51 +113,65 @@ class RingLoader:
         ctx = mp.get_context(start_method)
         self._shm = shared_memory.SharedMemory(create=True, size=self.slot_bytes * self.num_slots)
         self._ring = np.ndarray((self.slot_bytes * self.num_slots,), dtype=np.uint8, buffer=self._shm.buf)
-        self._tasks, self._results = ctx.Queue(), ctx.Queue()
-        self._free: "queue.LifoQueue[int]" = queue.LifoQueue()  # (a stack: a released slot is the next one filled -- the working set stays what is in flight)
-        for s in reversed(range(self.num_slots)):
-            self._free.put(s)
-        self._procs = [ctx.Process(target=_worker, args=(self._shm.name, self.slot_bytes, self.num_slots, self._tasks, self._results, load_batch, worker_init_fn, w),
-                                   daemon=True) for w in range(self.num_workers)]
+        self._tasks = [ctx.Queue() for _ in range(W)]  # one per worker: batch i is loaded by worker i mod W into a slot that worker owns
+        self._results = ctx.Queue()
+        # worker w owns slots w * per_worker ... ; stacks: a released slot is the next one filled
+        self._free: List[List[int]] = [list(range((w + 1) * per_worker - 1, w * per_worker - 1, -1)) for w in range(W)]
+        self._freed = threading.Condition()
+        self._procs = [ctx.Process(target=_worker, args=(self._shm.name, self.slot_bytes, self.num_slots, self._tasks[w], self._results, load_batch, worker_init_fn, w),
+                                   daemon=True) for w in range(W)]
         for p in self._procs:
             p.start()
-        self._closed = False
+        self._closed = self._broken = False
         self._lock = threading.Lock()
+
+    def _give_back(self, slot: int) -> None:
+        with self._freed:
+            self._free[slot // self.slots_per_worker].append(slot)
+            self._freed.notify_all()
 
     # -- iteration ----------------------------------------------------------------------------------------------------------------
     def batches(self, specs: Iterable[Any]) -> Iterator[RingBatch]:
-        """Load every spec of `specs` (in the workers, up to one per free slot ahead) and yield the batches in submission order."""
+        """Load every spec of `specs` (in the workers, as far ahead as their slots allow) and yield the batches in submission order."""
+        if self._broken:
+            raise RuntimeError("ring loader: an earlier pass failed or was abandoned half-way (slots and results of it are still in flight): close this loader")
+        self._broken = True  # (until this pass has delivered everything it handed out)
         it = iter(specs)
+        W = self.num_workers
         submitted = delivered = 0
         exhausted = False
         done: Dict[int, Tuple[int, int, Any]] = {}
         asked: Dict[int, Any] = {}
         while True:
-            # hand out work while slots are free (never blocks: what is not free yet is picked up on a later turn)
+            # hand out work: batch i to worker i mod W while that worker has a slot (never blocks: a worker without one holds OLDER batches,
+            # which are delivered first anyway)
             while not exhausted:
-                try:
-                    slot = self._free.get_nowait()
-                except queue.Empty:
+                w = submitted % W
+                with self._freed:
+                    slot = self._free[w].pop() if self._free[w] else None
+                if slot is None:
                     break
                 try:
                     spec = next(it)
                 except StopIteration:
                     exhausted = True
-                    self._free.put(slot)
+                    self._give_back(slot)
                     break
-                self._tasks.put((submitted, slot, spec))
+                self._tasks[w].put((submitted, slot, spec))
                 asked[submitted] = spec
                 submitted += 1
             if delivered == submitted and exhausted:
+                self._broken = False
                 return
             if delivered in done:
                 slot, used, meta = done.pop(delivered)
                 yield RingBatch(self, delivered, slot, self._ring[slot * self.slot_bytes : slot * self.slot_bytes + used], meta, asked.pop(delivered))
                 delivered += 1
                 continue
-            if delivered == submitted:  # nothing in flight and no slot free: wait for the consumer to release one
-                slot = self._free.get()
-                self._free.put(slot)
+            if delivered == submitted:  # nothing in flight and the next worker has no slot: wait for the consumer to release one of its
+                with self._freed:
+                    if not self._free[submitted % W]:
+                        self._freed.wait(timeout=1.0)
                 continue
             try:
                 idx, slot, used, meta, err = self._results.get(timeout=1.0)
@@ -168,9 +192,9 @@ class RingLoader:
             if self._closed:
                 return
             self._closed = True
-        for _ in self._procs:
+        for q in self._tasks:
             try:
-                self._tasks.put(None)
+                q.put(None)
             except Exception:  # noqa: BLE001
                 pass
         for p in self._procs:
@@ -213,3 +237,38 @@ def pack_into(out: np.ndarray, arrays: List[np.ndarray]) -> Tuple[int, np.ndarra
     for a, o, n in zip(arrays, offs, lens):
         flat[o : o + n] = a
     return used, offs[:-1].copy(), lens
+
+
+class SlotWriter:
+    """Appends 1-D arrays of ONE dtype to a slot as they are loaded, each on an ALIGN-byte boundary.  Copying every cut the moment it is
+    decoded (instead of collecting the batch and packing it at the end) keeps ONE decoded array alive at a time: the allocator hands the
+    same block out again and again, where 60 arrays alive at once are 60 fresh mappings per batch -- ~150 page faults per 10 s cut,
+    measured as the larger half of a worker's time (tools/loader_worker_probe.py)."""
+
+    def __init__(self, out: np.ndarray):
+        self.out, self.used, self.dtype, self.offs, self.lens = out, 0, None, [], []
+
+    def add(self, a: np.ndarray) -> bool:
+        """-> False (nothing written) when `a` is of another dtype or does not fit any more."""
+        if self.dtype is None:
+            self.dtype = a.dtype
+        elif a.dtype != self.dtype:
+            return False
+        item = self.dtype.itemsize
+        nbytes = a.shape[0] * item
+        if self.used + nbytes > self.out.shape[0]:
+            return False
+        self.out[self.used : self.used + nbytes].view(self.dtype)[:] = a
+        self.offs.append(self.used // item)
+        self.lens.append(a.shape[0])
+        self.used = (self.used + nbytes + ALIGN - 1) & ~(ALIGN - 1)
+        return True
+
+    def arrays(self) -> List[np.ndarray]:
+        """Copies of what was added (for a batch that turns out not to fit: it then travels as arrays)."""
+        flat = self.out.view(self.dtype) if self.dtype is not None else None
+        return [flat[o : o + n].copy() for o, n in zip(self.offs, self.lens)]
+
+    def finish(self) -> Tuple[int, np.ndarray, np.ndarray]:
+        """-> (bytes used, element offsets, lengths)"""
+        return min(self.used, self.out.shape[0]), np.array(self.offs, dtype=np.int64), np.array(self.lens, dtype=np.int64)

@@ -518,28 +518,29 @@ class LoadCutsIntoSlot:
         from lhotse import CutSet, MonoCut, validate
         from lhotse.audio.utils import suppress_audio_loading_errors
 
-        from .ring_loader import pack_into
+        from .ring_loader import SlotWriter
 
         validate(CutSet.from_cuts(cuts))
         assert all(c.has_recording for c in cuts)
         cache = self.__dict__.setdefault("_rec_cache", {})
-        kept, audio = [], []
+        kept, slot, loose = [], SlotWriter(out), None
         for i, c in enumerate(cuts):
             with suppress_audio_loading_errors():
-                audio.append(c.load_audio())
+                a = c.load_audio()
                 kept.append(i)
+                # every cut goes into the slot the moment it is loaded (one decoded array alive at a time); the first one that is not mono
+                # float32, or does not fit, turns the batch into a list of arrays
+                if loose is None and not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[0] == 1 and slot.add(a[0])):
+                    loose = [x.reshape(1, -1) for x in slot.arrays()]
+                if loose is not None:
+                    loose.append(a)
         t = self.template
         meta = {"kept": kept, "frags": None if t is None else [manifest_fragments(cuts[i], t, self.frame_shift, cache, MonoCut) for i in kept]}
-        if not audio:
+        if loose is not None:
+            meta["audio"] = loose
             return 0, meta
-        if all(isinstance(a, np.ndarray) and a.dtype == np.float32 and a.ndim == 2 and a.shape[0] == 1 for a in audio):
-            try:
-                used, meta["offs"], meta["lens"] = pack_into(out, [a[0] for a in audio])
-                return used, meta
-            except ValueError:
-                pass
-        meta["audio"] = audio
-        return 0, meta
+        used, meta["offs"], meta["lens"] = slot.finish()
+        return used, meta
 
 
 def _shm_free_bytes() -> Optional[int]:
@@ -902,17 +903,19 @@ def compute_and_store_features_batch(
 
                 sr0 = getattr(first, "sampling_rate", None) or 16000
                 slot_bytes = int(batch_duration * sr0 * 4 * 1.01) + 65536  # a batch of `batch_duration` seconds, float32, every cut on a 16-byte boundary
-                slots = 2 * num_workers + _SAVE_BACKLOG + 4
+                holds = _SAVE_BACKLOG + 4  # slots the extractor / save threads keep at any time
+                per_worker = 2 + -(-holds // num_workers)  # (every worker owns its slots: lhotse_amd/ring_loader.py)
                 room = _shm_free_bytes()
-                if room is not None and slots * slot_bytes > 0.8 * room:
-                    slots = max(num_workers + 4, min(slots, int(0.8 * room // slot_bytes)))
-                if room is not None and slots * slot_bytes > 0.8 * room:
+                if room is not None and per_worker * num_workers * slot_bytes > 0.8 * room:
+                    per_worker = min(per_worker, int(0.8 * room // (slot_bytes * num_workers)))
+                if per_worker < 2:
+                    want = 2 * num_workers * slot_bytes >> 20
                     if loader == "ring":
-                        raise OSError(f"loader='ring' needs {slots * slot_bytes >> 20} MiB of /dev/shm ({room >> 20} MiB are free): lower batch_duration / num_workers")
-                    warnings.warn(f"lhotse_amd.compute_and_store_features_batch: /dev/shm has {room >> 20} MiB free, the ring loader wants {slots * slot_bytes >> 20} MiB; "
+                        raise OSError(f"loader='ring' needs {want} MiB of /dev/shm ({room >> 20} MiB are free): lower batch_duration / num_workers")
+                    warnings.warn(f"lhotse_amd.compute_and_store_features_batch: /dev/shm has {room >> 20} MiB free, the ring loader wants {want} MiB; "
                                   "using the DataLoader", RuntimeWarning, stacklevel=2)
                 else:
-                    ring = RingLoader(LoadCutsIntoSlot(base, frame_shift), num_workers, slot_bytes, slots, start_method=loader_kw.get("multiprocessing_context"),
+                    ring = RingLoader(LoadCutsIntoSlot(base, frame_shift), num_workers, slot_bytes, per_worker * num_workers, start_method=loader_kw.get("multiprocessing_context"),
                                       worker_init_fn=worker_init_fn, preload=["lhotse", "lhotse.dataset", "lhotse_amd.storage"])
             if ring is None:
                 batches = DataLoader(_fragmenting_dataset_class()(collate, base, frame_shift, pack=augment_fn is None), batch_size=None, sampler=sampler,

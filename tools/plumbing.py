@@ -417,12 +417,15 @@ class DecodeIntoSlot:
         self.ds = DecodeDataset(cuts, pcm16=pcm16, template=template, frame_shift=frame_shift)
 
     def __call__(self, idx: List[int], out: np.ndarray):
-        from lhotse_amd.ring_loader import pack_into
+        from lhotse_amd.ring_loader import SlotWriter
         from lhotse_amd.storage import manifest_fragments
 
         ds = self.ds
-        audio = [read_wav(ds.cuts[i].path, ds.pcm16)[0] for i in idx]
-        used, offs, lens = pack_into(out, audio)
+        slot = SlotWriter(out)
+        for i in idx:  # (every cut into the slot the moment it is decoded, as lhotse_amd.storage.LoadCutsIntoSlot does)
+            if not slot.add(read_wav(ds.cuts[i].path, ds.pcm16)[0]):
+                raise ValueError("batch does not fit its ring slot")
+        used, offs, lens = slot.finish()
         frags = [manifest_fragments(ds.cuts[i], ds.template, ds.frame_shift, ds._rc) for i in idx]
         return used, {"offs": offs, "lens": lens, "frags": frags}
 
