@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define HIPFEAT_ABI_VERSION 4
+#define HIPFEAT_ABI_VERSION 5
 
 #if defined(HIPFEAT_BUILD)
 #define HIPFEAT_API __attribute__((visibility("default")))
@@ -358,6 +358,20 @@ HIPFEAT_API hipfeat_status hipfeat_host_pipeline_release(hipfeat_host_pipeline* 
  * staging, of those: waiting for a staging set's previous uploads / downloads (back-pressure from PCIe and the device), batches}:
  * lets a driver say which stage binds its run. */
 HIPFEAT_API hipfeat_status hipfeat_host_pipeline_stats(const hipfeat_host_pipeline* pipeline, int64_t* h_stats);
+/*
+ * ABI v5: upload straight out of the loader's memory.  What lhotse's driver receives per batch is whatever its DataLoader delivered
+ * (lhotse/cut/set.py:2374-2398): pageable arrays, which the pipeline above first copies into page-locked staging -- measured as the
+ * largest single CPU consumer of the offline path once the loader keeps up (4-5 of 14 busy CPUs, profiles/r06_ring_loader_ab.txt).
+ * hipfeat_host_register page-locks [ptr, ptr + bytes) of the CALLER's memory for DMA by `device` (any mapping: the slots of a
+ * shared-memory ring that loader processes fill); hipfeat_host_unregister(ptr) undoes it (before the memory is unmapped; never while a
+ * batch that reads it is outstanding).  hipfeat_host_pipeline_submit recognises a batch whose cuts all lie in ONE registered range, in
+ * ascending order, each on a 16-byte boundary and (nearly) back to back, and uploads that span with one copy: no staging, no packing
+ * threads.  Everything else about the call is unchanged (the cuts' memory must stay untouched until _wait returns, as before).
+ * hipfeat_host_pipeline_direct_batches = how many batches of the pipeline went that way so far (-1: NULL pipeline).
+ */
+HIPFEAT_API hipfeat_status hipfeat_host_register(int32_t device, void* ptr, int64_t bytes);
+HIPFEAT_API hipfeat_status hipfeat_host_unregister(void* ptr);
+HIPFEAT_API int64_t hipfeat_host_pipeline_direct_batches(const hipfeat_host_pipeline* pipeline);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import build as _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (return C type, [argument C types]) ; mirrors include/hipfeat.h one to one.
 _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
@@ -93,6 +93,9 @@ _SIGNATURES: Dict[str, Tuple[str, List[str]]] = {
     "hipfeat_host_pipeline_wait": ("int", ["hipfeat_host_pipeline*", "int64_t"]),
     "hipfeat_host_pipeline_release": ("int", ["hipfeat_host_pipeline*", "int64_t"]),
     "hipfeat_host_pipeline_stats": ("int", ["const hipfeat_host_pipeline*", "int64_t*"]),
+    "hipfeat_host_register": ("int", ["int32_t", "void*", "int64_t"]),
+    "hipfeat_host_unregister": ("int", ["void*"]),
+    "hipfeat_host_pipeline_direct_batches": ("int64_t", ["const hipfeat_host_pipeline*"]),
     "hipfeat_extract_host": (
         "int",
         ["const hipfeat_plan*", "const float*", "int64_t", "const int64_t*", "const int64_t*", "const int64_t*", "int64_t", "float*", "int64_t", "const int64_t*", "int64_t", "void*"],

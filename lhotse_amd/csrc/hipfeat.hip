@@ -2888,7 +2888,7 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_archive_open(const char* const* h_
     a->files.fds.push_back(fd);
     a->files.size.push_back((int64_t)end);
   }
-  if (num_files > 1) a->files.pool = new hipfeat::WorkPool(num_files - 1);
+  if (num_files > 1) a->files.pool = new hipfeat::WorkPool(num_files - 1, "hipfeat-stripe");
   *out = a;
   return HIPFEAT_OK;
 }

@@ -7,6 +7,7 @@
 //   * archive_append: the packed (sum T_b, F) matrix of a batch appended to the flat archive file(s) by a few writer threads.
 // No HIP in this file.
 #pragma once
+#include <pthread.h>
 
 #include <algorithm>
 #include <atomic>
@@ -29,8 +30,12 @@ namespace hipfeat {
 // batch costs 50-100 us each -- as much as the work itself for a 600 s batch cut eight ways.)
 class WorkPool {
  public:
-  explicit WorkPool(int workers) {
-    for (int i = 0; i < workers; ++i) th_.emplace_back([this] { loop(); });
+  // `name` (<= 15 characters) shows in /proc/<pid>/task/*/comm: per-thread CPU accounting of a run (tools/plumbing.py)
+  explicit WorkPool(int workers, const char* name = "hipfeat-pool") {
+    for (int i = 0; i < workers; ++i) {
+      th_.emplace_back([this] { loop(); });
+      (void)pthread_setname_np(th_.back().native_handle(), name);
+    }
   }
   ~WorkPool() {
     {

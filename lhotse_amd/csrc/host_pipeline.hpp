@@ -52,8 +52,28 @@ struct PipeOut {  // one page-locked result buffer
   int64_t ticket = -1;  // -1 = free
 };
 
+// memory of the caller that is page-locked for DMA (hipfeat_host_register): base -> (bytes, device)
+struct PinnedRange {
+  size_t bytes;
+  int device;
+};
+std::mutex g_pinned_mu;
+std::map<const char*, PinnedRange> g_pinned;
+
+// the registered range [p, p + bytes) lies in, for `device`: its base, or nullptr
+const char* pinned_base_of(const void* p, size_t bytes, int device) {
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  const char* c = static_cast<const char*>(p);
+  auto it = g_pinned.upper_bound(c);
+  if (it == g_pinned.begin()) return nullptr;
+  --it;
+  if (it->second.device != device || c + bytes > it->first + it->second.bytes) return nullptr;
+  return it->first;
+}
+
 struct PipeJob {
   int64_t ticket = 0;
+  bool direct = false;  // the cuts lie back to back in page-locked memory of the caller: uploaded from there, no staging
   std::vector<const void*> items;
   std::vector<int64_t> lens, off, row0, padded;
   std::vector<std::pair<int64_t, int64_t>> chunks;
@@ -96,7 +116,7 @@ struct hipfeat_host_pipeline {
   int target_chunks = kPipeTargetChunks;
   // the pipeline thread's own clock (hipfeat_host_pipeline_stats): nanoseconds busy with batches / of those: packing / of those: waiting
   // for a staging set's previous uploads and downloads (= back-pressure from PCIe and the device); batches processed
-  std::atomic<int64_t> ns_busy{0}, ns_pack{0}, ns_slot_wait{0}, n_batches{0};
+  std::atomic<int64_t> ns_busy{0}, ns_pack{0}, ns_slot_wait{0}, n_batches{0}, n_direct{0};
 };
 
 static inline int64_t pipe_now_ns() {
@@ -139,7 +159,7 @@ static hipfeat_status pipe_process_batch(hipfeat_host_pipeline* p, PipeJob& j, P
     p->ns_slot_wait.fetch_add(pipe_now_ns() - t0, std::memory_order_relaxed);
   }
   const size_t in_bytes = (size_t)j.total * in_item;
-  if (s.h_cap < in_bytes) {
+  if (!j.direct && s.h_cap < in_bytes) {
     if (s.h) (void)hipHostFree(s.h);
     s.h = nullptr;
     s.h_cap = 0;
@@ -156,7 +176,8 @@ static hipfeat_status pipe_process_batch(hipfeat_host_pipeline* p, PipeJob& j, P
     HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     s.chunk_done.push_back(e);
   }
-  char* hin = static_cast<char*>(s.h);
+  // direct: "staging" is the caller's own page-locked memory (element 0 = the first cut; j.off are the cuts' offsets in it)
+  char* hin = j.direct ? const_cast<char*>(static_cast<const char*>(j.items[0])) : static_cast<char*>(s.h);
   float* d_wave = j.pcm16 ? s.d_wave : static_cast<float*>(s.d_raw);
   struct Piece {
     char* dst;
@@ -169,13 +190,13 @@ static hipfeat_status pipe_process_batch(hipfeat_host_pipeline* p, PipeJob& j, P
   for (const auto& ch : j.chunks) {
     const int64_t a = ch.first, b = ch.second;
     pieces.clear();
-    for (int64_t i = a; i < b; ++i) {
+    for (int64_t i = a; i < b && !j.direct; ++i) {
       const char* src = static_cast<const char*>(j.items[(size_t)i]);
       char* dst = hin + (size_t)j.off[(size_t)i] * in_item;
       const size_t nbytes = (size_t)j.lens[(size_t)i] * in_item;
       for (size_t q = 0; q < nbytes; q += kPipeCopyPiece) pieces.push_back(Piece{dst + q, src + q, std::min(kPipeCopyPiece, nbytes - q)});
     }
-    {
+    if (!j.direct) {
       const int64_t t0 = pipe_now_ns();
       p->pool->run(pieces.size(), [&](size_t i) { std::memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes); });
       p->ns_pack.fetch_add(pipe_now_ns() - t0, std::memory_order_relaxed);
@@ -207,6 +228,7 @@ static hipfeat_status pipe_process_batch(hipfeat_host_pipeline* p, PipeJob& j, P
   HIP_TRY(hipEventRecord(s.downloaded, p->s_out));
   HIP_TRY(hipEventRecord(o.done, p->s_out));
   s.used = true;
+  if (j.direct) p->n_direct.fetch_add(1, std::memory_order_relaxed);
   return HIPFEAT_OK;
 }
 
@@ -264,8 +286,9 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_create(const hipfeat
     return fail(HIPFEAT_ERR_HIP, "host pipeline: stream / event creation failed: %s", hipGetErrorName(e));
   }
   if (const char* tc = route_env("HIPFEAT_PIPE_CHUNKS")) p->target_chunks = std::min(16, std::max(1, atoi(tc)));
-  p->pool = new hipfeat::WorkPool(copy_threads - 1);  // the pipeline thread copies too
+  p->pool = new hipfeat::WorkPool(copy_threads - 1, "hipfeat-pack");  // the pipeline thread copies too
   p->worker = std::thread(pipe_worker, p);
+  (void)pthread_setname_np(p->worker.native_handle(), "hipfeat-pipe");
   *out = p;
   return HIPFEAT_OK;
 }
@@ -326,6 +349,31 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_submit(hipfeat_host_
     j->off[(size_t)b] = total;
     total += (n + align - 1) & ~(align - 1);
     max_len = std::max(max_len, n);
+  }
+  // The cuts as they lie in the caller's memory: ascending, each on a 16-byte boundary, with less slack between them than packing would
+  // save, and all inside ONE range registered for this device -> the span is uploaded as it is.
+  {
+    const char* first = static_cast<const char*>(h_items[0]);
+    bool ok = first && (reinterpret_cast<uintptr_t>(first) & 15) == 0;
+    int64_t span = 0;  // elements from the first cut to the (aligned) end of the last
+    for (int64_t b = 0; b < batch && ok; ++b) {
+      const char* q = static_cast<const char*>(h_items[b]);
+      const int64_t n = h_num_samples[b];
+      if (n == 0) {
+        ok = false;
+        break;
+      }
+      const int64_t at = (q - first) / (int64_t)in_item;
+      ok = q >= first && (reinterpret_cast<uintptr_t>(q) & 15) == 0 && at >= span;
+      span = at + ((n + align - 1) & ~(align - 1));
+    }
+    if (ok) ok = span <= total + total / 16 + 64;
+    // (the last cut's padding up to its 16-byte boundary is part of the upload: it must lie inside the registered range too)
+    if (ok && pinned_base_of(first, (size_t)span * in_item, plan->device)) {
+      j->direct = true;
+      for (int64_t b = 0; b < batch; ++b) j->off[(size_t)b] = (static_cast<const char*>(h_items[b]) - first) / (int64_t)in_item;
+      total = span;
+    }
   }
   j->total = total;
   if (zero_pad_batch) j->padded.assign((size_t)batch, max_len);
@@ -439,6 +487,46 @@ extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_release(hipfeat_host
   p->outs[(size_t)it->second->out].ticket = -1;
   p->jobs.erase(it);
   return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_host_register(int32_t device, void* ptr, int64_t bytes) {
+  if (!ptr || bytes <= 0) return fail(HIPFEAT_ERR_INVALID, "host register: NULL pointer / %lld bytes", (long long)bytes);
+  DeviceGuard g(device);
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    if (g_pinned.count(static_cast<const char*>(ptr))) return fail(HIPFEAT_ERR_INVALID, "host register: %p is registered already", ptr);
+  }
+  const hipError_t e = hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(HIPFEAT_ERR_HIP, "hipHostRegister(%p, %lld bytes) failed: %s", ptr, (long long)bytes, hipGetErrorName(e));
+  }
+  std::lock_guard<std::mutex> lk(g_pinned_mu);
+  g_pinned[static_cast<const char*>(ptr)] = PinnedRange{(size_t)bytes, (int)device};
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API hipfeat_status hipfeat_host_unregister(void* ptr) {
+  int device = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    auto it = g_pinned.find(static_cast<const char*>(ptr));
+    if (it == g_pinned.end()) return fail(HIPFEAT_ERR_INVALID, "host unregister: %p is not registered", ptr);
+    device = it->second.device;
+    g_pinned.erase(it);  // (first: no later submit takes the direct route out of it)
+  }
+  DeviceGuard g(device);
+  (void)hipDeviceSynchronize();  // (teardown path: whatever the device still reads out of this memory finishes first)
+  const hipError_t e = hipHostUnregister(ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(HIPFEAT_ERR_HIP, "hipHostUnregister(%p) failed: %s", ptr, hipGetErrorName(e));
+  }
+  return HIPFEAT_OK;
+}
+
+extern "C" HIPFEAT_API int64_t hipfeat_host_pipeline_direct_batches(const hipfeat_host_pipeline* p) {
+  return p ? p->n_direct.load(std::memory_order_relaxed) : -1;
 }
 
 extern "C" HIPFEAT_API hipfeat_status hipfeat_host_pipeline_stats(const hipfeat_host_pipeline* p, int64_t* h_stats) {

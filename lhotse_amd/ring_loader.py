@@ -124,6 +124,35 @@ class RingLoader:
             p.start()
         self._closed = self._broken = False
         self._lock = threading.Lock()
+        self._pin = None  # (lib, device index, queue of slots to page-lock, thread, {slot: registered?})
+
+    # -- page-locking the ring for the GPU ----------------------------------------------------------------------------------------
+    def pin_for(self, lib, device_index: int) -> None:
+        """From now on every slot is page-locked for DMA by GPU `device_index` (libhipfeat's hipfeat_host_register) the first time a
+        batch is delivered in it -- on a background thread, so that batch itself still takes the library's staging copy; from its second
+        use on, the host pipeline uploads the slot's cuts straight out of the ring (no packing threads, no second copy of the audio).
+        Call it once the GPU is in use (not before the workers are forked: ring_loader's own rule).  A refused registration (locked-memory
+        limits) is remembered and the slot stays on the staging route."""
+        if self._pin is not None or self._closed:
+            return
+        todo: "queue.SimpleQueue[Optional[int]]" = queue.SimpleQueue()
+        state: Dict[int, bool] = {}
+        base = self._ring.ctypes.data
+
+        def work():
+            while True:
+                slot = todo.get()
+                if slot is None:
+                    return
+                st = lib.raw("hipfeat_host_register", int(device_index), base + slot * self.slot_bytes, self.slot_bytes)
+                state[slot] = st == 0
+
+        th = threading.Thread(target=work, name="ring-pin", daemon=True)
+        self._pin = (lib, int(device_index), todo, th, state)
+        th.start()
+
+    def pinned_slots(self) -> int:
+        return 0 if self._pin is None else sum(1 for ok in self._pin[4].values() if ok)
 
     def _give_back(self, slot: int) -> None:
         with self._freed:
@@ -165,6 +194,9 @@ class RingLoader:
                 return
             if delivered in done:
                 slot, used, meta = done.pop(delivered)
+                if self._pin is not None and slot not in self._pin[4]:
+                    self._pin[4][slot] = False  # (asked for; True once the pin thread has it registered)
+                    self._pin[2].put(slot)
                 yield RingBatch(self, delivered, slot, self._ring[slot * self.slot_bytes : slot * self.slot_bytes + used], meta, asked.pop(delivered))
                 delivered += 1
                 continue
@@ -201,6 +233,15 @@ class RingLoader:
             p.join(timeout=5)
             if p.is_alive():
                 p.terminate()
+        if self._pin is not None:  # (the caller has collected every batch it submitted out of this ring: nothing reads it any more)
+            lib, _, todo, th, state = self._pin
+            todo.put(None)
+            th.join(timeout=30)
+            base = self._ring.ctypes.data
+            for slot, ok in state.items():
+                if ok:
+                    lib.raw("hipfeat_host_unregister", base + slot * self.slot_bytes)
+            self._pin = None
         self._ring = None
         try:
             self._shm.close()

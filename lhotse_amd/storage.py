@@ -645,6 +645,16 @@ class _HostFeatures:
         self._array = None
 
 
+def _pin_ring(ring, extractor) -> None:
+    """Once the extractor has its plan on a GPU: have the ring's slots page-locked for that GPU as they come into use, so that the
+    library's host pipeline uploads straight out of them (``RingLoader.pin_for``; ``HIPFEAT_RING_PIN=0`` keeps the staging copy)."""
+    if ring._pin is not None or os.environ.get("HIPFEAT_RING_PIN", "1") == "0":
+        return
+    plan = getattr(extractor, "_plan", None) or getattr(extractor, "plan", None)
+    if getattr(plan, "handle", None) and getattr(plan, "device", None) is not None and plan.device.type == "cuda":
+        ring.pin_for(plan.lib, plan.device.index or 0)
+
+
 class _SlotPending:
     """A pending feature matrix whose input lives in a slot of the ring loader: the slot goes back to the ring when the result is there
     (the library packs a batch on its pipeline thread -- a finished result is the proof that the caller's buffers are no longer read)."""
@@ -938,6 +948,7 @@ def compute_and_store_features_batch(
                         flat = rb.data.view(np.float32)
                         waves = [flat[o : o + n] for o, n in zip(meta["offs"].tolist(), meta["lens"].tolist())]
                     pending, frames = _batch_features_pending(extractor, waves, sr, None, half=np_dtype == "<f2")
+                    _pin_ring(ring, extractor)
                     return archive, batch_cuts, _SlotPending(pending, rb), frames, template_of(pending, sr), meta["frags"]
 
             def save(archive, batch_cuts, pending, frames: List[int], template: Dict, frags):

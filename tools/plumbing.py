@@ -210,6 +210,100 @@ def cpu_per_cut(cuts: List[Cut], out_dir: str, num_jobs: int) -> Dict:
             "per_process_cuts_per_s": round(n / wall / num_jobs, 1), "errors": [o[1] for o in outs if isinstance(o[1], str)] or None}
 
 
+def _cgroup_cpu() -> Optional[Dict]:
+    """usage / user / system microseconds and throttled periods of this container's cgroup (v2), or None."""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            d = dict(ln.split() for ln in f)
+        return {k: int(d[k]) for k in ("usage_usec", "user_usec", "system_usec", "nr_periods", "nr_throttled", "throttled_usec") if k in d}
+    except OSError:
+        return None
+
+
+def cpu_quota() -> Optional[float]:
+    """CPUs this container may use per period (cgroup v2 cpu.max), None = unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        return None
+
+
+def _thread_cpu(pids=()) -> Dict[str, float]:
+    """CPU seconds (user + system) by thread name: this process's threads (libhipfeat names its own: hipfeat-pipe / -pack / -stripe; the
+    interpreter's threads and the HIP runtime's all read "python...") and, as "loader workers", the processes `pids`."""
+    tick = os.sysconf("SC_CLK_TCK")
+    out: Dict[str, float] = {}
+
+    def add(name, path):
+        try:
+            with open(path) as f:
+                st = f.read()
+            rest = st[st.rindex(")") + 2 :].split()
+            out[name] = out.get(name, 0.0) + (int(rest[11]) + int(rest[12])) / tick
+        except (OSError, ValueError, IndexError):
+            pass
+
+    try:
+        for t in os.listdir("/proc/self/task"):
+            try:
+                with open(f"/proc/self/task/{t}/comm") as f:
+                    name = f.read().strip()
+            except OSError:
+                continue
+            add("main thread" if int(t) == os.getpid() else name, f"/proc/self/task/{t}/stat")
+    except OSError:
+        pass
+    for pid in pids:
+        add("loader workers", f"/proc/{pid}/stat")
+    return out
+
+
+class _Accounting:
+    """CPU of the whole container, of this process's threads by name and of the loader's workers, and the library's pipeline thread's own
+    clock, over the steady region of a leg (from the first batch to the end)."""
+
+    def __init__(self, ex, pids=()):
+        self.ex, self.c0, self.p0, self.t0, self.pids, self.th0 = ex, None, None, None, list(pids), None
+
+    def _pipe(self):
+        try:
+            return self.ex._native_pipe().stats() if getattr(getattr(self.ex, "plan", None), "handle", None) else None
+        except Exception:  # noqa: BLE001
+            return None
+
+    def first_batch(self):
+        if self.t0 is None:
+            self.t0, self.c0, self.p0, self.th0 = time.perf_counter(), _cgroup_cpu(), self._pipe(), _thread_cpu(self.pids)
+
+    def stop(self):
+        """End of the steady region -- BEFORE the loader's workers and the archive's writer threads are torn down."""
+        if self.t0 is not None:
+            self.end = (time.perf_counter(), _cgroup_cpu(), self._pipe(), _thread_cpu(self.pids))
+
+    def result(self) -> Dict:
+        out: Dict = {}
+        if self.t0 is None:
+            return out
+        if getattr(self, "end", None) is None:
+            self.stop()
+        t1, c1, p1, th1 = self.end
+        dt = max(t1 - self.t0, 1e-9)
+        out["cpus_busy_by_thread_name"] = {k: round((v - (self.th0 or {}).get(k, 0.0)) / dt, 2) for k, v in sorted(th1.items()) if v - (self.th0 or {}).get(k, 0.0) > 0.005 * dt}
+        if self.c0 and c1:
+            out["container_cpus_busy"] = round((c1["usage_usec"] - self.c0["usage_usec"]) * 1e-6 / dt, 2)
+            out["container_cpus_busy_user_system"] = [round((c1[k] - self.c0[k]) * 1e-6 / dt, 2) for k in ("user_usec", "system_usec")]
+            out["container_cpu_quota"] = cpu_quota()
+            out["quota_periods_throttled"] = [c1["nr_throttled"] - self.c0["nr_throttled"], c1["nr_periods"] - self.c0["nr_periods"]]
+        if p1:
+            q0 = self.p0 or {"busy_s": 0.0, "pack_s": 0.0, "device_backpressure_s": 0.0}
+            out["pipeline_thread_busy_share"] = round((p1["busy_s"] - q0["busy_s"]) / dt, 3)
+            out["pipeline_thread_packing_share"] = round((p1["pack_s"] - q0["pack_s"]) / dt, 3)
+            out["pipeline_thread_waiting_for_pcie_or_device_share"] = round((p1["device_backpressure_s"] - q0["device_backpressure_s"]) / dt, 3)
+        return out
+
+
+
 # ----------------------------------------------------------------------------------------------------------------------------------
 # loader side of legs B / C (DataLoader worker processes)
 # ----------------------------------------------------------------------------------------------------------------------------------
@@ -345,6 +439,7 @@ def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
     stats: Dict = {}
     t_load = [0.0]
     t_first = [None]
+    acct = _Accounting(ex)
 
     def timed_batches(loader):
         it = iter(loader)
@@ -359,6 +454,7 @@ def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
             if t_first[0] is None:
                 t_first[0] = tb - t0
             yield b
+            acct.first_batch()  # (behind the first batch's extraction: the plan and its pipeline exist)
 
     t0 = time.perf_counter()
     with gzip.open(os.path.join(out_dir, "cuts.jsonl.gz"), "wb") as manifest, \
@@ -395,6 +491,7 @@ def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
 
         S.pump_batches(timed_batches(_loader(DecodeDataset(cuts, pcm16=pcm16, template=template, frame_shift=ex.frame_shift, packed=packed), batches, num_workers, context)),
                        extract, save, stats=stats, finish=lines)
+        acct.stop()
         paths = [str(p) for p in ar.paths]
     wall = time.perf_counter() - t0
     steady = (len(cuts) - len(batches[0])) / max(wall - (t_first[0] or 0.0), 1e-9)
@@ -406,7 +503,7 @@ def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
             "storage": storage, "stripes": stripes, "main_thread_waiting_for_the_loader_share": round(t_load[0] / wall, 3),
             "main_thread_submit_share": round(stats.get("extract_s", 0.0) / wall, 3), "main_thread_blocked_on_the_save_threads_share": round(stats.get("wait_s", 0.0) / wall, 3),
             "archive_thread_busy_share": round(busy["save"] / wall, 3), "archive_thread_waiting_for_the_device_share": round(busy["wait"] / wall, 3),
-            "manifest_thread_busy_share": round(busy["lines"] / wall, 3), "archive_paths": paths, "manifest": os.path.join(out_dir, "cuts.jsonl.gz")}
+            "manifest_thread_busy_share": round(busy["lines"] / wall, 3), **acct.result(), "archive_paths": paths, "manifest": os.path.join(out_dir, "cuts.jsonl.gz")}
 
 
 class DecodeIntoSlot:
@@ -430,7 +527,8 @@ class DecodeIntoSlot:
         return used, {"offs": offs, "lens": lens, "frags": frags}
 
 
-def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = False, half: bool = False, stripes: int = 8, context: Optional[str] = None) -> Dict:
+def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = False, half: bool = False, stripes: int = 8, context: Optional[str] = None,
+             pin: bool = True) -> Dict:
     """Leg D: leg C with the ring loader (lhotse_amd/ring_loader.py) in place of the DataLoader -- workers decode into slots of ONE shared
     ring, the main process hands views of a slot to the host pipeline and frees the slot once the library has packed the batch."""
     from lhotse_amd import storage as S
@@ -445,8 +543,10 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
     stats: Dict = {}
     t_load = [0.0]
     t_first = [None]
+    acct = _Accounting(ex)
     t0 = time.perf_counter()
     loader = RingLoader(DecodeIntoSlot(cuts, pcm16, template, ex.frame_shift), num_workers, slot_bytes=60 * (SAMPLES + 8) * item, start_method=context)
+    acct.pids = [p.pid for p in loader._procs]
 
     def timed(it):
         while True:
@@ -460,6 +560,7 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
             if t_first[0] is None:
                 t_first[0] = tb - t0
             yield b
+            acct.first_batch()
 
     try:
         with gzip.open(os.path.join(out_dir, "cuts.jsonl.gz"), "wb") as manifest, \
@@ -469,6 +570,8 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
                 flat = rb.data.view(np.int16 if pcm16 else np.float32)
                 waves = [flat[o : o + n] for o, n in zip(rb.meta["offs"].tolist(), rb.meta["lens"].tolist())]
                 pending, frames = S._batch_features_pending(ex, waves, SR, None, half=half)
+                if pin:
+                    S._pin_ring(loader, ex)  # (slots are page-locked for the GPU as they come into use: uploads straight out of the ring)
                 return rb, pending, frames
 
             def save(rb, pending, frames):
@@ -494,6 +597,12 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
                 busy["lines"] += time.perf_counter() - ta
 
             S.pump_batches(timed(loader.batches(batches)), extract, save, stats=stats, finish=lines)
+            acct.stop()
+            pinned = loader.pinned_slots()
+            try:
+                direct = int(ex.plan.lib.raw("hipfeat_host_pipeline_direct_batches", ex._native_pipe().handle)) if getattr(ex.plan, "handle", None) else None
+            except Exception:  # noqa: BLE001
+                direct = None
             paths = [str(p) for p in ar.paths]
     finally:
         loader.close()
@@ -503,11 +612,12 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
     return {"steady_region_epoch": [round(now - wall + (t_first[0] or 0.0), 3), round(now, 3)], "steady_cuts": len(cuts) - len(batches[0]),
             "cuts_per_s": round(steady, 1), "cuts_per_s_incl_worker_start": round(len(cuts) / wall, 1), "seconds_to_first_batch": round(t_first[0] or 0.0, 3),
             "cuts": len(cuts), "seconds": round(wall, 3), "num_workers": num_workers, "input": "int16" if pcm16 else "float32",
-            "transport": f"shared ring of {loader.num_slots} slots", "worker_start": loader.start_method, "storage": storage, "stripes": stripes,
+            "transport": f"shared ring of {loader.num_slots} slots", "ring_slots_page_locked": pinned, "batches_uploaded_straight_from_the_ring": direct,
+            "batches": len(batches), "worker_start": loader.start_method, "storage": storage, "stripes": stripes,
             "main_thread_waiting_for_the_loader_share": round(t_load[0] / wall, 3), "main_thread_submit_share": round(stats.get("extract_s", 0.0) / wall, 3),
             "main_thread_blocked_on_the_save_threads_share": round(stats.get("wait_s", 0.0) / wall, 3), "archive_thread_busy_share": round(busy["save"] / wall, 3),
             "archive_thread_waiting_for_the_device_share": round(busy["wait"] / wall, 3), "manifest_thread_busy_share": round(busy["lines"] / wall, 3),
-            "archive_paths": paths, "manifest": os.path.join(out_dir, "cuts.jsonl.gz")}
+            **acct.result(), "archive_paths": paths, "manifest": os.path.join(out_dir, "cuts.jsonl.gz")}
 
 
 def read_back(result: Dict, index: int) -> np.ndarray:
@@ -545,6 +655,7 @@ def main() -> None:
     ap.add_argument("--half", action="store_true")
     ap.add_argument("--stripes", type=int, default=8)
     ap.add_argument("--per-cut-transport", action="store_true")
+    ap.add_argument("--no-pin", action="store_true", help="leg D: keep the library's staging copy (do not page-lock the ring's slots)")
     ap.add_argument("--context", default=None)
     ap.add_argument("--gpu-first", action="store_true", help="touch the GPU BEFORE the workers are forked (the hazardous order)")
     ap.add_argument("--passes", type=int, default=2)
@@ -571,7 +682,7 @@ def main() -> None:
             if a.leg == "B":
                 r = hip_batch_numpy_files(ex, cuts, d, a.workers, context=a.context)
             elif a.leg == "D":
-                r = hip_ring(ex, cuts, d, a.workers, pcm16=a.pcm16, half=a.half, stripes=a.stripes, context=a.context)
+                r = hip_ring(ex, cuts, d, a.workers, pcm16=a.pcm16, half=a.half, stripes=a.stripes, context=a.context, pin=not a.no_pin)
             else:
                 r = hip_bulk(ex, cuts, d, a.workers, pcm16=a.pcm16, half=a.half, stripes=a.stripes, packed=not a.per_cut_transport, context=a.context)
             r.pop("archive_paths", None), r.pop("manifest", None)

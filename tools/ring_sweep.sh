@@ -10,28 +10,28 @@ PY
 stat() { grep -E "usage_usec|user_usec|system_usec|nr_throttled|throttled_usec" /sys/fs/cgroup/cpu.stat 2>/dev/null | tr '\n' ' '; }
 one() {  # leg workers extra...
   local leg=$1 w=$2; shift 2
-  HIPFEAT_NO_FORK_WARNING=1 python tools/plumbing.py --leg $leg --wav-dir /dev/shm/ring_wav --repeat 400 --workers $w --passes 1 "$@" 2>/dev/null | python -c "
+  HIPFEAT_NO_FORK_WARNING=1 python tools/plumbing.py --leg $leg --wav-dir /dev/shm/ring_wav --repeat 1000 --workers $w --passes 1 "$@" 2>/dev/null | python -c "
 import sys,json
-r=json.loads(sys.stdin.readline()); print('leg $leg workers $w $*', r['cuts_per_s'], r['seconds_to_first_batch'], {k:v for k,v in r.items() if k.endswith('share')})"
+r=json.loads(sys.stdin.readline()); print('leg $leg workers $w $*', r['cuts_per_s'], r['seconds_to_first_batch'], {k:v for k,v in r.items() if k.endswith('share') or k.startswith(('container','quota','cpus','ring_slots','batches'))})"
 }
 {
 echo "cpu.max: $(cat /sys/fs/cgroup/cpu.max)"
 for rep in 1 2; do
-  for w in 6 8 10 12 16; do
+  for w in 6 8 12; do
     for extra in "" "--pcm16 --half"; do
-      echo "before: $(stat)"; one D $w $extra; echo "after:  $(stat)"
+      one D $w $extra; one D $w $extra --no-pin
     done
   done
   one C 8; one C 8 --pcm16 --half
 done
 } 2>&1 | tee $OUT/ab.txt
 # several processes sharing the GPU, leg D each (own plan, pipeline, archive, ring), started together
-for cfg in "2 6" "3 4" "4 3" "2 8"; do
+for cfg in "2 6" "4 3"; do
   set -- $cfg; procs=$1; w=$2
   for extra in "" "--pcm16 --half"; do
     at=$(python -c "import time; print(time.time()+12)")
     for k in $(seq 1 $procs); do
-      HIPFEAT_NO_FORK_WARNING=1 python tools/plumbing.py --leg D --wav-dir /dev/shm/ring_wav --repeat 400 --workers $w --passes 1 --start-at $at $extra 2>/dev/null > $OUT/mp_${procs}x${w}_$k.json &
+      HIPFEAT_NO_FORK_WARNING=1 python tools/plumbing.py --leg D --wav-dir /dev/shm/ring_wav --repeat 1000 --workers $w --passes 1 --start-at $at $extra 2>/dev/null > $OUT/mp_${procs}x${w}_$k.json &
     done
     wait
     python - $OUT $procs $w "$extra" <<'PY'
