@@ -110,7 +110,9 @@ def cpu_baseline(seconds: float = 12.0, procs: int = 0, mode: str = "", what: st
     import subprocess
 
     ncpu = os.cpu_count() or 1
-    sweep = [procs] if procs else sorted({max(1, min(ncpu, n)) for n in (ncpu // 8, ncpu // 4, ncpu // 2)})
+    quota = cpu_quota()  # the container's cgroup CPU quota (the MI355X boxes of round 6: 16 CPUs' worth on a 256-thread host)
+    counts = (ncpu // 8, ncpu // 4, ncpu // 2) if quota is None else (int(quota), int(1.5 * quota), int(2 * quota), ncpu // 8)
+    sweep = [procs] if procs else sorted({max(1, min(ncpu, n)) for n in counts})
     per = max(4.0, seconds / len(sweep))
     runs = []
     for n in sweep:
@@ -128,10 +130,12 @@ def cpu_baseline(seconds: float = 12.0, procs: int = 0, mode: str = "", what: st
         "audio_seconds_per_s": best["audio_seconds_per_s"],
         "cpu_model": cpu_model(),
         "logical_cores": ncpu,
+        "container_cpu_quota": quota,
         "sweep": runs,
         "sample": f"{best['cuts']} cuts in {best['seconds']:.0f} s wall: {best['processes']} single-threaded processes of the reference's torch CPU {what} "
         f"call sequence (oracle/kaldi_torch.py, pinned to the reference's outputs on the goldens; {best['cuts_per_s'] / best['processes']:.0f} cuts/s per process), "
-        f"best of a sweep over {[r['processes'] for r in runs]} processes; host has {ncpu} logical cores ({cpu_model()})",
+        f"best of a sweep over {[r['processes'] for r in runs]} processes; host has {ncpu} logical cores ({cpu_model()})"
+        + ("" if quota is None else f", of which this container may use {quota:g} CPUs' worth of time (cgroup cpu.max)"),
     }
     if not mode:  # baseline A: batched, default intra-op threads
         worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
@@ -144,6 +148,16 @@ def cpu_baseline(seconds: float = 12.0, procs: int = 0, mode: str = "", what: st
         except Exception as e:  # the line must still be printed
             out["batched"] = {"value": None, "error": repr(e)}
     return out
+
+
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max), None = unlimited / unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        return None
 
 
 def kernel_source_hash(files) -> str:
@@ -945,15 +959,16 @@ class BulkSave:
 class Plumbing:
     """BASELINE configs[0] / SURVEY 8d baseline C on the GPU box: 64 int16 WAV files on tmpfs -> decoding DataLoader worker processes ->
     features -> storage + gzip JSONL manifest (tools/plumbing.py, which cites the lhotse driver each leg keeps the structure of).  A step =
-    ONE pass of the product's bulk driver (leg C) over `repeat` x 64 cuts; `extra` carries leg B (lhotse's batch-driver structure with
-    lhotse's own per-cut .npy save path around HipFbank) and, as `cpu_baseline`, leg A (the reference's per-cut CPU driver restated:
-    num_jobs = 1 and num_jobs = cores/4).  lhotse itself cannot run here (not installed on the box; a Python reference cannot travel):
+    ONE pass of the product's bulk driver over `repeat` x 64 cuts with the product's default loader, the shared-memory ring (leg D);
+    `extra` carries leg C (the same driver behind a torch DataLoader), leg B (lhotse's batch-driver structure with lhotse's own per-cut
+    .npy save path around HipFbank), several processes sharing the GPU and, as `cpu_baseline`, leg A (the reference's per-cut CPU
+    driver restated: num_jobs = 1 and num_jobs = the container's CPU quota).  lhotse itself cannot run here (not installed on the box; a Python reference cannot travel):
     the REAL drivers are timed next to legs A in the authoring container, profiles/r06_plumbing_container.json."""
 
     name = "plumbing"
     host_bound = True
     metric = "cuts/sec (64 x 10 s 16 kHz int16 WAV files on tmpfs -> decode -> 80-dim log-mel fbank -> storage + manifest; decode-, PCIe- and host-inclusive)"
-    default_cuts = 100  # passes over the 64 files per step (6400 cuts)
+    default_cuts = 400  # passes over the 64 files per step (25 600 cuts: ~1 s at the ring loader's rate)
     cpu_mode, cpu_what = "", "Fbank"
 
     def __init__(self, dev, rank, args):
@@ -985,10 +1000,12 @@ class Plumbing:
         self.settle = 0
         self._run = 0
         self.last = None
+        self.quota = cpu_quota()
         self.workload = (f"BASELINE configs[0] with the GPU in it: 64 x 10 s 16 kHz mono int16 WAV files on {self.fs}, visited {self.repeat} x per step "
-                         f"({self.units} cuts, 600 s batches) -> {self.workers} DataLoader worker processes decode (stdlib wave, int16 / 32768) and serialise the manifest "
-                         f"line halves -> hipfeat_host_pipeline -> hip_archive striped over {self.stripes} file(s) + gzip JSONL manifest flushed per batch "
-                         "(the product's bulk driver; lhotse's own drivers cannot run on this box, see extra.plumbing.what)")
+                         f"({self.units} cuts, 600 s batches) -> {self.workers} loader worker processes decode (stdlib wave, int16 / 32768) straight into the slots of "
+                         "one shared-memory ring and serialise the manifest line halves -> hipfeat_host_pipeline uploads out of the (page-locked) slots -> "
+                         f"hip_archive striped over {self.stripes} file(s) + gzip JSONL manifest flushed per batch (the product's bulk driver with its default loader; "
+                         f"lhotse's own drivers cannot run on this box, see extra.plumbing.what); container CPU quota: {self.quota} of {os.cpu_count()} logical CPUs")
 
     def _dir(self, tag):
         self._run += 1
@@ -1001,7 +1018,7 @@ class Plumbing:
         # this process holds a live HIP context: workers FORKED off it would slow every device round trip by ~30 ms while they live
         # (lhotse_amd/_lib.py, profiles/r06_loader_pipeline_probe.txt) -- the product's driver starts them through a fork server in that
         # situation, and so does this step
-        self.last = self.P.hip_bulk(self.ex, self.cuts, self._dir("bulk"), self.workers, stripes=self.stripes, context="forkserver")
+        self.last = self.P.hip_ring(self.ex, self.cuts, self._dir("ring"), self.workers, stripes=self.stripes, context="forkserver")
         if prev:
             shutil.rmtree(os.path.dirname(prev["manifest"]), ignore_errors=True)
 
@@ -1035,21 +1052,21 @@ class Plumbing:
             return {"error": (p.stderr or p.stdout)[-600:]}
         return rows
 
-    def _shared_gpu(self, procs: int, workers: int):
-        """Leg C in `procs` FRESH processes that share this GPU (each with its own plan, pipeline, archive and `workers` loader workers),
+    def _shared_gpu(self, procs: int, workers: int, leg: str = "D", flags=(), label: str = "float32 -> hip_archive"):
+        """Leg `leg` in `procs` FRESH processes that share this GPU (each with its own plan, pipeline, archive and `workers` loader workers),
         started together: what one GPU takes when the loader-bound driver is run as several processes -- the sharded driver accepts any
         number of ranks per device.  Aggregate = cuts of all processes behind their first batches / the span of their steady regions."""
         import subprocess
 
         start = time.time() + 12.0  # (imports and plan creation of all processes are over by then)
-        cmd = [sys.executable, os.path.join(ROOT, "tools", "plumbing.py"), "--leg", "C", "--wav-dir", os.path.dirname(self.paths[0]), "--repeat", str(self.repeat),
-               "--stripes", str(self.stripes), "--workers", str(workers), "--passes", "1", "--start-at", str(start)]
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "plumbing.py"), "--leg", leg, "--wav-dir", os.path.dirname(self.paths[0]), "--repeat", str(self.repeat),
+               "--stripes", str(self.stripes), "--workers", str(workers), "--passes", "1", "--start-at", str(start), *flags]
         ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIPFEAT_NO_FORK_WARNING="1")) for _ in range(procs)]
         rows = []
         for p in ps:
             o, _ = p.communicate(timeout=900)
             rows += [json.loads(ln) for ln in o.splitlines() if ln.startswith("{")]
-        key = f"C hip_bulk float32 -> hip_archive, {procs} PROCESSES sharing the GPU x {workers} loader workers each"
+        key = f"{leg} {'hip_ring' if leg == 'D' else 'hip_bulk'} {label}, {procs} PROCESSES sharing the GPU x {workers} loader workers each"
         if len(rows) != procs:
             return {key: {"error": f"{len(rows)} of {procs} processes answered"}}
         t0, t1 = min(r["steady_region_epoch"][0] for r in rows), max(r["steady_region_epoch"][1] for r in rows)
@@ -1060,7 +1077,9 @@ class Plumbing:
         import shutil
 
         P, out = self.P, {}
-        keep = ("cuts_per_s", "cuts_per_s_incl_worker_start", "seconds_to_first_batch", "cuts", "num_workers", "worker_start", "transport", "input", "storage")
+        keep = ("cuts_per_s", "cuts_per_s_incl_worker_start", "seconds_to_first_batch", "cuts", "num_workers", "worker_start", "transport", "input", "storage",
+                "ring_slots_page_locked", "batches_uploaded_straight_from_the_ring", "batches", "cpus_busy_by_thread_name", "container_cpus_busy",
+                "container_cpus_busy_user_system", "container_cpu_quota", "quota_periods_throttled")
 
         def brief(rows, k=0):
             if isinstance(rows, dict):
@@ -1069,27 +1088,34 @@ class Plumbing:
             return {**{a: r[a] for a in keep if a in r}, **{a: v for a, v in r.items() if a.endswith("_share")}}
 
         W = self.workers
-        small = max(4, self.repeat // 4)
+        small = max(4, self.repeat // 8)   # (legs that move 1-6 k cuts/s)
         # fresh processes, workers forked before the GPU is touched (pass 0 of each) -----------------------------------------------------
         for wk in sorted({4, W} if full else {W}):
             out[f"B hip_batch_numpy_files, {wk} loader workers"] = brief(self._fresh("--leg", "B", "--workers", wk, "--passes", 1, repeat=small))
-        out[f"C hip_bulk float32 -> hip_archive, {W} loader workers"] = brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1))
+        out[f"C hip_bulk float32 -> hip_archive, {W} loader workers (torch DataLoader, one packed tensor per batch)"] = \
+            brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, repeat=max(4, self.repeat // 4)))
+        out[f"D hip_ring float32 -> hip_archive, {W} loader workers (shared-memory ring, slots page-locked for the GPU)"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1))
+        out[f"D hip_ring int16 -> hip_archive_f16, {W} loader workers"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--pcm16", "--half"))
+        half_w = max(2, W * 3 // 4)
+        out.update(self._shared_gpu(2, half_w, "D"))
         if full:
-            out[f"C hip_bulk int16 -> hip_archive_f16, {W} loader workers"] = brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--pcm16", "--half"))
-            out["C hip_bulk float32 -> hip_archive, 4 loader workers"] = brief(self._fresh("--leg", "C", "--workers", 4, "--passes", 1, repeat=small))
+            out.update(self._shared_gpu(2, half_w, "D", ("--pcm16", "--half"), "int16 -> hip_archive_f16"))
+            out[f"D hip_ring float32 -> hip_archive, {W} loader workers, staging copy kept (slots not page-locked)"] = \
+                brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--no-pin"))
+            out[f"D hip_ring float32 -> hip_archive, {W} loader workers, fork server, GPU touched before"] = \
+                brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--gpu-first", "--context", "forkserver"))
+            out[f"C hip_bulk int16 -> hip_archive_f16, {W} loader workers"] = brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--pcm16", "--half", repeat=max(4, self.repeat // 4)))
             out[f"C hip_bulk float32 -> hip_archive, {W} loader workers, one array per cut through the worker queue (lhotse's transport)"] = \
                 brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--per-cut-transport", repeat=small))
-        # the hazard: the same leg with the GPU touched BEFORE the workers are forked, and its remedy (fork server) -------------------------
-        out[f"C hip_bulk float32 -> hip_archive, {W} loader workers, FORKED AFTER the GPU was touched"] = \
-            brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--gpu-first", repeat=small))
-        if full:
+            # the hazard: the same leg with the GPU touched BEFORE the workers are forked, and its remedy (fork server) ---------------------
+            out[f"C hip_bulk float32 -> hip_archive, {W} loader workers, FORKED AFTER the GPU was touched"] = \
+                brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--gpu-first", repeat=small))
             out[f"C hip_bulk float32 -> hip_archive, {W} loader workers, fork server, GPU touched before"] = \
-                brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--gpu-first", "--context", "forkserver"))
-        if full:
-            out.update(self._shared_gpu(4, 8))
+                brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--gpu-first", "--context", "forkserver", repeat=max(4, self.repeat // 4)))
+            out.update(self._shared_gpu(4, max(2, W // 2), "D"))
         if not args.no_cpu_baseline:
             ncpu = len(os.sched_getaffinity(0))
-            for jobs in sorted({1, max(1, min(64, ncpu // 4))}):
+            for jobs in sorted({1, max(1, min(64, ncpu // 4 if self.quota is None else int(self.quota)))}):
                 n = 64 * (2 if jobs == 1 else max(2, min(40, jobs)))
                 d = self._dir("a")
                 out[f"A cpu_per_cut (compute_and_store_features(Fbank(), NumpyFilesWriter, num_jobs={jobs}) restated; kind = port)"] = P.cpu_per_cut(P.make_cuts(self.paths, n // 64), d, jobs)
@@ -1098,9 +1124,12 @@ class Plumbing:
                        "shares are of wall time.  A = the reference's per-cut CPU driver restated with the reference's torch call sequence as the extractor "
                        "(oracle/kaldi_torch.py: the checker / baseline, never the product path); B = the structure of CutSet.compute_and_store_features_batch "
                        "(lhotse/cut/set.py:2296-2408) around HipFbank with lhotse's own save path (one .npy per cut, one json.dumps + flush per cut on ONE save "
-                       "thread) and lhotse's transport (one array per cut through the worker queue); C = the product's bulk driver (one packed tensor per batch).  "
-                       "B and C run in FRESH processes (tools/plumbing.py): the GPU is first touched at the first batch, after the workers were forked, as under "
-                       "lhotse's driver.  The two last C legs show the fork hazard (lhotse_amd/_lib.py) and its remedy.  lhotse itself cannot run on this box; "
+                       "thread) and lhotse's transport (one array per cut through the worker queue); C = the product's bulk driver behind a torch DataLoader (one packed "
+                       "tensor per batch); D = the product's bulk driver with its default loader, lhotse_amd/ring_loader.py (workers decode into slots of one shared "
+                       "ring, the slots are page-locked for the GPU as they come into use and the host pipeline uploads straight out of them: ABI v5).  "
+                       "B, C and D run in FRESH processes (tools/plumbing.py): the GPU is first touched at the first batch, after the workers were forked, as under "
+                       "lhotse's driver.  container_cpus_busy / quota_periods_throttled: the whole container's CPU time over the leg against its cgroup quota "
+                       "(the host-bound legs end at that quota, not at the GPU).  The C legs marked so show the fork hazard (lhotse_amd/_lib.py) and its remedy.  lhotse itself cannot run on this box; "
                        "the real drivers are timed next to leg A in the authoring container: profiles/r06_plumbing_container.json")
         return {"plumbing": out}
 
@@ -1535,12 +1564,12 @@ def sub_config(name: str, args, dev, rank: int, dist, cdev, world: int):
 
 
 def sub_plumbing(args, dev, rank: int):
-    """`extra.configs.plumbing`: one warm + two timed passes of the product's bulk driver over 64 WAV files x 50 (leg C), the other legs
+    """`extra.configs.plumbing`: one warm + two timed passes of the product's bulk driver over 64 WAV files x 200 (leg D: the ring loader), the other legs
     and the CPU per-cut baseline as its `legs` (tools/plumbing.py) -- BASELINE configs[0] / SURVEY 8d baseline C."""
     import copy
 
     a = copy.copy(args)
-    a.cuts = 50
+    a.cuts = 200
     w = Plumbing(dev, rank, a)
     try:
         w.step()
@@ -1550,7 +1579,9 @@ def sub_plumbing(args, dev, rank: int):
         dt = time.perf_counter() - t0
         out = {"metric": w.metric, "value": round(2 * w.units / dt, 1), "unit": "cuts/s", "steps": 2, "warmup": 1, "ms_per_step": round(dt / 2 * 1e3, 2),
                "workload": w.workload, "cuts_per_step": w.units,
-               "last_pass": {k: v for k, v in w.last.items() if k.endswith("_share") or k in ("cuts_per_s", "cuts_per_s_incl_worker_start", "seconds_to_first_batch", "transport")},
+               "last_pass": {k: v for k, v in w.last.items() if k.endswith("_share") or k in ("cuts_per_s", "cuts_per_s_incl_worker_start", "seconds_to_first_batch", "transport",
+                                                                                                "ring_slots_page_locked", "batches_uploaded_straight_from_the_ring", "batches",
+                                                                                                "cpus_busy_by_thread_name", "container_cpus_busy", "container_cpu_quota", "quota_periods_throttled")},
                "what": "value = whole passes incl. the start of the loader's worker processes (a pass is ~1 s: a corpus-sized run amortises that start); "
                        "last_pass.cuts_per_s = the rate behind the first batch"}
         if not args.no_parity:

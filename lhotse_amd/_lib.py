@@ -304,6 +304,33 @@ def note_plan_created() -> None:
     _PLANS_CREATED += 1
 
 
+def cpu_quota() -> Optional[float]:
+    """CPUs' worth of time this container may use (cgroup v2 ``cpu.max``, v1 ``cfs_quota_us``), or None (unlimited / unknown).  The MI355X
+    boxes of round 6 report 256 schedulable CPUs and a quota of 16: thread / worker counts sized by the affinity mask alone oversubscribe
+    such a host sixteen-fold and are throttled (profiles/r06_host_limits.txt)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        return None if q == "max" else int(q) / int(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def usable_cpus() -> int:
+    """min(CPUs this process may run on, the container's CPU quota), at least 1."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q = cpu_quota()
+    return max(1, n if q is None else min(n, int(q + 0.5)))
+
+
 def hip_live() -> bool:
     """Has this process touched the GPU (a plan of this package, or torch's own context)?"""
     if _PLANS_CREATED:

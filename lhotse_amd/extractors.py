@@ -560,9 +560,10 @@ class NativeHostPipeline:
 
     def __init__(self, plan, copy_threads: Optional[int] = None):
         self.plan, self.lib = plan, plan.lib
-        # copy threads: HIPFEAT_COPY_THREADS, else a quarter of the CPUs this process may run on, 2 ... 12 (profiles/r05_copy_threads.txt)
+        # copy threads: HIPFEAT_COPY_THREADS, else a quarter of the CPUs this process may USE (affinity mask and the container's CPU quota:
+        # _lib.usable_cpus), 2 ... 12 (profiles/r05_copy_threads.txt)
         env = os.environ.get("HIPFEAT_COPY_THREADS")
-        threads = copy_threads or (int(env) if env else max(2, min(12, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)) // 4)))
+        threads = copy_threads or (int(env) if env else max(2, min(12, _lib.usable_cpus() // 4)))
         h = np.zeros(1, dtype=np.uint64)
         self.handle = 0
         self.lib.check("hipfeat_host_pipeline_create", plan.handle, int(threads), _lib.addr(h))

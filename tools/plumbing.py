@@ -633,8 +633,12 @@ def read_back(result: Dict, index: int) -> np.ndarray:
 
 
 def default_workers() -> int:
+    """Loader workers for the GPU legs: half of the CPUs this container may use (affinity mask AND cgroup quota), 2 ... 16."""
     n = len(os.sched_getaffinity(0))
-    return max(2, min(16, n // 4))
+    q = cpu_quota()
+    if q is not None:
+        n = min(n, int(q + 0.5))
+    return max(2, min(16, n // 2))
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
