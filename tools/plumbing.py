@@ -507,23 +507,26 @@ def hip_bulk(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
 
 
 class DecodeIntoSlot:
-    """`load_batch` of lhotse_amd.ring_loader.RingLoader for this corpus: decode the batch's WAV files straight into the ring slot (packed),
-    serialise the manifest-line halves; what travels back is lengths + offsets + the halves."""
+    """`load_batch` of lhotse_amd.ring_loader.RingLoader for this corpus: the batch's cut objects arrive with the task (as lhotse's sampler
+    hands a CutSet per batch to the loader: lhotse_amd.storage.LoadCutsIntoSlot), their WAV files are decoded straight into the ring slot
+    (packed), the manifest-line halves serialised; what travels back is lengths + offsets + the halves."""
 
-    def __init__(self, cuts: List[Cut], pcm16: bool, template: Dict, frame_shift: float):
-        self.ds = DecodeDataset(cuts, pcm16=pcm16, template=template, frame_shift=frame_shift)
+    def __init__(self, pcm16: bool, template: Dict, frame_shift: float):
+        self.pcm16, self.template, self.frame_shift, self._rc = pcm16, template, frame_shift, {}
 
-    def __call__(self, idx: List[int], out: np.ndarray):
+    def __getstate__(self):
+        return {"pcm16": self.pcm16, "template": self.template, "frame_shift": self.frame_shift, "_rc": {}}
+
+    def __call__(self, batch_cuts: List[Cut], out: np.ndarray):
         from lhotse_amd.ring_loader import SlotWriter
         from lhotse_amd.storage import manifest_fragments
 
-        ds = self.ds
         slot = SlotWriter(out)
-        for i in idx:  # (every cut into the slot the moment it is decoded, as lhotse_amd.storage.LoadCutsIntoSlot does)
-            if not slot.add(read_wav(ds.cuts[i].path, ds.pcm16)[0]):
+        for c in batch_cuts:  # (every cut into the slot the moment it is decoded, as lhotse_amd.storage.LoadCutsIntoSlot does)
+            if not slot.add(read_wav(c.path, self.pcm16)[0]):
                 raise ValueError("batch does not fit its ring slot")
         used, offs, lens = slot.finish()
-        frags = [manifest_fragments(ds.cuts[i], ds.template, ds.frame_shift, ds._rc) for i in idx]
+        frags = [manifest_fragments(c, self.template, self.frame_shift, self._rc) for c in batch_cuts]
         return used, {"offs": offs, "lens": lens, "frags": frags}
 
 
@@ -545,7 +548,7 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
     t_first = [None]
     acct = _Accounting(ex)
     t0 = time.perf_counter()
-    loader = RingLoader(DecodeIntoSlot(cuts, pcm16, template, ex.frame_shift), num_workers, slot_bytes=60 * (SAMPLES + 8) * item, start_method=context)
+    loader = RingLoader(DecodeIntoSlot(pcm16, template, ex.frame_shift), num_workers, slot_bytes=60 * (SAMPLES + 8) * item, start_method=context)
     acct.pids = [p.pid for p in loader._procs]
 
     def timed(it):
@@ -596,7 +599,7 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
                 manifest.flush()
                 busy["lines"] += time.perf_counter() - ta
 
-            S.pump_batches(timed(loader.batches(batches)), extract, save, stats=stats, finish=lines)
+            S.pump_batches(timed(loader.batches([cuts[i] for i in idx] for idx in batches)), extract, save, stats=stats, finish=lines)
             acct.stop()
             pinned = loader.pinned_slots()
             try:
