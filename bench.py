@@ -1564,12 +1564,12 @@ def sub_config(name: str, args, dev, rank: int, dist, cdev, world: int):
 
 
 def sub_plumbing(args, dev, rank: int):
-    """`extra.configs.plumbing`: one warm + two timed passes of the product's bulk driver over 64 WAV files x 200 (leg D: the ring loader), the other legs
+    """`extra.configs.plumbing`: one warm + two timed passes of the product's bulk driver over 64 WAV files x 400 (leg D: the ring loader), the other legs
     and the CPU per-cut baseline as its `legs` (tools/plumbing.py) -- BASELINE configs[0] / SURVEY 8d baseline C."""
     import copy
 
     a = copy.copy(args)
-    a.cuts = 200
+    a.cuts = 400
     w = Plumbing(dev, rank, a)
     try:
         w.step()

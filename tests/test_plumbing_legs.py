@@ -6,6 +6,7 @@ import gzip
 import json
 import os
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -102,3 +103,64 @@ def test_ring_loader_leg_and_the_loader_itself(tmp_path, cpu_plan):
         del held
         with pytest.raises(RuntimeError, match="boom"):
             list(rl.batches([(1, 10), (-1, 0), (2, 10)]))
+
+
+def test_slot_writer_and_page_locking_bookkeeping_of_the_ring():
+    """SlotWriter: cuts land on 16-byte boundaries as they are added, a cut of another dtype or one that does not fit is refused without
+    a trace, `arrays()` gives back what was added.  RingLoader.pin_for: every slot is handed to libhipfeat's hipfeat_host_register ONCE,
+    the first time a batch is delivered in it, on a background thread; refused registrations are remembered and not retried; close()
+    unregisters exactly the slots that were registered (a stand-in library records the calls: no GPU here)."""
+    from lhotse_amd.ring_loader import ALIGN, RingLoader, SlotWriter
+
+    out = np.zeros(4096, dtype=np.uint8)
+    w = SlotWriter(out)
+    a, b = np.arange(5, dtype=np.float32), np.arange(7, dtype=np.float32) + 100
+    assert w.add(a) and w.add(b)
+    assert not w.add(np.zeros(3, dtype=np.int16))  # another dtype
+    assert not w.add(np.zeros(2000, dtype=np.float32))  # does not fit
+    used, offs, lens = w.finish()
+    assert offs.tolist() == [0, 8] and lens.tolist() == [5, 7] and used == 64 and used % ALIGN == 0
+    flat = out.view(np.float32)
+    assert np.array_equal(flat[0:5], a) and np.array_equal(flat[8:15], b)
+    back = w.arrays()
+    assert np.array_equal(back[0], a) and np.array_equal(back[1], b) and back[0].base is None
+
+    class Lib:
+        def __init__(self):
+            self.calls, self.refuse = [], set()
+
+        def raw(self, name, *args):
+            self.calls.append((name, *args))
+            if name == "hipfeat_host_register" and args[1] in self.refuse:
+                return 3
+            return 0
+
+    def load(spec, o):
+        s = SlotWriter(o)
+        s.add(np.full(16, spec, dtype=np.float32))
+        used, offs, lens = s.finish()
+        return used, {"offs": offs, "lens": lens}
+
+    lib = Lib()
+    rl = RingLoader(load, num_workers=2, slot_bytes=4096, num_slots=4, start_method="fork")
+    base = rl._ring.ctypes.data
+    lib.refuse.add(base + 1 * rl.slot_bytes)  # slot 1 is refused (e.g. a locked-memory limit)
+    rl.pin_for(lib, 3)
+    rl.pin_for(lib, 3)  # (idempotent)
+    seen = set()
+    for rb in rl.batches(range(30)):
+        assert rb.data.view(np.float32)[0] == rb.index
+        seen.add(rb.slot)
+        rb.release()
+    for _ in range(200):  # the pin thread works behind the deliveries
+        if len(rl._pin[4]) == len(seen) and len([c for c in lib.calls if c[0] == "hipfeat_host_register"]) == len(seen):
+            break
+        time.sleep(0.01)
+    regs = [c for c in lib.calls if c[0] == "hipfeat_host_register"]
+    assert sorted(c[2] for c in regs) == sorted(base + s * rl.slot_bytes for s in seen) and all(c[1] == 3 and c[3] == rl.slot_bytes for c in regs)
+    assert len(regs) == len(set(regs))  # once per slot
+    assert rl.pinned_slots() == len(seen - {1})
+    rl.close()
+    unreg = [c[1] for c in lib.calls if c[0] == "hipfeat_host_unregister"]
+    assert sorted(unreg) == sorted(base + s * rl.slot_bytes for s in seen - {1})
+    rl.close()  # (idempotent)

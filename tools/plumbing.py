@@ -547,6 +547,14 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
     t_load = [0.0]
     t_first = [None]
     acct = _Accounting(ex)
+
+    def direct_batches():
+        try:
+            return int(ex.plan.lib.raw("hipfeat_host_pipeline_direct_batches", ex._native_pipe().handle)) if getattr(getattr(ex, "_plan", None), "handle", None) else 0
+        except Exception:  # noqa: BLE001
+            return 0
+
+    direct0 = direct_batches()
     t0 = time.perf_counter()
     loader = RingLoader(DecodeIntoSlot(pcm16, template, ex.frame_shift), num_workers, slot_bytes=60 * (SAMPLES + 8) * item, start_method=context)
     acct.pids = [p.pid for p in loader._procs]
@@ -602,10 +610,7 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
             S.pump_batches(timed(loader.batches([cuts[i] for i in idx] for idx in batches)), extract, save, stats=stats, finish=lines)
             acct.stop()
             pinned = loader.pinned_slots()
-            try:
-                direct = int(ex.plan.lib.raw("hipfeat_host_pipeline_direct_batches", ex._native_pipe().handle)) if getattr(ex.plan, "handle", None) else None
-            except Exception:  # noqa: BLE001
-                direct = None
+            direct = direct_batches() - direct0
             paths = [str(p) for p in ar.paths]
     finally:
         loader.close()
