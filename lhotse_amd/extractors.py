@@ -616,6 +616,16 @@ class NativeHostPipeline:
             self._outstanding.add(int(res[2]))
         return PendingFeatures(self, int(res[2]), arr, frames, keep)
 
+    def drain(self) -> None:
+        """Block until every batch submitted so far has left the caller's waveforms alone and its result is on the host (results stay
+        outstanding: their owners still ``release()`` them).  A driver calls this before it unmaps memory batches were submitted out of
+        (the ring loader's slots) on a path where not every batch was collected -- an exception half-way through a run."""
+        with self._state:
+            tickets = sorted(self._outstanding)
+        for t in tickets:
+            if self.handle:
+                self._waitf(self.handle, int(t))  # (a failed batch answers with its status: it was drained by the pipeline thread itself)
+
     def stats(self) -> Dict[str, float]:
         """The pipeline thread's own clock since creation: seconds busy / packing / waiting for PCIe + device, batches."""
         a = np.zeros(4, dtype=np.int64)

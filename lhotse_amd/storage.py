@@ -995,6 +995,9 @@ def compute_and_store_features_batch(
                 run(archive, batches, save, finish, np_dtype == "<f2", template_of, extract=extract_ring)
             finally:
                 if ring is not None:
+                    pipe = getattr(extractor, "__dict__", {}).get("_native_pipeline")
+                    if pipe is not None:  # (after an exception batches may still be queued that read the ring's slots: not unmapped under them)
+                        pipe.drain()
                     ring.close()
         return manifest.open_manifest()
 

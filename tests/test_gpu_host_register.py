@@ -123,3 +123,41 @@ def test_ring_loader_with_page_locked_slots_feeds_the_host_pipeline():
             b.release()
         assert rl.pinned_slots() >= 2
         assert _direct(ex) >= 20  # (every slot's first batch went through staging, most of the rest straight out of the ring)
+
+
+class _NoiseThenBoom(_Noise):
+    def __call__(self, spec, out):
+        if spec[0] == 25:
+            raise ValueError("boom")
+        return super().__call__(spec, out)
+
+
+def test_a_failed_run_drains_the_pipeline_before_the_page_locked_ring_is_unmapped():
+    """A worker fails half-way through: batches submitted out of page-locked slots are still queued / in flight when the consumer gives up.
+    NativeHostPipeline.drain() (what the product's driver calls before RingLoader.close()) waits for them, the slots are unregistered
+    and unmapped afterwards, and the extractor works on."""
+    specs = [(s, [16000, 24000]) for s in range(40)]
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cuda:0"))
+    pend = []
+    rl = RingLoader(_NoiseThenBoom(), num_workers=2, slot_bytes=1 << 18, num_slots=4, start_method="forkserver")
+    try:
+        with pytest.raises(RuntimeError, match="boom"):
+            for rb in rl.batches(specs):
+                flat = rb.data.view(np.float32)
+                views = [flat[o : o + n] for o, n in zip(rb.meta["offs"].tolist(), rb.meta["lens"].tolist())]
+                pend.append((rb, ex.submit_host_items(views, 16000)))
+                rl.pin_for(ex.plan.lib, 0)
+                if len(pend) > 3:  # (a consumer that collects with a lag of three batches)
+                    b, p = pend.pop(0)
+                    p.wait()
+                    p.release()
+                    b.release()
+        assert pend  # submitted, not collected
+    finally:
+        ex._native_pipe().drain()
+        rl.close()
+    for b, p in pend:
+        p.release()
+    del pend
+    x = torch.from_numpy(np.random.RandomState(0).rand(16000).astype(np.float32) - 0.5)
+    assert ex.extract(x, 16000).shape == (100, 80)
