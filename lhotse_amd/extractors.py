@@ -375,7 +375,7 @@ class _Plan:
 # --------------------------------------------------------------------------------------
 _COPY_POOL: Optional[ThreadPoolExecutor] = None
 _COPY_PIECE = 1 << 20  # floats per task (4 MiB)
-_COPY_THREADS = max(2, min(12, (os.cpu_count() or 2) // 2))
+_COPY_THREADS = max(2, min(12, _lib.usable_cpus() // 2))  # (affinity mask and the container's CPU quota, not the host's CPU count)
 _PACK_RUN = 1 << 20    # floats per pack-and-upload run of pack_to_device, at least (4 MiB)
 
 

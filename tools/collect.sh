@@ -15,6 +15,8 @@
 #   power        package power / shader clock while the headline kernel runs (tools/power_probe.sh)
 #   suite        python -m pytest tests -m gpu  (+ the parity artefact gpurun_out/parity_report.json)
 #   smoke        __graft_entry__.smoke()
+#   host         CPUs, cgroup quota, memory, /dev/shm of the box (tools/host_limits_probe.sh with the current ring loader)
+#   ring         leg C (DataLoader) vs leg D (shared ring, page-locked / not) of the plumbing workload, 1 / 2 / 4 processes per GPU (tools/ring_sweep.sh)
 #   mfcc_ab      the MODE 2 twiddle A/B of round 6 (tools/r6_mfcc_ab.sh; needs lhotse_amd/_lib/var_mfcc_tws.so)
 set -u
 NAME=${1:?outdir}; shift
@@ -83,6 +85,10 @@ for section in "$@"; do
       cp gpurun_out/parity_report.json "$OUT/parity_report.json" 2>/dev/null; tail -3 "$OUT/pytest_gpu.txt" ;;
     smoke)
       python __graft_entry__.py --smoke > "$OUT/smoke.txt" 2>&1; echo "rc=$?"; tail -8 "$OUT/smoke.txt" ;;
+    host)
+      bash tools/host_limits_probe.sh > "$OUT/host_limits.txt" 2>&1; head -12 "$OUT/host_limits.txt" ;;
+    ring)
+      bash tools/ring_sweep.sh "$OUT/ring" > /dev/null 2>&1; tail -4 "$OUT/ring/multi.txt" ;;
     mfcc_ab)
       tools/r6_mfcc_ab.sh "$OUT/mfcc_ab" > "$OUT/mfcc_ab.txt" 2>&1; cat "$OUT/mfcc_ab.txt" ;;
     *) echo "unknown section $section" ;;
