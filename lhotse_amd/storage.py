@@ -693,6 +693,17 @@ def _batch_features_pending(extractor, waves, sampling_rate: int, lengths, half:
     return _HostFeatures(host, frames), frames
 
 
+def _packed_features_pending(extractor, flat: np.ndarray, offs: np.ndarray, lens: np.ndarray, sampling_rate: int, half: bool = False):
+    """``_batch_features_pending`` for a batch that lies in ONE host buffer (a slot of the ring loader): handed to the library's host
+    pipeline by base pointer + offsets when that route is open, as 1-D views otherwise."""
+    if hasattr(extractor, "submit_host_packed") and getattr(extractor.plan, "handle", None) and extractor.plan.device.type == "cuda" \
+            and not getattr(extractor.config, "dither", 0.0) and len(lens) > 0:
+        pending = extractor.submit_host_packed(flat, offs, lens, sampling_rate, half=half)
+        return pending, [int(t) for t in pending.frames]
+    waves = [flat[o : o + n] for o, n in zip(offs.tolist(), lens.tolist())]
+    return _batch_features_pending(extractor, waves, sampling_rate, None, half=half)
+
+
 def pump_batches(batches, extract, save, backlog: int = None, stats: Optional[Dict] = None, finish=None) -> None:
     """The loop of the batch driver (lhotse/cut/set.py:2365-2404): the calling thread runs ``extract(batch)`` -> arguments of ``save`` (or
     None to skip the batch), ONE background thread runs ``save(*args)`` behind it -- and, with ``finish``, a second one runs
@@ -943,11 +954,9 @@ def compute_and_store_features_batch(
                     sr = batch_cuts[0].sampling_rate
                     assert all(c.sampling_rate == sr for c in batch_cuts)
                     if "audio" in meta:  # (a batch that did not fit a slot / is not mono float32: it came by pickle)
-                        waves = meta["audio"]
+                        pending, frames = _batch_features_pending(extractor, meta["audio"], sr, None, half=np_dtype == "<f2")
                     else:
-                        flat = rb.data.view(np.float32)
-                        waves = [flat[o : o + n] for o, n in zip(meta["offs"].tolist(), meta["lens"].tolist())]
-                    pending, frames = _batch_features_pending(extractor, waves, sr, None, half=np_dtype == "<f2")
+                        pending, frames = _packed_features_pending(extractor, rb.data.view(np.float32), meta["offs"], meta["lens"], sr, half=np_dtype == "<f2")
                     _pin_ring(ring, extractor)
                     return archive, batch_cuts, _SlotPending(pending, rb), frames, template_of(pending, sr), meta["frags"]
 

@@ -161,3 +161,33 @@ def test_a_failed_run_drains_the_pipeline_before_the_page_locked_ring_is_unmappe
     del pend
     x = torch.from_numpy(np.random.RandomState(0).rand(16000).astype(np.float32) - 0.5)
     assert ex.extract(x, 16000).shape == (100, 80)
+
+
+@pytest.mark.parametrize("pcm16", [False, True])
+def test_submit_packed_equals_submit_on_the_views(pcm16):
+    """submit_host_packed(flat, offs, lens) -- base pointer + offsets, no view per cut -- is submit_host_items on the 1-D views, bit for
+    bit; bad arguments are refused before anything is queued."""
+    rng = np.random.RandomState(5)
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cuda:0"))
+    dt = np.int16 if pcm16 else np.float32
+    lens = [16000, 9999, 32000, 4800]
+    buf = np.zeros(1 << 19, dtype=np.uint8)
+    w = SlotWriter(buf)
+    for n in lens:
+        assert w.add(rng.randint(-9000, 9000, size=n).astype(np.int16) if pcm16 else (rng.rand(n).astype(np.float32) - 0.5))
+    used, offs, ln = w.finish()
+    flat = buf[:used].view(dt)
+    p = ex.submit_host_items([flat[o : o + n] for o, n in zip(offs.tolist(), ln.tolist())], 16000)
+    want = p.wait().copy()
+    p.release()
+    q = ex.submit_host_packed(flat, offs, ln, 16000)
+    got = q.wait().copy()
+    assert list(q.frames) == [(n + 80) // 160 for n in lens]
+    q.release()
+    assert np.array_equal(got, want)
+    with pytest.raises(ValueError, match="outside the buffer"):
+        ex.submit_host_packed(flat, offs, ln + 10 ** 6, 16000)
+    with pytest.raises(TypeError, match="1-D C-contiguous"):
+        ex.submit_host_packed(flat.astype(np.float64), offs, ln, 16000)
+    with pytest.raises(ValueError):
+        ex.submit_host_packed(flat, offs[:2], ln, 16000)

@@ -29,12 +29,14 @@ for section in "$@"; do
   echo "== $section"
   case $section in
     bench)
-      python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "rc=$?"
-      python bench.py --no-cpu-baseline --no-extra > "$OUT/bench_default_steps.json" 2> /dev/null
+      timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "rc=$?"
+      timeout 600 python bench.py --no-cpu-baseline --no-extra > "$OUT/bench_default_steps.json" 2> /dev/null
       tail -c 300 "$OUT/bench.json"; echo ;;
     stats)
       prof_env
-      rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-fed > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.err"
+      # (BENCH_NO_PLUMBING: under rocprofv3's preloaded tool a multiprocessing fork server cannot restore its signal handlers, its workers die
+      #  and the server itself never exits -- rocprofv3 then waits for it for ever; the kernels of the line are what is profiled here)
+      BENCH_NO_PLUMBING=1 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-fed > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.err"
       summarise "$OUT/prof" "$OUT/kernel_stats.txt"; head -12 "$OUT/kernel_stats.txt" ;;
     pmc)
       for cfg in fbank16k mfcc40_libri onthefly; do
@@ -61,7 +63,7 @@ for section in "$@"; do
       for cfg in mfcc40_libri onthefly bulk_save plumbing; do
         timeout 900 python bench.py --config $cfg > "$OUT/bench_$cfg.json" 2> "$OUT/bench_$cfg.err"; echo "$cfg rc=$?"
       done
-      python bench.py --total-cuts 100000 --steps 10 --no-cpu-baseline --no-extra > "$OUT/bench_total100k.json" 2> "$OUT/bench_total100k.err" ;;
+      timeout 900 python bench.py --total-cuts 100000 --steps 10 --no-cpu-baseline --no-extra > "$OUT/bench_total100k.json" 2> "$OUT/bench_total100k.err" ;;
     stripes)
       for n in 1 8 16 32; do
         timeout 600 python bench.py --config bulk_save --stripes $n --no-cpu-baseline > "$OUT/bench_bulk_save_stripes$n.json" 2> /dev/null; echo "stripes $n rc=$?"
@@ -84,7 +86,7 @@ for section in "$@"; do
       timeout 1800 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.txt" 2>&1; echo "rc=$?"
       cp gpurun_out/parity_report.json "$OUT/parity_report.json" 2>/dev/null; tail -3 "$OUT/pytest_gpu.txt" ;;
     smoke)
-      python __graft_entry__.py --smoke > "$OUT/smoke.txt" 2>&1; echo "rc=$?"; tail -8 "$OUT/smoke.txt" ;;
+      timeout 600 python __graft_entry__.py --smoke > "$OUT/smoke.txt" 2>&1; echo "rc=$?"; tail -8 "$OUT/smoke.txt" ;;
     host)
       bash tools/host_limits_probe.sh > "$OUT/host_limits.txt" 2>&1; head -12 "$OUT/host_limits.txt" ;;
     ring)

@@ -578,9 +578,7 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
                 S.NativeArchive(os.path.join(out_dir, "feats"), mode="w", np_dtype="<f2" if half else "<f4", stripes=stripes, name=storage) as ar:
 
             def extract(rb):
-                flat = rb.data.view(np.int16 if pcm16 else np.float32)
-                waves = [flat[o : o + n] for o, n in zip(rb.meta["offs"].tolist(), rb.meta["lens"].tolist())]
-                pending, frames = S._batch_features_pending(ex, waves, SR, None, half=half)
+                pending, frames = S._packed_features_pending(ex, rb.data.view(np.int16 if pcm16 else np.float32), rb.meta["offs"], rb.meta["lens"], SR, half=half)
                 if pin:
                     S._pin_ring(loader, ex)  # (slots are page-locked for the GPU as they come into use: uploads straight out of the ring)
                 return rb, pending, frames
