@@ -73,7 +73,12 @@ def test_the_default_line_carries_the_other_baseline_configs_and_both_regimes():
     assert plumb["value"] > 0 and plumb["parity"]["pass"] is True and plumb["last_pass"]["cuts_per_s"] > 0
     legs = plumb["legs"]
     # (leg A, the CPU per-cut driver, belongs to the CPU baseline: this test runs the line with --no-cpu-baseline)
-    assert any(k.startswith("B hip_batch_numpy_files") for k in legs) and any(k.startswith("C hip_bulk") for k in legs) and any("FORKED AFTER" in k for k in legs)
+    # (the fork-hazard legs and the staging-copy variant are part of `--config plumbing`, not of the default line)
+    assert any(k.startswith("B hip_batch_numpy_files") for k in legs) and any(k.startswith("C hip_bulk") for k in legs)
+    assert any(k.startswith("D hip_ring float32") and "PROCESSES" not in k for k in legs) and any(k.startswith("D hip_ring") and "2 PROCESSES sharing the GPU" in k for k in legs)
+    ring = next(v for k, v in legs.items() if k.startswith("D hip_ring float32") and "PROCESSES" not in k)
+    assert ring["ring_slots_page_locked"] > 0 and ring["batches_uploaded_straight_from_the_ring"] > 0
+    assert ring["container_cpu_quota"] is None or ring["container_cpu_quota"] > 0
     assert all(v["cuts_per_s"] > 0 for k, v in legs.items() if isinstance(v, dict)), legs
     for name, c in cfgs.items():
         assert c["parity"]["pass_rel_l2"] is True and c["value"] > 0 and c["roofline"]["frac"] > 0 and c["steps"] > 0, (name, c)
