@@ -1298,10 +1298,27 @@ def init_dist(backend: str, dev):
     os.environ.setdefault("WORLD_SIZE", "1")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 
+    def quiet_stdout(fn):
+        """gloo announces its connections on STDOUT from C++ ("[Gloo] Rank 0 is connected to ..."): the contract is ONE JSON line there, so
+        file descriptor 1 points at stderr while a gloo group is being set up."""
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            return fn()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+
     def gloo_group(why: str):
-        store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1, world, is_master=(rank == 0),
-                              timeout=datetime.timedelta(seconds=120), wait_for_workers=False)
-        dist.init_process_group(backend="gloo", store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        def make():
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + 1, world, is_master=(rank == 0),
+                                  timeout=datetime.timedelta(seconds=120), wait_for_workers=False)
+            dist.init_process_group(backend="gloo", store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            dist.barrier()  # (the full mesh is connected here at the latest)
+
+        quiet_stdout(make)
         return dist, why
 
     if backend == "nccl":
@@ -1322,7 +1339,10 @@ def init_dist(backend: str, dev):
             except Exception:  # noqa: BLE001
                 pass
             return gloo_group("gloo (RCCL initialisation failed)")
-    dist.init_process_group(backend=backend)
+    if backend == "gloo":
+        quiet_stdout(lambda: (dist.init_process_group(backend=backend), dist.barrier()))
+    else:
+        dist.init_process_group(backend=backend)
     return dist, backend
 
 

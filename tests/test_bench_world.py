@@ -25,6 +25,7 @@ def _run(world: int, steps: int = 4, warmup: int = 2):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]  # rank 0 prints ONE line, nobody else prints JSON
+    assert [ln for ln in p.stdout.splitlines() if ln.strip() and "[Gloo]" in ln] == [], p.stdout[:500]  # (gloo's C++ connection chatter is kept off stdout)
     return json.loads(lines[0])
 
 
