@@ -1098,6 +1098,11 @@ class Plumbing:
         out[f"D hip_ring int16 -> hip_archive_f16, {W} loader workers"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--pcm16", "--half"))
         half_w = max(2, W * 3 // 4)
         out.update(self._shared_gpu(2, half_w, "D"))
+        # the per-cut driver (leg A's loop) with HipFbank as a drop-in of Fbank: what changes for a user who changes only the extractor object
+        for jobs in sorted({1, max(1, int(self.quota or 16) // 2)} if full else {max(1, int(self.quota or 16) // 2)}):
+            rows = self._fresh("--leg", "E", "--jobs", jobs, repeat=max(4, self.repeat // (2 if jobs > 1 else 16)))
+            out[f"E per-cut driver (compute_and_store_features structure) around HipFbank, num_jobs={jobs} processes sharing the GPU"] = \
+                rows if isinstance(rows, dict) else {k: rows[0][k] for k in ("cuts_per_s", "per_process_cuts_per_s", "cuts", "num_jobs", "errors")}
         if full:
             out.update(self._shared_gpu(2, half_w, "D", ("--pcm16", "--half"), "int16 -> hip_archive_f16"))
             out[f"D hip_ring float32 -> hip_archive, {W} loader workers, staging copy kept (slots not page-locked)"] = \
@@ -1125,7 +1130,7 @@ class Plumbing:
                        "(oracle/kaldi_torch.py: the checker / baseline, never the product path); B = the structure of CutSet.compute_and_store_features_batch "
                        "(lhotse/cut/set.py:2296-2408) around HipFbank with lhotse's own save path (one .npy per cut, one json.dumps + flush per cut on ONE save "
                        "thread) and lhotse's transport (one array per cut through the worker queue); C = the product's bulk driver behind a torch DataLoader (one packed "
-                       "tensor per batch); D = the product's bulk driver with its default loader, lhotse_amd/ring_loader.py (workers decode into slots of one shared "
+                       "tensor per batch); E = leg A's per-cut loop with HipFbank in place of the reference extractor (one cut per call, .npy + manifest line per cut, every job process its own plan); D = the product's bulk driver with its default loader, lhotse_amd/ring_loader.py (workers decode into slots of one shared "
                        "ring, the slots are page-locked for the GPU as they come into use and the host pipeline uploads straight out of them: ABI v5).  "
                        "B, C and D run in FRESH processes (tools/plumbing.py): the GPU is first touched at the first batch, after the workers were forked, as under "
                        "lhotse's driver.  container_cpus_busy / quota_periods_throttled: the whole container's CPU time over the leg against its cgroup quota "

@@ -61,3 +61,18 @@ def test_ring_slots_are_page_locked_and_later_batches_take_the_direct_route(tmp_
     for a, b in zip(d["archive_paths"], e["archive_paths"]):
         with open(a, "rb") as fa, open(b, "rb") as fb:
             assert fa.read() == fb.read()
+
+
+def test_per_cut_driver_leg_on_the_real_plan(tmp_path):
+    """Leg E in a fresh process (the jobs are forked off a process that never touches the GPU): two jobs, each with its own plan."""
+    import json
+    import subprocess
+
+    import plumbing as P
+
+    P.write_corpus(str(tmp_path / "wav"), n_files=4, seed=2)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "plumbing.py"), "--leg", "E", "--wav-dir", str(tmp_path / "wav"), "--repeat", "10", "--jobs", "2"],
+                       capture_output=True, text=True, timeout=600)
+    rows = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(rows) == 1, p.stderr[-1500:]
+    assert rows[0]["cuts"] == 40 and rows[0]["errors"] is None and rows[0]["cuts_per_s"] > 0 and rows[0]["extractor"] == "hip"

@@ -164,3 +164,24 @@ def test_slot_writer_and_page_locking_bookkeeping_of_the_ring():
     unreg = [c[1] for c in lib.calls if c[0] == "hipfeat_host_unregister"]
     assert sorted(unreg) == sorted(base + s * rl.slot_bytes for s in seen - {1})
     rl.close()  # (idempotent)
+
+
+def test_per_cut_driver_leg_with_the_hip_extractor(tmp_path, cpu_plan):
+    """Leg E: the per-cut driver of leg A (CutSet.compute_and_store_features, lhotse/cut/set.py:2141-2195) with HipFbank in place of the
+    reference's Fbank -- forked job processes, each with its own extractor; same files, same manifest fields, the extractor's name."""
+    import plumbing as P
+
+    from oracle.kaldi_torch import TorchFbank
+
+    paths = P.write_corpus(str(tmp_path / "wav"), n_files=3, seed=5)
+    cuts = P.make_cuts(paths, 2)
+    e = P.cpu_per_cut(cuts, str(tmp_path / "e"), num_jobs=2, extractor="hip")
+    assert e["cuts"] == 6 and e["errors"] is None and e["extractor"] == "hip"
+    for j in range(2):
+        with gzip.open(tmp_path / "e" / f"cuts-{j}.jsonl.gz", "rt") as f:
+            for ln, k in zip(f, range(j, 6, 2)):
+                d = json.loads(ln)
+                assert d["id"] == cuts[k].id and d["features"]["type"] == "hip-fbank" and d["features"]["num_frames"] == 1000
+                got = np.load(os.path.join(d["features"]["storage_path"], d["features"]["storage_key"]))
+                want = TorchFbank().extract(P.read_wav(cuts[k].path)[0])
+                assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-4

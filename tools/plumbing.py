@@ -151,27 +151,44 @@ def numpy_files_write(storage_dir: str, key: str, value: np.ndarray) -> str:
 # ----------------------------------------------------------------------------------------------------------------------------------
 # leg A: the CPU per-cut driver (baseline C of SURVEY 8d), restated; oracle/ is touched HERE ONLY
 # ----------------------------------------------------------------------------------------------------------------------------------
-def _cpu_job(job: int, cuts: List[Cut], out_dir: str) -> int:
+_JOB_EXTRACTOR: Dict = {}
+
+
+def _cpu_job(job: int, cuts: List[Cut], out_dir: str, extractor: str = "cpu") -> int:
+    """One job of the per-cut driver (lhotse/cut/set.py:2141-2195, lhotse/features/base.py:160-282): per cut load_audio -> extract ->
+    writer.write -> manifest line.  extractor "cpu" = the reference's torch call sequence (oracle: leg A, the baseline), "hip" = the
+    product's HipFbank as a drop-in of it (leg E: every job process builds its own plan the first time it extracts)."""
     import torch
 
     torch.set_num_threads(1)  # lhotse/bin/modes/features.py:25-32
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    from oracle.kaldi_torch import TorchFbank
+    ex = _JOB_EXTRACTOR.get(extractor)
+    if ex is None:
+        if extractor == "hip":
+            import lhotse_amd
 
-    ex = TorchFbank()
+            hip = lhotse_amd.HipFbank()
+            name, fn = hip.name, (lambda x: hip.extract(x, SR))
+        else:
+            from oracle.kaldi_torch import TorchFbank
+
+            name, fn = "kaldi-fbank", TorchFbank().extract
+        ex = _JOB_EXTRACTOR[extractor] = (name, fn)
+    name, fn = ex
     store = os.path.join(out_dir, f"feats-{job}")
     with gzip.open(os.path.join(out_dir, f"cuts-{job}.jsonl.gz"), "wt") as man:
         for c in cuts:
-            feats = ex.extract(read_wav(c.path)[0])
+            feats = fn(read_wav(c.path)[0])
             key = numpy_files_write(store, c.id, feats)
             assert feats.shape == (FRAMES, NUM_MELS)
-            man.write(json.dumps(cut_manifest_dict(c, features_dict(c, "kaldi-fbank", feats.shape[0], "numpy_files", store, key))) + "\n")
+            man.write(json.dumps(cut_manifest_dict(c, features_dict(c, name, feats.shape[0], "numpy_files", store, key))) + "\n")
     return len(cuts)
 
 
-def cpu_per_cut(cuts: List[Cut], out_dir: str, num_jobs: int) -> Dict:
-    """Leg A.  Job i takes cuts i, i + N, ... (LazySlicer, cut/set.py:2158-2160); worker processes are forked HERE (the reference spawns:
+def cpu_per_cut(cuts: List[Cut], out_dir: str, num_jobs: int, extractor: str = "cpu") -> Dict:
+    """Leg A (extractor "cpu") / leg E ("hip": the same per-cut driver with HipFbank in place of Fbank -- what a lhotse user gets who changes
+    nothing but the extractor object; call it from a process that has not touched the GPU, the jobs are forked).  Job i takes cuts i, i + N, ... (LazySlicer, cut/set.py:2158-2160); worker processes are forked HERE (the reference spawns:
     process start-up is outside the timed loop of a corpus-sized run either way, so it is excluded: workers are started, warmed with one
     cut, then released together)."""
     import multiprocessing as mp
@@ -183,11 +200,11 @@ def cpu_per_cut(cuts: List[Cut], out_dir: str, num_jobs: int) -> Dict:
 
     def body(j):
         try:
-            _cpu_job(j, cuts[:1], os.path.join(out_dir, f"warm{j}"))  # imports, first-call costs
+            _cpu_job(j, cuts[:1], os.path.join(out_dir, f"warm{j}"), extractor)  # imports, first-call costs (leg E: the job's plan)
             ready.put(j)
             go.wait()
             t0 = time.perf_counter()
-            n = _cpu_job(j, cuts[j::num_jobs], out_dir)
+            n = _cpu_job(j, cuts[j::num_jobs], out_dir, extractor)
             res.put((n, time.perf_counter() - t0))
         except BaseException as e:  # noqa: BLE001
             ready.put(-1)
@@ -206,7 +223,7 @@ def cpu_per_cut(cuts: List[Cut], out_dir: str, num_jobs: int) -> Dict:
     for p in ps:
         p.join(timeout=30)
     n = sum(o[0] for o in outs)
-    return {"cuts_per_s": round(n / wall, 1), "cuts": n, "seconds": round(wall, 3), "num_jobs": num_jobs,
+    return {"cuts_per_s": round(n / wall, 1), "cuts": n, "seconds": round(wall, 3), "num_jobs": num_jobs, "extractor": extractor,
             "per_process_cuts_per_s": round(n / wall / num_jobs, 1), "errors": [o[1] for o in outs if isinstance(o[1], str)] or None}
 
 
@@ -657,7 +674,8 @@ def main() -> None:
     import tempfile
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--leg", required=True, choices=["B", "C", "D"])
+    ap.add_argument("--leg", required=True, choices=["B", "C", "D", "E"])
+    ap.add_argument("--jobs", type=int, default=8, help="leg E: job processes of the per-cut driver")
     ap.add_argument("--wav-dir", required=True)
     ap.add_argument("--repeat", type=int, default=50)
     ap.add_argument("--workers", type=int, default=8)
@@ -677,6 +695,12 @@ def main() -> None:
 
     paths = sorted(os.path.join(a.wav_dir, f) for f in os.listdir(a.wav_dir) if f.endswith(".wav"))
     cuts = make_cuts(paths, a.repeat)
+    if a.leg == "E":  # the per-cut driver with HipFbank: job processes forked off THIS process, which never touches the GPU
+        base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+        with tempfile.TemporaryDirectory(prefix="hipfeat_leg_", dir=base) as td:
+            r = cpu_per_cut(cuts, td, a.jobs, extractor="hip")
+        print(json.dumps(r), flush=True)
+        return
     ex = lhotse_amd.HipFbank()  # (no plan yet: created lazily by the first extraction)
     if a.gpu_first:
         import torch
