@@ -1059,7 +1059,7 @@ class Plumbing:
         import subprocess
 
         start = time.time() + 12.0  # (imports and plan creation of all processes are over by then)
-        cmd = [sys.executable, os.path.join(ROOT, "tools", "plumbing.py"), "--leg", leg, "--wav-dir", os.path.dirname(self.paths[0]), "--repeat", str(self.repeat),
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "plumbing.py"), "--leg", leg, "--wav-dir", os.path.dirname(self.paths[0]), "--repeat", str(max(self.repeat, 1000) if leg == "D" else self.repeat),
                "--stripes", str(self.stripes), "--workers", str(workers), "--passes", "1", "--start-at", str(start), *flags]
         ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIPFEAT_NO_FORK_WARNING="1")) for _ in range(procs)]
         rows = []
@@ -1094,8 +1094,9 @@ class Plumbing:
             out[f"B hip_batch_numpy_files, {wk} loader workers"] = brief(self._fresh("--leg", "B", "--workers", wk, "--passes", 1, repeat=small))
         out[f"C hip_bulk float32 -> hip_archive, {W} loader workers (torch DataLoader, one packed tensor per batch)"] = \
             brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, repeat=max(4, self.repeat // 4)))
-        out[f"D hip_ring float32 -> hip_archive, {W} loader workers (shared-memory ring, slots page-locked for the GPU)"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1))
-        out[f"D hip_ring int16 -> hip_archive_f16, {W} loader workers"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--pcm16", "--half"))
+        long = max(self.repeat, 1000)  # (D legs: 64 000 cuts, ~2 s -- every slot's first batch still goes through staging while it is being page-locked)
+        out[f"D hip_ring float32 -> hip_archive, {W} loader workers (shared-memory ring, slots page-locked for the GPU)"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, repeat=long))
+        out[f"D hip_ring int16 -> hip_archive_f16, {W} loader workers"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--pcm16", "--half", repeat=long))
         half_w = max(2, W * 3 // 4)
         out.update(self._shared_gpu(2, half_w, "D"))
         # the per-cut driver (leg A's loop) with HipFbank as a drop-in of Fbank: what changes for a user who changes only the extractor object
@@ -1106,9 +1107,9 @@ class Plumbing:
         if full:
             out.update(self._shared_gpu(2, half_w, "D", ("--pcm16", "--half"), "int16 -> hip_archive_f16"))
             out[f"D hip_ring float32 -> hip_archive, {W} loader workers, staging copy kept (slots not page-locked)"] = \
-                brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--no-pin"))
+                brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--no-pin", repeat=long))
             out[f"D hip_ring float32 -> hip_archive, {W} loader workers, fork server, GPU touched before"] = \
-                brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--gpu-first", "--context", "forkserver"))
+                brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--gpu-first", "--context", "forkserver", repeat=long))
             out[f"C hip_bulk int16 -> hip_archive_f16, {W} loader workers"] = brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--pcm16", "--half", repeat=max(4, self.repeat // 4)))
             out[f"C hip_bulk float32 -> hip_archive, {W} loader workers, one array per cut through the worker queue (lhotse's transport)"] = \
                 brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, "--per-cut-transport", repeat=small))
