@@ -1077,7 +1077,7 @@ class Plumbing:
         import shutil
 
         P, out = self.P, {}
-        keep = ("cuts_per_s", "cuts_per_s_incl_worker_start", "seconds_to_first_batch", "cuts", "num_workers", "worker_start", "transport", "input", "storage",
+        keep = ("cuts_per_s", "cuts_per_s_incl_worker_start", "seconds_to_first_batch", "cuts", "num_workers", "worker_start", "transport", "input", "storage", "save_thread_busy_share",
                 "ring_slots_page_locked", "batches_uploaded_straight_from_the_ring", "batches", "cpus_busy_by_thread_name", "container_cpus_busy",
                 "container_cpus_busy_user_system", "container_cpu_quota", "quota_periods_throttled")
 
@@ -1097,6 +1097,8 @@ class Plumbing:
         long = max(self.repeat, 1000)  # (D legs: 64 000 cuts, ~2 s -- every slot's first batch still goes through staging while it is being page-locked)
         out[f"D hip_ring float32 -> hip_archive, {W} loader workers (shared-memory ring, slots page-locked for the GPU)"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, repeat=long))
         out[f"D hip_ring int16 -> hip_archive_f16, {W} loader workers"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--pcm16", "--half", repeat=long))
+        out[f"F hip_ring float32 -> lhotse's NumpyFilesWriter layout (one .npy + one manifest dict per cut), {W} loader workers"] = \
+            brief(self._fresh("--leg", "F", "--workers", W, "--passes", 1, repeat=max(4, self.repeat // 2)))
         half_w = max(2, W * 3 // 4)
         out.update(self._shared_gpu(2, half_w, "D"))
         # the per-cut driver (leg A's loop) with HipFbank as a drop-in of Fbank: what changes for a user who changes only the extractor object
@@ -1131,7 +1133,7 @@ class Plumbing:
                        "(oracle/kaldi_torch.py: the checker / baseline, never the product path); B = the structure of CutSet.compute_and_store_features_batch "
                        "(lhotse/cut/set.py:2296-2408) around HipFbank with lhotse's own save path (one .npy per cut, one json.dumps + flush per cut on ONE save "
                        "thread) and lhotse's transport (one array per cut through the worker queue); C = the product's bulk driver behind a torch DataLoader (one packed "
-                       "tensor per batch); E = leg A's per-cut loop with HipFbank in place of the reference extractor (one cut per call, .npy + manifest line per cut, every job process its own plan); D = the product's bulk driver with its default loader, lhotse_amd/ring_loader.py (workers decode into slots of one shared "
+                       "tensor per batch); F = D's loader and pipeline in front of lhotse's own per-cut storage (lhotse_amd.compute_and_store_features_batch(storage_type=NumpyFilesWriter)); E = leg A's per-cut loop with HipFbank in place of the reference extractor (one cut per call, .npy + manifest line per cut, every job process its own plan); D = the product's bulk driver with its default loader, lhotse_amd/ring_loader.py (workers decode into slots of one shared "
                        "ring, the slots are page-locked for the GPU as they come into use and the host pipeline uploads straight out of them: ABI v5).  "
                        "B, C and D run in FRESH processes (tools/plumbing.py): the GPU is first touched at the first batch, after the workers were forked, as under "
                        "lhotse's driver.  container_cpus_busy / quota_periods_throttled: the whole container's CPU time over the leg against its cgroup quota "

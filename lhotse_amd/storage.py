@@ -783,8 +783,9 @@ def compute_and_store_features_batch(
     ``loader`` (round 6): ``"ring"`` = the worker processes load every batch's audio straight into a slot of ONE shared-memory ring
     (``lhotse_amd.ring_loader``; what travels per batch is a few hundred bytes + the manifest-line halves, and the cut objects never
     come back: the main process kept them), ``"dataloader"`` = ``torch.utils.data.DataLoader`` over lhotse's waveform dataset as
-    lhotse's own driver uses it (lhotse/cut/set.py:2302-2304).  ``None`` = the ring wherever it applies (``hip_archive`` storages with a
-    manifest path, ``collate=False``, no ``augment_fn``, ``num_workers`` > 0, enough room in /dev/shm), the DataLoader otherwise.  Same
+    lhotse's own driver uses it (lhotse/cut/set.py:2302-2304).  ``None`` = the ring wherever it applies (``collate=False``, no
+    ``augment_fn``, ``num_workers`` > 0, enough room in /dev/shm; any storage type -- with the ``hip_archive`` storages and a manifest
+    path the workers also serialise the manifest-line halves), the DataLoader otherwise.  Same
     batches, same manifests, same archive bytes either way; measured with real WAV decoding in the workers the ring moves 13.7 k / 20 k
     cuts/s (float32 / int16 corpus) where the DataLoader moves 5-6 k / 8-10 k (profiles/r06_ring_loader_ab.txt).
 
@@ -900,10 +901,60 @@ def compute_and_store_features_batch(
 
     if loader not in (None, "ring", "dataloader"):
         raise ValueError(f"loader={loader!r}: expected None, 'ring' or 'dataloader'")
-    ring_applies = native and not collate and augment_fn is None and num_workers > 0
+    ring_applies = not collate and augment_fn is None and num_workers > 0
     if loader == "ring" and not ring_applies:
-        raise ValueError("loader='ring' serves the hip_archive storages with a manifest_path, collate=False, no augment_fn and num_workers > 0")
+        raise ValueError("loader='ring' serves collate=False without an augment_fn and with num_workers > 0")
     use_ring = ring_applies and loader != "dataloader"
+
+    def open_ring(template_base, first):
+        """The shared-memory ring loader for this run, or None (not asked for / no room in /dev/shm: the DataLoader then)."""
+        if not use_ring:
+            return None
+        from .ring_loader import RingLoader
+
+        sr0 = getattr(first, "sampling_rate", None) or 16000
+        slot_bytes = int(batch_duration * sr0 * 4 * 1.01) + 65536  # a batch of `batch_duration` seconds, float32, every cut on a 16-byte boundary
+        holds = _SAVE_BACKLOG + 4  # slots the extractor / save threads keep at any time
+        per_worker = 2 + -(-holds // num_workers)  # (every worker owns its slots: lhotse_amd/ring_loader.py)
+        room = _shm_free_bytes()
+        if room is not None and per_worker * num_workers * slot_bytes > 0.8 * room:
+            per_worker = min(per_worker, int(0.8 * room // (slot_bytes * num_workers)))
+        if per_worker < 2:
+            want = 2 * num_workers * slot_bytes >> 20
+            if loader == "ring":
+                raise OSError(f"loader='ring' needs {want} MiB of /dev/shm ({room >> 20} MiB are free): lower batch_duration / num_workers")
+            warnings.warn(f"lhotse_amd.compute_and_store_features_batch: /dev/shm has {room >> 20} MiB free, the ring loader wants {want} MiB; "
+                          "using the DataLoader", RuntimeWarning, stacklevel=3)
+            return None
+        return RingLoader(LoadCutsIntoSlot(template_base, frame_shift), num_workers, slot_bytes, per_worker * num_workers, start_method=loader_kw.get("multiprocessing_context"),
+                          worker_init_fn=worker_init_fn, preload=["lhotse", "lhotse.dataset", "lhotse_amd.storage"])
+
+    def ring_extract(ring, writer, half: bool, template_of):
+        """`extract` of pump_batches for batches that arrive in slots of the ring."""
+
+        def extract_ring(rb):
+            meta = rb.meta
+            batch_cuts = [rb.spec[i] for i in meta["kept"]]
+            if len(batch_cuts) == 0:
+                rb.release()
+                return None
+            sr = batch_cuts[0].sampling_rate
+            assert all(c.sampling_rate == sr for c in batch_cuts)
+            if "audio" in meta:  # (a batch that did not fit a slot / is not mono float32: it came by pickle)
+                pending, frames = _batch_features_pending(extractor, meta["audio"], sr, None, half=half)
+            else:
+                pending, frames = _packed_features_pending(extractor, rb.data.view(np.float32), meta["offs"], meta["lens"], sr, half=half)
+            _pin_ring(ring, extractor)
+            return writer, batch_cuts, _SlotPending(pending, rb), frames, template_of(pending, sr), meta["frags"]
+
+        return extract_ring
+
+    def close_ring(ring) -> None:
+        if ring is not None:
+            pipe = getattr(extractor, "__dict__", {}).get("_native_pipeline")
+            if pipe is not None:  # (after an exception batches may still be queued that read the ring's slots: not unmapped under them)
+                pipe.drain()
+            ring.close()
 
     if native:
         # ---- the native path: archive appends and manifest lines in libhipfeat, fragments from the loader's workers -------------------
@@ -918,47 +969,14 @@ def compute_and_store_features_batch(
             # lhotse's waveform dataset + the halves of every cut's manifest line, made where the cut is loaded (the DataLoader's worker
             # processes when num_workers > 0); a module-level class: picklable, so the `spawn` start method works too
             # (packed in the worker -- one shared-memory segment per batch instead of one per cut -- unless an augment_fn wants the per-cut arrays)
-            ring = None
-            if use_ring:
-                from .ring_loader import RingLoader
-
-                sr0 = getattr(first, "sampling_rate", None) or 16000
-                slot_bytes = int(batch_duration * sr0 * 4 * 1.01) + 65536  # a batch of `batch_duration` seconds, float32, every cut on a 16-byte boundary
-                holds = _SAVE_BACKLOG + 4  # slots the extractor / save threads keep at any time
-                per_worker = 2 + -(-holds // num_workers)  # (every worker owns its slots: lhotse_amd/ring_loader.py)
-                room = _shm_free_bytes()
-                if room is not None and per_worker * num_workers * slot_bytes > 0.8 * room:
-                    per_worker = min(per_worker, int(0.8 * room // (slot_bytes * num_workers)))
-                if per_worker < 2:
-                    want = 2 * num_workers * slot_bytes >> 20
-                    if loader == "ring":
-                        raise OSError(f"loader='ring' needs {want} MiB of /dev/shm ({room >> 20} MiB are free): lower batch_duration / num_workers")
-                    warnings.warn(f"lhotse_amd.compute_and_store_features_batch: /dev/shm has {room >> 20} MiB free, the ring loader wants {want} MiB; "
-                                  "using the DataLoader", RuntimeWarning, stacklevel=2)
-                else:
-                    ring = RingLoader(LoadCutsIntoSlot(base, frame_shift), num_workers, slot_bytes, per_worker * num_workers, start_method=loader_kw.get("multiprocessing_context"),
-                                      worker_init_fn=worker_init_fn, preload=["lhotse", "lhotse.dataset", "lhotse_amd.storage"])
+            ring = open_ring(base, first)
             if ring is None:
                 batches = DataLoader(_fragmenting_dataset_class()(collate, base, frame_shift, pack=augment_fn is None), batch_size=None, sampler=sampler,
                                      num_workers=num_workers, **loader_kw)
                 extract_ring = None
             else:
                 batches = ring.batches(list(b) for b in sampler)
-
-                def extract_ring(rb):
-                    meta = rb.meta
-                    batch_cuts = [rb.spec[i] for i in meta["kept"]]
-                    if len(batch_cuts) == 0:
-                        rb.release()
-                        return None
-                    sr = batch_cuts[0].sampling_rate
-                    assert all(c.sampling_rate == sr for c in batch_cuts)
-                    if "audio" in meta:  # (a batch that did not fit a slot / is not mono float32: it came by pickle)
-                        pending, frames = _batch_features_pending(extractor, meta["audio"], sr, None, half=np_dtype == "<f2")
-                    else:
-                        pending, frames = _packed_features_pending(extractor, rb.data.view(np.float32), meta["offs"], meta["lens"], sr, half=np_dtype == "<f2")
-                    _pin_ring(ring, extractor)
-                    return archive, batch_cuts, _SlotPending(pending, rb), frames, template_of(pending, sr), meta["frags"]
+                extract_ring = ring_extract(ring, archive, np_dtype == "<f2", lambda pending, sr: template_of(pending, sr))
 
             def save(archive, batch_cuts, pending, frames: List[int], template: Dict, frags):
                 frames = np.ascontiguousarray(frames, dtype=np.int64)
@@ -1003,16 +1021,16 @@ def compute_and_store_features_batch(
             try:
                 run(archive, batches, save, finish, np_dtype == "<f2", template_of, extract=extract_ring)
             finally:
-                if ring is not None:
-                    pipe = getattr(extractor, "__dict__", {}).get("_native_pipeline")
-                    if pipe is not None:  # (after an exception batches may still be queued that read the ring's slots: not unmapped under them)
-                        pipe.drain()
-                    ring.close()
+                close_ring(ring)
         return manifest.open_manifest()
 
     # ---- any other registered FeaturesWriter: per-cut write() calls, manifests through Python objects ------------------------------
-    batches = DataLoader(_fragmenting_dataset_class()(collate, None, frame_shift, pack=augment_fn is None), batch_size=None, sampler=sampler, num_workers=num_workers,
-                        **loader_kw)
+    ring = open_ring(None, next(iter(cuts), None))  # (no line halves here: the manifests of this path go through Python objects)
+    if ring is None:
+        batches = DataLoader(_fragmenting_dataset_class()(collate, None, frame_shift, pack=augment_fn is None), batch_size=None, sampler=sampler, num_workers=num_workers,
+                             **loader_kw)
+    else:
+        batches = ring.batches(list(b) for b in sampler)
 
     def save(writer, batch_cuts, pending, frames: List[int], template: Dict, frags):
         check_frames(batch_cuts, frames)
@@ -1045,5 +1063,9 @@ def compute_and_store_features_batch(
                                      "storage_type": writer.name, "storage_path": str(writer.storage_path)}
             return state["template"]
 
-        run(writer, batches, save, write_manifests, getattr(writer, "np_dtype", "<f4") == "<f2", template_of)
+        half = getattr(writer, "np_dtype", "<f4") == "<f2"
+        try:
+            run(writer, batches, save, write_manifests, half, template_of, extract=None if ring is None else ring_extract(ring, writer, half, template_of))
+        finally:
+            close_ring(ring)
     return manifest.open_manifest()

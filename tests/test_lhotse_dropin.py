@@ -843,3 +843,39 @@ def test_ring_loader_behind_the_batch_driver_equals_the_dataloader(tmp_path, cut
     assert (tmp_path / "small.hfa").read_bytes() == (tmp_path / "dl.hfa").read_bytes()
     with pytest.raises(OSError, match="/dev/shm"):
         S.compute_and_store_features_batch(many, ex, tmp_path / "small2", manifest_path=tmp_path / "small2.jsonl.gz", loader="ring", **kw)
+
+
+def test_ring_loader_serves_lhotse_s_own_storage_types_too(tmp_path, cutset, cpu_device, monkeypatch):
+    """The ring is a transport: with lhotse's own writers (NumpyFilesWriter here: one .npy per cut, manifests through Python objects) the
+    driver stores the same arrays under the same manifest lines as behind the DataLoader -- and really uses the ring."""
+    import lhotse_amd as LA
+    import lhotse_amd.ring_loader as R
+    from lhotse import CutSet
+    from lhotse.features.io import NumpyFilesWriter
+    from lhotse_amd import storage as S
+
+    cuts = [c.with_id(f"{c.id}-{k}") for k in range(3) for c in cutset]
+    many = CutSet.from_cuts(cuts)
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cpu"))
+    made = []
+    real = R.RingLoader
+
+    class Spy(real):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+
+    monkeypatch.setattr(R, "RingLoader", Spy)
+    kw = dict(batch_duration=4.0, num_workers=2, storage_type=NumpyFilesWriter)
+    a = list(S.compute_and_store_features_batch(many, ex, tmp_path / "dl", manifest_path=tmp_path / "dl.jsonl.gz", loader="dataloader", **kw))
+    assert made == []
+    b = list(S.compute_and_store_features_batch(many, ex, tmp_path / "ring", manifest_path=tmp_path / "ring.jsonl.gz", **kw))
+    assert len(made) == 1 and made[0]._closed
+    assert [c.id for c in a] == [c.id for c in b] == [c.id for c in cuts]
+    for x, y in zip(a, b):
+        assert x.features.storage_type == y.features.storage_type == "numpy_files" and x.features.storage_key == y.features.storage_key
+        assert np.array_equal(x.load_features(), y.load_features())
+    assert [ln.replace(str(tmp_path / "ring"), "@") for ln in _lines(tmp_path / "ring.jsonl.gz")] == [ln.replace(str(tmp_path / "dl"), "@") for ln in _lines(tmp_path / "dl.jsonl.gz")]
+    # without a manifest path (an in-memory CutSet comes back), still through the ring
+    c = S.compute_and_store_features_batch(many, ex, tmp_path / "mem", batch_duration=4.0, num_workers=2, storage_type=NumpyFilesWriter)
+    assert len(made) == 2 and [x.id for x in c] == [x.id for x in cuts]

@@ -185,3 +185,23 @@ def test_per_cut_driver_leg_with_the_hip_extractor(tmp_path, cpu_plan):
                 got = np.load(os.path.join(d["features"]["storage_path"], d["features"]["storage_key"]))
                 want = TorchFbank().extract(P.read_wav(cuts[k].path)[0])
                 assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-4
+
+
+def test_ring_leg_with_lhotse_s_numpy_files_storage(tmp_path, cpu_plan):
+    """Leg F: the ring's transport in front of lhotse's own per-cut storage (one .npy + one manifest line per cut)."""
+    import plumbing as P
+
+    import lhotse_amd as LA
+    from oracle.kaldi_torch import TorchFbank
+
+    paths = P.write_corpus(str(tmp_path / "wav"), n_files=3, seed=5)
+    cuts = P.make_cuts(paths, 2)
+    f = P.hip_ring_numpy_files(LA.HipFbank(LA.HipFbankConfig(device="cpu")), cuts, str(tmp_path / "f"), num_workers=2)
+    assert f["cuts"] == 6 and f["storage"] == "numpy_files"
+    with gzip.open(f["manifest"], "rt") as fh:
+        lines = [json.loads(ln) for ln in fh]
+    assert [d["id"] for d in lines] == [c.id for c in cuts]
+    for k in (0, 5):
+        got = np.load(os.path.join(lines[k]["features"]["storage_path"], lines[k]["features"]["storage_key"]))
+        want = TorchFbank().extract(P.read_wav(cuts[k].path)[0])
+        assert got.shape == (1000, 80) and np.linalg.norm(got - want) / np.linalg.norm(want) <= 1e-4

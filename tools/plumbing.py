@@ -543,7 +543,7 @@ class DecodeIntoSlot:
             if not slot.add(read_wav(c.path, self.pcm16)[0]):
                 raise ValueError("batch does not fit its ring slot")
         used, offs, lens = slot.finish()
-        frags = [manifest_fragments(c, self.template, self.frame_shift, self._rc) for c in batch_cuts]
+        frags = None if self.template is None else [manifest_fragments(c, self.template, self.frame_shift, self._rc) for c in batch_cuts]
         return used, {"offs": offs, "lens": lens, "frags": frags}
 
 
@@ -643,6 +643,79 @@ def hip_ring(ex, cuts: List[Cut], out_dir: str, num_workers: int, pcm16: bool = 
             **acct.result(), "archive_paths": paths, "manifest": os.path.join(out_dir, "cuts.jsonl.gz")}
 
 
+def hip_ring_numpy_files(ex, cuts: List[Cut], out_dir: str, num_workers: int, context: Optional[str] = None) -> Dict:
+    """Leg F: the product's driver with lhotse's OWN storage (NumpyFilesWriter: one .npy per cut, one manifest dict per cut, flushed per
+    batch) behind the ring loader -- lhotse_amd.compute_and_store_features_batch(storage_type=NumpyFilesWriter): leg B's save path, the
+    ring's transport, the library's host pipeline."""
+    from lhotse_amd import storage as S
+    from lhotse_amd.ring_loader import RingLoader
+
+    os.makedirs(out_dir, exist_ok=True)
+    store = os.path.join(out_dir, "feats")
+    batches = batches_of(cuts)
+    busy = {"save": 0.0, "wait": 0.0}
+    stats: Dict = {}
+    t_load, t_first = [0.0], [None]
+    acct = _Accounting(ex)
+    t0 = time.perf_counter()
+    loader = RingLoader(DecodeIntoSlot(False, None, ex.frame_shift), num_workers, slot_bytes=60 * (SAMPLES + 8) * 4, start_method=context)
+    acct.pids = [p.pid for p in loader._procs]
+
+    def timed(it):
+        while True:
+            ta = time.perf_counter()
+            try:
+                b = next(it)
+            except StopIteration:
+                return
+            tb = time.perf_counter()
+            t_load[0] += tb - ta
+            if t_first[0] is None:
+                t_first[0] = tb - t0
+            yield b
+            acct.first_batch()
+
+    try:
+        with gzip.open(os.path.join(out_dir, "cuts.jsonl.gz"), "wt") as man:
+
+            def extract(rb):
+                pending, frames = S._packed_features_pending(ex, rb.data.view(np.float32), rb.meta["offs"], rb.meta["lens"], SR, half=False)
+                S._pin_ring(loader, ex)
+                return rb, pending, frames
+
+            def save(rb, pending, frames):
+                ta = time.perf_counter()
+                host = pending.wait()
+                batch_cuts = rb.spec
+                rb.release()
+                tb = time.perf_counter()
+                row = 0
+                for c, t in zip(batch_cuts, frames):
+                    feat_mat = host[row : row + t]
+                    row += t
+                    key = numpy_files_write(store, c.id, feat_mat)
+                    assert feat_mat.shape == (FRAMES, NUM_MELS)
+                    man.write(json.dumps(cut_manifest_dict(c, features_dict(c, ex.name, t, "numpy_files", store, key))) + "\n")
+                man.flush()  # (one flush per batch)
+                del host
+                pending.release()
+                busy["wait"] += tb - ta
+                busy["save"] += time.perf_counter() - tb
+
+            S.pump_batches(timed(loader.batches([cuts[i] for i in idx] for idx in batches)), extract, save, stats=stats)
+            acct.stop()
+    finally:
+        loader.close()
+    wall = time.perf_counter() - t0
+    steady = (len(cuts) - len(batches[0])) / max(wall - (t_first[0] or 0.0), 1e-9)
+    return {"cuts_per_s": round(steady, 1), "cuts_per_s_incl_worker_start": round(len(cuts) / wall, 1), "seconds_to_first_batch": round(t_first[0] or 0.0, 3),
+            "cuts": len(cuts), "seconds": round(wall, 3), "num_workers": num_workers, "transport": f"shared ring of {loader.num_slots} slots", "storage": "numpy_files",
+            "worker_start": loader.start_method, "main_thread_waiting_for_the_loader_share": round(t_load[0] / wall, 3),
+            "main_thread_submit_share": round(stats.get("extract_s", 0.0) / wall, 3), "main_thread_blocked_on_the_save_threads_share": round(stats.get("wait_s", 0.0) / wall, 3),
+            "save_thread_busy_share": round(busy["save"] / wall, 3), "save_thread_waiting_for_the_device_share": round(busy["wait"] / wall, 3), **acct.result(),
+            "manifest": os.path.join(out_dir, "cuts.jsonl.gz")}
+
+
 def read_back(result: Dict, index: int) -> np.ndarray:
     """Cut `index` of a leg-C run, through the archive reader named by its manifest line."""
     from lhotse_amd import storage as S
@@ -674,7 +747,7 @@ def main() -> None:
     import tempfile
 
     ap = argparse.ArgumentParser()
-    ap.add_argument("--leg", required=True, choices=["B", "C", "D", "E"])
+    ap.add_argument("--leg", required=True, choices=["B", "C", "D", "E", "F"])
     ap.add_argument("--jobs", type=int, default=8, help="leg E: job processes of the per-cut driver")
     ap.add_argument("--wav-dir", required=True)
     ap.add_argument("--repeat", type=int, default=50)
@@ -715,6 +788,8 @@ def main() -> None:
             d = os.path.join(td, f"p{k}")
             if a.leg == "B":
                 r = hip_batch_numpy_files(ex, cuts, d, a.workers, context=a.context)
+            elif a.leg == "F":
+                r = hip_ring_numpy_files(ex, cuts, d, a.workers, context=a.context)
             elif a.leg == "D":
                 r = hip_ring(ex, cuts, d, a.workers, pcm16=a.pcm16, half=a.half, stripes=a.stripes, context=a.context, pin=not a.no_pin)
             else:
