@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, workdir, first, balance, q, sub="sharded"):
+def _rank_main(rank, world, port, workdir, first, balance, q, sub="sharded", workers=0):
     """One rank: a fresh process, as under torchrun."""
     try:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), HIPFEAT_RUN_ID=f"test-{port}")
@@ -49,13 +49,13 @@ def _rank_main(rank, world, port, workdir, first, balance, q, sub="sharded"):
         if first:
             cuts = cuts.subset(first=first)
         out = LA.compute_and_store_features_sharded(cuts, LA.HipFbank(), storage_path=work / sub, manifest_path=work / sub / "cuts.jsonl.gz",
-                                                    batch_duration=3.0, num_workers=0, balance=balance, barrier_timeout=120.0)
+                                                    batch_duration=3.0, num_workers=workers, balance=balance, barrier_timeout=120.0)
         import torch.distributed as dist
 
         assert not dist.is_initialized()  # the group the driver created for its barrier is gone again
         # a second call in the same processes (everything is in the manifests already): the rendezvous must come up again
         again = LA.compute_and_store_features_sharded(cuts, LA.HipFbank(), storage_path=work / sub, manifest_path=work / sub / "cuts.jsonl.gz",
-                                                      batch_duration=3.0, num_workers=0, balance=balance, barrier_timeout=120.0)
+                                                      batch_duration=3.0, num_workers=workers, balance=balance, barrier_timeout=120.0)
         assert [c.id for c in again] == [c.id for c in out] and not dist.is_initialized()
         q.put((rank, [c.id for c in out], dict(LA.storage.TEMPLATE_STATS), None))
     except BaseException as e:  # noqa: BLE001 -- the parent must see the reason
@@ -65,11 +65,11 @@ def _rank_main(rank, world, port, workdir, first, balance, q, sub="sharded"):
         raise
 
 
-def _run_ranks(workdir, world=2, first=0, balance="round_robin", group=True, sub="sharded"):
+def _run_ranks(workdir, world=2, first=0, balance="round_robin", group=True, sub="sharded", workers=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port() if group else 0
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, str(workdir), first, balance, q, sub)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, str(workdir), first, balance, q, sub, workers)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -185,3 +185,13 @@ def test_ranks_without_a_rendezvous_address_meet_through_marker_files(world, mon
     # duration-balanced shards: both ranks carry about half of the audio
     loads = [sum(c.duration for c in CutSet.from_file(work / "sharded" / f"cuts-{r}.jsonl.gz")) for r in range(2)]
     assert abs(loads[0] - loads[1]) / sum(loads) < 0.1
+
+
+def test_two_ranks_each_behind_its_own_ring_loader(world):
+    """Round 6: every rank of the sharded driver loads its shard through its own shared-memory ring (the default loader with
+    num_workers > 0): two spawned gloo ranks x one loader worker each equal the single-process run cut for cut, feature for feature."""
+    work, single = world
+    res = _run_ranks(work, world=2, sub="sharded_ring", workers=1)
+    assert sorted(res) == [0, 1]
+    assert sum(s.get("native", 0) for _, s in res.values()) >= len(single)  # (every line came out of the C splice, fed by the ring's workers)
+    _check_combined(work, single, sub="sharded_ring")
