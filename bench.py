@@ -1059,7 +1059,7 @@ class Plumbing:
         import subprocess
 
         start = time.time() + 12.0  # (imports and plan creation of all processes are over by then)
-        cmd = [sys.executable, os.path.join(ROOT, "tools", "plumbing.py"), "--leg", leg, "--wav-dir", os.path.dirname(self.paths[0]), "--repeat", str(max(self.repeat, 1000) if leg == "D" else self.repeat),
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "plumbing.py"), "--leg", leg, "--wav-dir", os.path.dirname(self.paths[0]), "--repeat", str(getattr(self, "long", self.repeat) if leg == "D" else self.repeat),
                "--stripes", str(self.stripes), "--workers", str(workers), "--passes", "1", "--start-at", str(start), *flags]
         ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, HIPFEAT_NO_FORK_WARNING="1")) for _ in range(procs)]
         rows = []
@@ -1094,7 +1094,14 @@ class Plumbing:
             out[f"B hip_batch_numpy_files, {wk} loader workers"] = brief(self._fresh("--leg", "B", "--workers", wk, "--passes", 1, repeat=small))
         out[f"C hip_bulk float32 -> hip_archive, {W} loader workers (torch DataLoader, one packed tensor per batch)"] = \
             brief(self._fresh("--leg", "C", "--workers", W, "--passes", 1, repeat=max(4, self.repeat // 4)))
-        long = max(self.repeat, 1000)  # (D legs: 64 000 cuts, ~2 s -- every slot's first batch still goes through staging while it is being page-locked)
+        # D legs: 64 000 cuts, ~2 s (every slot's first batch still goes through staging while it is being page-locked) -- 20 GB of archive per
+        # process in the temporary directory: only where there is room for it
+        try:
+            st = os.statvfs(self.tmp.name)
+            roomy = st.f_bavail * st.f_frsize > (120 << 30)
+        except OSError:
+            roomy = False
+        self.long = long = max(self.repeat, 1000) if roomy else self.repeat
         out[f"D hip_ring float32 -> hip_archive, {W} loader workers (shared-memory ring, slots page-locked for the GPU)"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, repeat=long))
         out[f"D hip_ring int16 -> hip_archive_f16, {W} loader workers"] = brief(self._fresh("--leg", "D", "--workers", W, "--passes", 1, "--pcm16", "--half", repeat=long))
         out[f"F hip_ring float32 -> lhotse's NumpyFilesWriter layout (one .npy + one manifest dict per cut), {W} loader workers"] = \
