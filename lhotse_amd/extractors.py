@@ -984,6 +984,11 @@ class _HipExtractor(FeatureExtractor):
         offs = np.zeros(len(items), dtype=np.int64)
         np.cumsum(padded[:-1], out=offs[1:])
         total = int(offs[-1] + lens[-1]) if len(items) else 0
+        if dev.type != "cuda":  # only reachable with a stand-in plan (tests): the conversion the device does, x / 32768 (exact)
+            host = torch.zeros(total, dtype=torch.float32)
+            for x, o, n in zip(items, offs, lens):
+                host[o : o + n] = (x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))).to(torch.float32) / 32768.0
+            return host, offs, lens
         if all(isinstance(x, torch.Tensor) and x.device == dev for x in items):
             pcm = torch.zeros(total, dtype=torch.int16, device=dev)
             for x, o, n in zip(items, offs, lens):

@@ -460,6 +460,7 @@ def compute_and_store_features_sharded(
     loader: str = None,
     loader_start_method: str = None,
     worker_init_fn=None,
+    wav_pcm16: bool = False,
 ):
     """Feature extraction of one CutSet over the GPUs of a node: the multi-GPU form of ``compute_and_store_features_batch``.
 
@@ -472,7 +473,7 @@ def compute_and_store_features_sharded(
     ``manifest_path`` in input order.  NO collective touches the data path; the barrier is the only communication.
 
     ``archive_stripes``: files per rank's ``hip_archive`` (``feats-r.hfa``, ``feats-r.1.hfa``, ...; see ``compute_and_store_features_batch``).
-    ``loader`` / ``loader_start_method`` / ``worker_init_fn``: every rank's loader, as in ``compute_and_store_features_batch`` (the
+    ``loader`` / ``loader_start_method`` / ``worker_init_fn`` / ``wav_pcm16``: every rank's loader, as in ``compute_and_store_features_batch`` (the
     shared-memory ring by default where it applies).
 
     ``numa_bind`` (default on, for world > 1): before the extractor touches its GPU -- i.e. before any pinned staging buffer exists and
@@ -544,7 +545,7 @@ def compute_and_store_features_sharded(
         out = compute_and_store_features_batch(mine, extractor, sub_storage, manifest_path=sub_manifest, batch_duration=batch_duration,
                                                num_workers=num_workers, collate=collate, augment_fn=augment_fn, storage_type=storage_type,
                                                overwrite=overwrite, archive_stripes=archive_stripes, loader=loader,
-                                               loader_start_method=loader_start_method, worker_init_fn=worker_init_fn)
+                                               loader_start_method=loader_start_method, worker_init_fn=worker_init_fn, wav_pcm16=wav_pcm16)
         meet.barrier("extracted")
         if rank == 0:
             out = combine_shard_manifests(cuts, manifest_path, [shard_paths(storage_path, manifest_path, r)[1] for r in range(world)], owner)

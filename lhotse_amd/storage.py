@@ -499,6 +499,45 @@ def unpack_batch_audio(batch: Dict):
     return out
 
 
+def pcm16_wav_segment(cut, mono_type=None) -> Optional[np.ndarray]:
+    """The int16 samples of which ``cut.load_audio()`` returns ``x / 32768`` as float32 -- read with the stdlib ``wave`` module -- or None
+    when that cannot be guaranteed: only a MonoCut over a recording that is ONE local mono 16-bit PCM ``.wav`` file without transforms
+    qualifies, and only when the file holds exactly the samples lhotse would end up with (``Recording.load_audio`` +
+    ``assert_and_maybe_fix_num_samples``, lhotse/audio/recording.py:389-492, 1032-1068: anything that would make lhotse pad, trim, warn
+    or raise is left to lhotse).  The device converts int16 -> float32 as x / 32768 (``hipfeat_pcm16_to_float``, exact), which is what the
+    audio backends do on the host: same features, a third of the loader's memory traffic and half the bytes over PCIe."""
+    import wave
+    from math import isclose
+
+    from lhotse.utils import compute_num_samples
+
+    if mono_type is not None and type(cut) is not mono_type:
+        return None
+    rec = getattr(cut, "recording", None)
+    if rec is None or getattr(rec, "transforms", None) or len(rec.sources) != 1 or getattr(rec, "has_video", False):
+        return None
+    src = rec.sources[0]
+    if src.type != "file" or not str(src.source).lower().endswith(".wav") or list(src.channels) != [0] or list(rec.channel_ids) != [0] or cut.channel != 0:
+        return None
+    sr = rec.sampling_rate
+    start = compute_num_samples(cut.start, sr)
+    whole = isclose(cut.duration, rec.duration, abs_tol=1e-3)  # (lhotse then reads to the end of the file and fixes the count up)
+    want = compute_num_samples(cut.duration if cut.duration is not None else rec.duration - cut.start, sr)
+    try:
+        with wave.open(str(src.source), "rb") as f:
+            if f.getnchannels() != 1 or f.getsampwidth() != 2 or f.getframerate() != sr or f.getcomptype() != "NONE":
+                return None
+            n = f.getnframes()
+            if start + want > n or (whole and n - start != want):
+                return None
+            f.setpos(start)
+            raw = f.readframes(want)
+    except (OSError, EOFError, wave.Error):
+        return None
+    x = np.frombuffer(raw, dtype="<i2")
+    return x if x.shape[0] == want else None
+
+
 class LoadCutsIntoSlot:
     """`load_batch` of ``lhotse_amd.ring_loader.RingLoader`` for lhotse cuts: what ``FragmentingWaveformDataset.__getitem__`` does with
     ``collate=False`` (lhotse/dataset/unsupervised.py:66-80: validate, load every cut's audio, drop the cuts whose audio fails to load the
@@ -508,11 +547,22 @@ class LoadCutsIntoSlot:
     that is not all mono float32, or does not fit a slot (one cut longer than ``batch_duration``), travels as ``"audio"`` by pickle -- the
     DataLoader's transport, for that batch only."""
 
-    def __init__(self, template: Optional[Dict], frame_shift: float):
-        self.template, self.frame_shift = template, frame_shift
+    def __init__(self, template: Optional[Dict], frame_shift: float, pcm16: bool = False):
+        self.template, self.frame_shift, self.pcm16 = template, frame_shift, pcm16
 
     def __getstate__(self):
-        return {"template": self.template, "frame_shift": self.frame_shift}
+        return {"template": self.template, "frame_shift": self.frame_shift, "pcm16": self.pcm16}
+
+    def _pcm16_batch(self, cuts, out: np.ndarray, mono_type):
+        """The whole batch as int16 PCM in the slot (``pcm16_wav_segment`` for EVERY cut), or None: the batch then takes lhotse's route."""
+        from .ring_loader import SlotWriter
+
+        slot = SlotWriter(out)
+        for c in cuts:
+            x = pcm16_wav_segment(c, mono_type)
+            if x is None or not slot.add(x):
+                return None
+        return slot.finish()
 
     def __call__(self, cuts, out: np.ndarray):
         from lhotse import CutSet, MonoCut, validate
@@ -523,6 +573,14 @@ class LoadCutsIntoSlot:
         validate(CutSet.from_cuts(cuts))
         assert all(c.has_recording for c in cuts)
         cache = self.__dict__.setdefault("_rec_cache", {})
+        t = self.template
+        if self.pcm16:
+            packed = self._pcm16_batch(cuts, out, MonoCut)
+            if packed is not None:
+                kept = list(range(len(cuts)))
+                meta = {"kept": kept, "pcm16": True, "frags": None if t is None else [manifest_fragments(c, t, self.frame_shift, cache, MonoCut) for c in cuts]}
+                used, meta["offs"], meta["lens"] = packed
+                return used, meta
         kept, slot, loose = [], SlotWriter(out), None
         for i, c in enumerate(cuts):
             with suppress_audio_loading_errors():
@@ -534,7 +592,6 @@ class LoadCutsIntoSlot:
                     loose = [x.reshape(1, -1) for x in slot.arrays()]
                 if loose is not None:
                     loose.append(a)
-        t = self.template
         meta = {"kept": kept, "frags": None if t is None else [manifest_fragments(cuts[i], t, self.frame_shift, cache, MonoCut) for i in kept]}
         if loose is not None:
             meta["audio"] = loose
@@ -776,6 +833,7 @@ def compute_and_store_features_batch(
     loader_start_method: Optional[str] = None,
     worker_init_fn: Optional[Callable] = None,
     loader: Optional[str] = None,
+    wav_pcm16: bool = False,
 ):
     """``CutSet.compute_and_store_features_batch`` with the bulk save path of this module (same arguments; ``storage_type``
     defaults to ``HipArchiveWriter``).  Returns the CutSet with the ``Features`` manifests attached.
@@ -786,7 +844,10 @@ def compute_and_store_features_batch(
     lhotse's own driver uses it (lhotse/cut/set.py:2302-2304).  ``None`` = the ring wherever it applies (``collate=False``, no
     ``augment_fn``, ``num_workers`` > 0, enough room in /dev/shm; any storage type -- with the ``hip_archive`` storages and a manifest
     path the workers also serialise the manifest-line halves), the DataLoader otherwise.  Same
-    batches, same manifests, same archive bytes either way; measured with real WAV decoding in the workers the ring moves 13.7 k / 20 k
+    ``wav_pcm16`` (with the ring): batches whose cuts are ALL plain mono 16-bit PCM ``.wav`` segments (``pcm16_wav_segment``) are read as
+    int16 straight into the slot and converted on the device (x / 32768, exact: what the audio backend does on the host) -- the same
+    features; any other batch takes lhotse's ``load_audio``.  Off by default: it bypasses a custom audio backend for those files.
+    Same batches, same manifests, same archive bytes either way; measured with real WAV decoding in the workers the ring moves 13.7 k / 20 k
     cuts/s (float32 / int16 corpus) where the DataLoader moves 5-6 k / 8-10 k (profiles/r06_ring_loader_ab.txt).
 
     ``loader_start_method`` (round 6): how the DataLoader's worker processes are started -- ``None`` = ``"fork"`` (what lhotse's driver
@@ -926,7 +987,7 @@ def compute_and_store_features_batch(
             warnings.warn(f"lhotse_amd.compute_and_store_features_batch: /dev/shm has {room >> 20} MiB free, the ring loader wants {want} MiB; "
                           "using the DataLoader", RuntimeWarning, stacklevel=3)
             return None
-        return RingLoader(LoadCutsIntoSlot(template_base, frame_shift), num_workers, slot_bytes, per_worker * num_workers, start_method=loader_kw.get("multiprocessing_context"),
+        return RingLoader(LoadCutsIntoSlot(template_base, frame_shift, pcm16=wav_pcm16), num_workers, slot_bytes, per_worker * num_workers, start_method=loader_kw.get("multiprocessing_context"),
                           worker_init_fn=worker_init_fn, preload=["lhotse", "lhotse.dataset", "lhotse_amd.storage"])
 
     def ring_extract(ring, writer, half: bool, template_of):
@@ -943,7 +1004,9 @@ def compute_and_store_features_batch(
             if "audio" in meta:  # (a batch that did not fit a slot / is not mono float32: it came by pickle)
                 pending, frames = _batch_features_pending(extractor, meta["audio"], sr, None, half=half)
             else:
-                pending, frames = _packed_features_pending(extractor, rb.data.view(np.float32), meta["offs"], meta["lens"], sr, half=half)
+                if meta.get("pcm16"):
+                    TEMPLATE_STATS["pcm16_batches"] = TEMPLATE_STATS.get("pcm16_batches", 0) + 1
+                pending, frames = _packed_features_pending(extractor, rb.data.view(np.int16 if meta.get("pcm16") else np.float32), meta["offs"], meta["lens"], sr, half=half)
             _pin_ring(ring, extractor)
             return writer, batch_cuts, _SlotPending(pending, rb), frames, template_of(pending, sr), meta["frags"]
 

@@ -879,3 +879,50 @@ def test_ring_loader_serves_lhotse_s_own_storage_types_too(tmp_path, cutset, cpu
     # without a manifest path (an in-memory CutSet comes back), still through the ring
     c = S.compute_and_store_features_batch(many, ex, tmp_path / "mem", batch_duration=4.0, num_workers=2, storage_type=NumpyFilesWriter)
     assert len(made) == 2 and [x.id for x in c] == [x.id for x in cuts]
+
+
+def test_pcm16_wav_route_of_the_ring_loader(tmp_path, cutset, cpu_device, lhotse_mod):
+    """`wav_pcm16=True`: a batch whose cuts are all plain mono 16-bit PCM .wav segments is read as int16 straight into the ring slot (the device
+    converts x / 32768, exact); `pcm16_wav_segment` gives exactly the samples of which `cut.load_audio()` returns x / 32768 -- whole
+    recordings and sub-segments -- and declines everything lhotse would have to fix up, transform, mix or refuse; the driver then stores
+    the same bytes under the same manifest lines as the float32 route."""
+    import lhotse_amd as LA
+    from lhotse import CutSet, MonoCut, Recording
+    from lhotse.audio import AudioSource
+    from lhotse_amd import storage as S
+
+    cuts = list(cutset)
+    for c in cuts:
+        x = S.pcm16_wav_segment(c, MonoCut)
+        assert x is not None and x.dtype == np.int16 and np.array_equal(x.astype(np.float32) / 32768.0, c.load_audio()[0])
+    sub = cuts[3].truncate(offset=0.25, duration=1.0)  # a sub-segment of the 2 s recording
+    x = S.pcm16_wav_segment(sub, MonoCut)
+    assert x is not None and x.shape == (16000,) and np.array_equal(x.astype(np.float32) / 32768.0, sub.load_audio()[0])
+    tail = cuts[2].truncate(offset=0.5)  # up to the (odd-length) end
+    assert np.array_equal(S.pcm16_wav_segment(tail, MonoCut).astype(np.float32) / 32768.0, tail.load_audio()[0])
+    # declined: a speed-perturbed cut (transforms), a recording whose manifest overstates the file, a padded cut (not a MonoCut)
+    assert S.pcm16_wav_segment(cuts[0].perturb_speed(1.1), MonoCut) is None
+    ghost = Recording(id="ghost", sources=[AudioSource(type="file", channels=[0], source=cuts[0].recording.sources[0].source)], sampling_rate=16000, num_samples=32000, duration=2.0)
+    assert S.pcm16_wav_segment(MonoCut(id="g", start=0, duration=2.0, channel=0, recording=ghost), MonoCut) is None
+    assert S.pcm16_wav_segment(cuts[0].pad(duration=3.0), MonoCut) is None
+    # the worker side: an all-WAV batch arrives as int16, a batch with one declined cut takes lhotse's route (float32) as a whole
+    out = np.zeros(1 << 20, dtype=np.uint8)
+    load = S.LoadCutsIntoSlot(None, 0.01, pcm16=True)
+    used, meta = load(cuts[:3], out)
+    assert meta["pcm16"] is True and meta["kept"] == [0, 1, 2] and meta["lens"].tolist() == [c.num_samples for c in cuts[:3]]
+    flat = out[:used].view(np.int16)
+    for c, o, n in zip(cuts[:3], meta["offs"].tolist(), meta["lens"].tolist()):
+        assert o % 8 == 0 and np.array_equal(flat[o : o + n].astype(np.float32) / 32768.0, c.load_audio()[0])
+    used, meta = load([cuts[0], cuts[1].perturb_speed(0.9)], out)
+    assert "pcm16" not in meta and np.array_equal(out[:used].view(np.float32)[: cuts[0].num_samples], cuts[0].load_audio()[0])
+    # the driver: same manifests, same archive bytes
+    many = CutSet.from_cuts([c.with_id(f"{c.id}-{k}") for k in range(3) for c in cuts] + [sub.with_id("sub")])
+    ex = LA.HipFbank(LA.HipFbankConfig(device="cpu"))
+    kw = dict(batch_duration=4.0, num_workers=2)
+    a = list(S.compute_and_store_features_batch(many, ex, tmp_path / "f32", manifest_path=tmp_path / "f32.jsonl.gz", **kw))
+    before = S.TEMPLATE_STATS.get("pcm16_batches", 0)
+    b = list(S.compute_and_store_features_batch(many, ex, tmp_path / "i16", manifest_path=tmp_path / "i16.jsonl.gz", wav_pcm16=True, **kw))
+    assert S.TEMPLATE_STATS.get("pcm16_batches", 0) - before >= 4  # (the batches really came as int16)
+    assert [c.id for c in a] == [c.id for c in b] and len(a) == 16
+    assert (tmp_path / "i16.hfa").read_bytes() == (tmp_path / "f32.hfa").read_bytes()
+    assert [ln.replace(str(tmp_path / "i16"), "@") for ln in _lines(tmp_path / "i16.jsonl.gz")] == [ln.replace(str(tmp_path / "f32"), "@") for ln in _lines(tmp_path / "f32.jsonl.gz")]
